@@ -1,0 +1,115 @@
+"""Loads libpogs_amd.so (the HIP engine) and declares its C ABI (include/pogs_amd.h).
+
+There is no CPU fallback: if the library is missing the import fails loudly,
+exactly like the reference package does when libpogs_cpu.so is absent
+(python/pogs/graph.py:69-76).
+"""
+import ctypes
+import os
+import sys
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libpogs_amd.so")
+
+# PyTorch ships its own libamdhip64/librccl.  If torch is (going to be) used in
+# this process it must be the first to load the HIP runtime, otherwise two
+# runtimes end up in one address space and device pointers cannot be shared.
+if "torch" not in sys.modules and os.environ.get("POGS_AMD_NO_TORCH_PRELOAD", "0") != "1":
+    try:  # pragma: no cover - depends on the environment
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "pogs_amd: %s not found. Build it with:\n"
+        "  python -m pogs_amd.build        (needs hipcc; cross-compiles for gfx950 without a GPU)\n" % LIB_PATH
+    )
+
+lib = ctypes.CDLL(LIB_PATH)
+
+c_int, c_uint, c_size_t, c_double, c_float, c_void_p, c_char = (
+    ctypes.c_int, ctypes.c_uint, ctypes.c_size_t, ctypes.c_double, ctypes.c_float, ctypes.c_void_p, ctypes.c_char)
+
+UNIQUE_ID_BYTES = 128
+F32, F64 = 0, 1
+HOST, DEVICE = 0, 1
+COL_MAJ, ROW_MAJ = 0, 1
+PROJ_DEFAULT, PROJ_DIRECT, PROJ_CGLS = 0, 1, 2
+
+
+class PogsAmdDist(ctypes.Structure):
+    _fields_ = [("rank", c_int), ("world", c_int), ("m_global", c_size_t), ("unique_id", c_char * UNIQUE_ID_BYTES)]
+
+
+class PogsAmdOptions(ctypes.Structure):
+    _fields_ = [("device", c_int), ("projector", c_int), ("profile", c_int), ("reserved", c_int * 5)]
+
+
+class PogsAmdStats(ctypes.Structure):
+    _fields_ = [
+        ("t_total_s", c_double), ("t_init_s", c_double), ("t_loop_s", c_double), ("t_h2d_s", c_double),
+        ("iterations", c_uint), ("exact_iters", c_uint), ("norm_est_iters", c_uint), ("rho_updates", c_uint),
+        ("cg_iters", ctypes.c_ulonglong), ("matvecs", ctypes.c_ulonglong), ("matvecs_init", ctypes.c_ulonglong),
+        ("rho_final", c_double), ("nrmA", c_double),
+        ("stream_ms", c_double), ("stream_launches", ctypes.c_ulonglong), ("stream_bytes", c_double),
+        ("equil_ms", c_double), ("normest_ms", c_double), ("gram_ms", c_double), ("chol_ms", c_double),
+        ("trtri_ms", c_double), ("gram_flops", c_double), ("reserved", c_double * 8),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+def _dense_sig(real):
+    return [c_int, c_size_t, c_size_t, c_void_p] + [c_void_p] * 5 + [c_void_p] + [c_void_p] * 5 + [c_void_p] + \
+        [real, real, real, c_uint, c_uint, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+
+
+def _sparse_sig(real):
+    return [c_int, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p] + [c_void_p] * 5 + [c_void_p] + \
+        [c_void_p] * 5 + [c_void_p] + [real, real, real, c_uint, c_uint, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+
+
+lib.PogsD.argtypes = _dense_sig(c_double)
+lib.PogsS.argtypes = _dense_sig(c_float)
+lib.PogsSparseD.argtypes = _sparse_sig(c_double)
+lib.PogsSparseS.argtypes = _sparse_sig(c_float)
+for _f in (lib.PogsD, lib.PogsS, lib.PogsSparseD, lib.PogsSparseS):
+    _f.restype = c_int
+
+lib.PogsAmdDistUniqueId.argtypes = [c_void_p]
+lib.PogsAmdCreateDense.argtypes = [ctypes.POINTER(c_void_p), c_int, c_int, c_size_t, c_size_t, c_void_p, c_int,
+                                   ctypes.POINTER(PogsAmdOptions), ctypes.POINTER(PogsAmdDist)]
+lib.PogsAmdCreateSparse.argtypes = [ctypes.POINTER(c_void_p), c_int, c_int, c_size_t, c_size_t, c_size_t, c_void_p,
+                                    c_void_p, c_void_p, c_int, ctypes.POINTER(PogsAmdOptions)]
+lib.PogsAmdSolve.argtypes = [c_void_p] + [c_void_p] * 12 + [c_double, c_double, c_double, c_uint, c_uint, c_int, c_int,
+                                                            c_void_p, c_void_p, c_void_p, c_void_p,
+                                                            ctypes.POINTER(c_double), ctypes.POINTER(c_uint)]
+lib.PogsAmdBeginRun.argtypes = [c_void_p] + [c_void_p] * 12 + [c_double, c_double, c_double, c_uint, c_int, c_int]
+lib.PogsAmdIterate.argtypes = [c_void_p, c_uint, ctypes.POINTER(c_double), ctypes.POINTER(c_uint)]
+lib.PogsAmdGetStats.argtypes = [c_void_p, ctypes.POINTER(PogsAmdStats)]
+lib.PogsAmdResetStats.argtypes = [c_void_p]
+lib.PogsAmdDestroy.argtypes = [c_void_p]
+lib.PogsAmdDestroy.restype = None
+lib.PogsAmdLastError.restype = ctypes.c_char_p
+lib.PogsAmdProxEval.argtypes = [c_int, c_size_t] + [c_void_p] * 6 + [c_double, c_void_p, c_void_p]
+lib.PogsAmdFuncEval.argtypes = [c_int, c_size_t] + [c_void_p] * 6 + [c_void_p, ctypes.POINTER(c_double)]
+lib.PogsAmdGetEquil.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_double)]
+lib.PogsAmdProject.argtypes = [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p]
+lib.PogsAmdMul.argtypes = [c_void_p, c_char, c_double, c_void_p, c_double, c_void_p]
+lib.PogsAmdRandUniform.argtypes = [c_int, c_size_t, c_void_p]
+
+# Every symbol include/pogs_amd.h declares (checked by tests/test_abi.py).
+ABI_SYMBOLS = [
+    "PogsD", "PogsS", "PogsSparseD", "PogsSparseS",
+    "PogsAmdDistUniqueId", "PogsAmdCreateDense", "PogsAmdCreateSparse", "PogsAmdSolve", "PogsAmdBeginRun",
+    "PogsAmdIterate", "PogsAmdGetStats", "PogsAmdResetStats", "PogsAmdDestroy", "PogsAmdLastError",
+    "PogsAmdProxEval", "PogsAmdFuncEval", "PogsAmdGetEquil", "PogsAmdProject", "PogsAmdMul", "PogsAmdRandUniform",
+]
+
+
+def last_error():
+    msg = lib.PogsAmdLastError()
+    return msg.decode() if msg else ""

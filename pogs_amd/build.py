@@ -1,0 +1,76 @@
+"""Builds pogs_amd/libpogs_amd.so from pogs_amd/csrc/*.hip for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the
+resulting .so travels to the GPU box with the repo snapshot (it is git-ignored,
+not gpurun-ignored).  Usage: python -m pogs_amd.build [--force]
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(_HERE, "libpogs_amd.so")
+SOURCES = ["abi.hip", "dense.hip", "sparse.hip", "gemm.hip", "vec_kernels.hip", "dist.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _newest_dep():
+    t = 0.0
+    for root in (CSRC, os.path.join(_HERE, "..", "include")):
+        for f in os.listdir(root):
+            if f.endswith((".h", ".hip")):
+                t = max(t, os.path.getmtime(os.path.join(root, f)))
+    return t
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    return obj
+
+
+def build(force=False, verbose=False):
+    """Compile (if stale) and return the path of libpogs_amd.so."""
+    dep = _newest_dep()
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= dep:
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    todo = []
+    objs = []
+    headers_newer = max((os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h")),
+                        default=0.0)
+    headers_newer = max(headers_newer, os.path.getmtime(os.path.join(_HERE, "..", "include", "pogs_amd.h")))
+    for src in SOURCES:
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(obj)
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
+            os.path.getmtime(os.path.join(CSRC, src)), headers_newer)
+        if stale:
+            todo.append(src)
+    if verbose:
+        print("pogs_amd.build: compiling", todo, file=sys.stderr)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as ex:
+        list(ex.map(_compile, todo))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,347 @@
+// extern "C" entry points (include/pogs_amd.h).  No exception crosses this file.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+#include "prox.h"
+#include "vec_kernels.h"
+
+namespace pogs_amd {
+
+SolverBase *make_dense_solver(int dtype, int ord, size_t m, size_t n, const void *A, int mem,
+                              const PogsAmdOptions *opt, const PogsAmdDist *dist);
+SolverBase *make_sparse_solver(int dtype, int ord, size_t m, size_t n, size_t nnz, const void *data,
+                               const int *ptr, const int *ind, int mem, const PogsAmdOptions *opt);
+
+// gsl::rand (src/cpu/include/gsl/gsl_rand.h:8-16): a fresh
+// std::default_random_engine (libstdc++: minstd_rand0, x <- 16807 x mod 2^31-1,
+// seed 1) feeding uniform_real_distribution<T>(0,1) = generate_canonical: one
+// draw per float, two per double.  Restated so the Norm2Est start vector does
+// not depend on the C++ standard library in use.
+namespace {
+struct MinStd0 {
+  uint64_t s = 1;
+  uint32_t next() {
+    s = (s * 16807ull) % 2147483647ull;
+    return static_cast<uint32_t>(s);
+  }
+};
+}  // namespace
+void rand_uniform_host(float *x, size_t n) {
+  MinStd0 g;
+  const float r = static_cast<float>(2147483646.0L);
+  for (size_t i = 0; i < n; ++i) {
+    float v = static_cast<float>(g.next() - 1u) / r;
+    if (v >= 1.0f) v = std::nextafter(1.0f, 0.0f);
+    x[i] = v;
+  }
+}
+void rand_uniform_host(double *x, size_t n) {
+  MinStd0 g;
+  const double r = 2147483646.0;
+  for (size_t i = 0; i < n; ++i) {
+    const double lo = static_cast<double>(g.next() - 1u);
+    const double hi = static_cast<double>(g.next() - 1u);
+    double v = (lo + hi * r) / (r * r);
+    if (v >= 1.0) v = std::nextafter(1.0, 0.0);
+    x[i] = v;
+  }
+}
+
+namespace {
+
+thread_local std::string g_last_error;
+
+template <typename F>
+int guarded(F &&fn) {
+  try {
+    g_last_error.clear();
+    return fn();
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    std::fprintf(stderr, "pogs_amd: %s\n", e.what());
+    return POGS_ERROR;
+  } catch (...) {
+    g_last_error = "unknown error";
+    std::fprintf(stderr, "pogs_amd: unknown error\n");
+    return POGS_ERROR;
+  }
+}
+
+SolveParams make_params(double rho, double abs_tol, double rel_tol, unsigned max_iter, unsigned verbose,
+                        int adaptive_rho, int gap_stop) {
+  SolveParams p;
+  p.rho = rho; p.abs_tol = abs_tol; p.rel_tol = rel_tol;
+  p.max_iter = max_iter == 0 ? 1 : max_iter;
+  p.verbose = verbose;
+  p.adaptive_rho = adaptive_rho != 0;
+  p.gap_stop = gap_stop != 0;
+  return p;
+}
+
+// One-shot dense solve: src/interface_c/pogs_c.cpp:9-55.
+template <typename T>
+int pogs_dense(enum ORD ord, size_t m, size_t n, const T *A, const T *f_a, const T *f_b, const T *f_c,
+               const T *f_d, const T *f_e, const enum FUNCTION *f_h, const T *g_a, const T *g_b, const T *g_c,
+               const T *g_d, const T *g_e, const enum FUNCTION *g_h, T rho, T abs_tol, T rel_tol,
+               unsigned max_iter, unsigned verbose, int adaptive_rho, int gap_stop, T *x, T *y, T *l, T *optval,
+               unsigned *final_iter) {
+  return guarded([&]() {
+    std::unique_ptr<SolverBase> s(make_dense_solver(sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64, ord, m, n, A,
+                                                    POGS_AMD_HOST, nullptr, nullptr));
+    FnHost f{f_a, f_b, f_c, f_d, f_e, reinterpret_cast<const int *>(f_h)};
+    FnHost g{g_a, g_b, g_c, g_d, g_e, reinterpret_cast<const int *>(g_h)};
+    double ov = 0;
+    const int st = s->solve(f, g, make_params(rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop),
+                            x, y, l, nullptr, &ov, final_iter);
+    *optval = static_cast<T>(ov);
+    return st;
+  });
+}
+
+// One-shot sparse solve: src/interface_c/pogs_c.cpp:57-108.
+template <typename T>
+int pogs_sparse(enum ORD ord, size_t m, size_t n, size_t nnz, const T *data, const int *ptr, const int *ind,
+                const T *f_a, const T *f_b, const T *f_c, const T *f_d, const T *f_e, const enum FUNCTION *f_h,
+                const T *g_a, const T *g_b, const T *g_c, const T *g_d, const T *g_e, const enum FUNCTION *g_h,
+                T rho, T abs_tol, T rel_tol, unsigned max_iter, unsigned verbose, int adaptive_rho, int gap_stop,
+                T *x, T *y, T *l, T *optval, unsigned *final_iter) {
+  return guarded([&]() {
+    std::unique_ptr<SolverBase> s(make_sparse_solver(sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64, ord, m, n, nnz,
+                                                     data, ptr, ind, POGS_AMD_HOST, nullptr));
+    FnHost f{f_a, f_b, f_c, f_d, f_e, reinterpret_cast<const int *>(f_h)};
+    FnHost g{g_a, g_b, g_c, g_d, g_e, reinterpret_cast<const int *>(g_h)};
+    double ov = 0;
+    const int st = s->solve(f, g, make_params(rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop),
+                            x, y, l, nullptr, &ov, final_iter);
+    *optval = static_cast<T>(ov);
+    return st;
+  });
+}
+
+template <typename T>
+void prox_eval_host(size_t n, const int *h, const void *a, const void *b, const void *c, const void *d,
+                    const void *e, double rho, const void *in, void *out, double *fsum) {
+  POGS_CHECK(n < (1u << 31), "n too large");
+  hipStream_t s = nullptr;
+  const int cnt = static_cast<int>(n);
+  FnBuf<T> fb;
+  fb.alloc(n);
+  DevBuf<T> vin(n), vout(n);
+  auto up = [&](void *dst, const void *src, size_t bytes) {
+    POGS_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+  };
+  up(fb.h.p, h, n * sizeof(int));
+  up(fb.a.p, a, n * sizeof(T)); up(fb.b.p, b, n * sizeof(T)); up(fb.c.p, c, n * sizeof(T));
+  up(fb.d.p, d, n * sizeof(T)); up(fb.e.p, e, n * sizeof(T));
+  up(vin.p, in, n * sizeof(T));
+  // clamp c, e >= 0 as FunctionObj's constructor does (prox_lib.h:62-69): scale by 1.
+  DevBuf<T> ones(n);
+  launch_fill<T>(ones.p, static_cast<T>(1), n, s);
+  launch_scale_objective<T>(fb.view(), fb.a.p, fb.c.p, fb.d.p, fb.e.p, ones.p, cnt, false, s);
+  if (out) {
+    launch_prox_eval<T>(cnt, fb.view(), static_cast<T>(rho), vin.p, vout.p, s);
+    POGS_HIP_CHECK(hipMemcpyAsync(out, vout.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+  }
+  if (fsum) {
+    const int blocks = vec_blocks(cnt);
+    DevBuf<double> part(blocks), tot(1);
+    launch_func_eval<T>(cnt, fb.view(), vin.p, part.p, s);
+    SumJob j{part.p, blocks, 1, tot.p};
+    launch_sum_jobs(&j, 1, s);
+    POGS_HIP_CHECK(hipMemcpyAsync(fsum, tot.p, sizeof(double), hipMemcpyDeviceToHost, s));
+    POGS_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  POGS_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+}  // namespace
+}  // namespace pogs_amd
+
+using namespace pogs_amd;
+
+extern "C" {
+
+int PogsD(enum ORD ord, size_t m, size_t n, const double *A, const double *f_a, const double *f_b,
+          const double *f_c, const double *f_d, const double *f_e, const enum FUNCTION *f_h, const double *g_a,
+          const double *g_b, const double *g_c, const double *g_d, const double *g_e, const enum FUNCTION *g_h,
+          double rho, double abs_tol, double rel_tol, unsigned int max_iter, unsigned int verbose,
+          int adaptive_rho, int gap_stop, double *x, double *y, double *l, double *optval,
+          unsigned int *final_iter) {
+  return pogs_dense<double>(ord, m, n, A, f_a, f_b, f_c, f_d, f_e, f_h, g_a, g_b, g_c, g_d, g_e, g_h, rho, abs_tol,
+                            rel_tol, max_iter, verbose, adaptive_rho, gap_stop, x, y, l, optval, final_iter);
+}
+
+int PogsS(enum ORD ord, size_t m, size_t n, const float *A, const float *f_a, const float *f_b, const float *f_c,
+          const float *f_d, const float *f_e, const enum FUNCTION *f_h, const float *g_a, const float *g_b,
+          const float *g_c, const float *g_d, const float *g_e, const enum FUNCTION *g_h, float rho, float abs_tol,
+          float rel_tol, unsigned int max_iter, unsigned int verbose, int adaptive_rho, int gap_stop, float *x,
+          float *y, float *l, float *optval, unsigned int *final_iter) {
+  return pogs_dense<float>(ord, m, n, A, f_a, f_b, f_c, f_d, f_e, f_h, g_a, g_b, g_c, g_d, g_e, g_h, rho, abs_tol,
+                           rel_tol, max_iter, verbose, adaptive_rho, gap_stop, x, y, l, optval, final_iter);
+}
+
+int PogsSparseD(enum ORD ord, size_t m, size_t n, size_t nnz, const double *data, const int *ptr, const int *ind,
+                const double *f_a, const double *f_b, const double *f_c, const double *f_d, const double *f_e,
+                const enum FUNCTION *f_h, const double *g_a, const double *g_b, const double *g_c,
+                const double *g_d, const double *g_e, const enum FUNCTION *g_h, double rho, double abs_tol,
+                double rel_tol, unsigned int max_iter, unsigned int verbose, int adaptive_rho, int gap_stop,
+                double *x, double *y, double *l, double *optval, unsigned int *final_iter) {
+  return pogs_sparse<double>(ord, m, n, nnz, data, ptr, ind, f_a, f_b, f_c, f_d, f_e, f_h, g_a, g_b, g_c, g_d, g_e,
+                             g_h, rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop, x, y, l, optval,
+                             final_iter);
+}
+
+int PogsSparseS(enum ORD ord, size_t m, size_t n, size_t nnz, const float *data, const int *ptr, const int *ind,
+                const float *f_a, const float *f_b, const float *f_c, const float *f_d, const float *f_e,
+                const enum FUNCTION *f_h, const float *g_a, const float *g_b, const float *g_c, const float *g_d,
+                const float *g_e, const enum FUNCTION *g_h, float rho, float abs_tol, float rel_tol,
+                unsigned int max_iter, unsigned int verbose, int adaptive_rho, int gap_stop, float *x, float *y,
+                float *l, float *optval, unsigned int *final_iter) {
+  return pogs_sparse<float>(ord, m, n, nnz, data, ptr, ind, f_a, f_b, f_c, f_d, f_e, f_h, g_a, g_b, g_c, g_d, g_e,
+                            g_h, rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop, x, y, l, optval,
+                            final_iter);
+}
+
+int PogsAmdDistUniqueId(char *out) {
+  return guarded([&]() {
+    DistComm::unique_id(out);
+    return 0;
+  });
+}
+
+int PogsAmdCreateDense(PogsAmdSolver **out, int dtype, enum ORD ord, size_t m, size_t n, const void *A, int mem,
+                       const PogsAmdOptions *opt, const PogsAmdDist *dist) {
+  return guarded([&]() {
+    *out = nullptr;
+    std::unique_ptr<PogsAmdSolver> h(new PogsAmdSolver);
+    h->impl.reset(make_dense_solver(dtype, ord, m, n, A, mem, opt, dist));
+    *out = h.release();
+    return 0;
+  });
+}
+
+int PogsAmdCreateSparse(PogsAmdSolver **out, int dtype, enum ORD ord, size_t m, size_t n, size_t nnz,
+                        const void *data, const int *ptr, const int *ind, int mem, const PogsAmdOptions *opt) {
+  return guarded([&]() {
+    *out = nullptr;
+    std::unique_ptr<PogsAmdSolver> h(new PogsAmdSolver);
+    h->impl.reset(make_sparse_solver(dtype, ord, m, n, nnz, data, ptr, ind, mem, opt));
+    *out = h.release();
+    return 0;
+  });
+}
+
+int PogsAmdSolve(PogsAmdSolver *s, const void *f_a, const void *f_b, const void *f_c, const void *f_d,
+                 const void *f_e, const int *f_h, const void *g_a, const void *g_b, const void *g_c,
+                 const void *g_d, const void *g_e, const int *g_h, double rho, double abs_tol, double rel_tol,
+                 unsigned int max_iter, unsigned int verbose, int adaptive_rho, int gap_stop, void *x, void *y,
+                 void *l, void *mu, double *optval, unsigned int *final_iter) {
+  return guarded([&]() {
+    POGS_CHECK(s && s->impl, "null solver");
+    FnHost f{f_a, f_b, f_c, f_d, f_e, f_h};
+    FnHost g{g_a, g_b, g_c, g_d, g_e, g_h};
+    return s->impl->solve(f, g, make_params(rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop), x,
+                          y, l, mu, optval, final_iter);
+  });
+}
+
+int PogsAmdBeginRun(PogsAmdSolver *s, const void *f_a, const void *f_b, const void *f_c, const void *f_d,
+                    const void *f_e, const int *f_h, const void *g_a, const void *g_b, const void *g_c,
+                    const void *g_d, const void *g_e, const int *g_h, double rho, double abs_tol, double rel_tol,
+                    unsigned int max_iter, int adaptive_rho, int gap_stop) {
+  return guarded([&]() {
+    POGS_CHECK(s && s->impl, "null solver");
+    FnHost f{f_a, f_b, f_c, f_d, f_e, f_h};
+    FnHost g{g_a, g_b, g_c, g_d, g_e, g_h};
+    s->impl->begin_run(f, g, make_params(rho, abs_tol, rel_tol, max_iter, 0, adaptive_rho, gap_stop));
+    return 0;
+  });
+}
+
+int PogsAmdIterate(PogsAmdSolver *s, unsigned int iters, double *seconds, unsigned int *solves_completed) {
+  return guarded([&]() {
+    POGS_CHECK(s && s->impl, "null solver");
+    s->impl->iterate(iters, seconds, solves_completed);
+    return 0;
+  });
+}
+
+int PogsAmdGetStats(const PogsAmdSolver *s, PogsAmdStats *out) {
+  return guarded([&]() {
+    POGS_CHECK(s && s->impl && out, "null argument");
+    *out = const_cast<PogsAmdSolver *>(s)->impl->stats();
+    return 0;
+  });
+}
+
+int PogsAmdResetStats(PogsAmdSolver *s) {
+  return guarded([&]() {
+    POGS_CHECK(s && s->impl, "null solver");
+    PogsAmdStats &st = s->impl->stats();
+    st.t_loop_s = 0; st.iterations = 0; st.exact_iters = 0; st.rho_updates = 0;
+    st.cg_iters = 0; st.matvecs = 0;
+    st.stream_ms = 0; st.stream_launches = 0; st.stream_bytes = 0;
+    return 0;
+  });
+}
+
+void PogsAmdDestroy(PogsAmdSolver *s) {
+  try { delete s; } catch (...) {}
+}
+
+const char *PogsAmdLastError(void) { return g_last_error.c_str(); }
+
+int PogsAmdProxEval(int dtype, size_t n, const int *h, const void *a, const void *b, const void *c, const void *d,
+                    const void *e, double rho, const void *in, void *out) {
+  return guarded([&]() {
+    if (dtype == POGS_AMD_F32) prox_eval_host<float>(n, h, a, b, c, d, e, rho, in, out, nullptr);
+    else prox_eval_host<double>(n, h, a, b, c, d, e, rho, in, out, nullptr);
+    return 0;
+  });
+}
+
+int PogsAmdFuncEval(int dtype, size_t n, const int *h, const void *a, const void *b, const void *c, const void *d,
+                    const void *e, const void *in, double *out) {
+  return guarded([&]() {
+    if (dtype == POGS_AMD_F32) prox_eval_host<float>(n, h, a, b, c, d, e, 1.0, in, nullptr, out);
+    else prox_eval_host<double>(n, h, a, b, c, d, e, 1.0, in, nullptr, out);
+    return 0;
+  });
+}
+
+int PogsAmdGetEquil(const PogsAmdSolver *s, void *A_eq, void *d, void *e, double *nrmA) {
+  return guarded([&]() {
+    POGS_CHECK(s && s->impl, "null solver");
+    const_cast<PogsAmdSolver *>(s)->impl->get_equil(A_eq, d, e, nrmA);
+    return 0;
+  });
+}
+
+int PogsAmdProject(PogsAmdSolver *s, const void *x0, const void *y0, double tol, void *x, void *y) {
+  return guarded([&]() {
+    POGS_CHECK(s && s->impl, "null solver");
+    s->impl->project(x0, y0, tol, x, y);
+    return 0;
+  });
+}
+
+int PogsAmdMul(PogsAmdSolver *s, char trans, double alpha, const void *x, double beta, void *y) {
+  return guarded([&]() {
+    POGS_CHECK(s && s->impl, "null solver");
+    s->impl->mul(trans, alpha, x, beta, y);
+    return 0;
+  });
+}
+
+int PogsAmdRandUniform(int dtype, size_t n, void *out_host) {
+  return guarded([&]() {
+    if (dtype == POGS_AMD_F32) rand_uniform_host(static_cast<float *>(out_host), n);
+    else rand_uniform_host(static_cast<double *>(out_host), n);
+    return 0;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,644 @@
+// Dense graph-form ADMM solver with the direct (Gram + Cholesky) projector.
+//
+// Reference call stack being replaced:
+//   PogsD/PogsS -> Pogs<T,O> (src/interface_c/pogs_c.cpp:9-55)
+//     -> PogsImplementation::_Init (src/cpu/pogs.cpp:59-88)
+//          MatrixDense::Init/Equil (src/cpu/matrix/matrix_dense.cpp:85-200)
+//          Norm2Est (src/cpu/include/equil_helper.h:107-135)
+//          ProjectorDirect::Init (src/cpu/projector/projector_direct_dense.cpp:45-84)
+//     -> PogsImplementation::Solve (src/cpu/pogs.cpp:91-581)
+//          ProjectorDirect::Project (projector_direct_dense.cpp:87-175)
+//
+// HBM layout: A_eq row-major m x lda (lda = n rounded up to 16 bytes, padding
+// columns zero); x-sized vectors have n_pad entries with zero padding;
+// W = inv(chol(A^T A + I)) lower-triangular and U = W^T, both n x n_pad.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+
+#include "engine.h"
+#include "gemm.h"
+#include "ops.h"
+#include "reduce.h"
+#include "stream.h"
+#include "vec_kernels.h"
+
+namespace pogs_amd {
+
+void rand_uniform_host(float *x, size_t n);
+void rand_uniform_host(double *x, size_t n);
+
+namespace {
+
+// A <- diag(d) A diag(e), accumulating sum of squares of the result
+// (MultDiag + NormEst(kNormFro), matrix_dense.cpp:181,184,215-237).
+template <typename T>
+__global__ void __launch_bounds__(256) scale_de_kernel(T *A, size_t lda, int m, int n_pad, const T *d,
+                                                       const T *e, double *partials) {
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = Vec16<T>::N;
+  __shared__ double s_red[4];
+  const int vpr = n_pad / VEC;
+  double acc[1] = {0.0};
+  for (int row = blockIdx.x; row < m; row += gridDim.x) {
+    const T di = d[row];
+    T *rp = A + static_cast<size_t>(row) * lda;
+    for (int v = threadIdx.x; v < vpr; v += 256) {
+      V a = *reinterpret_cast<V *>(rp + v * VEC);
+      const V ev = *reinterpret_cast<const V *>(e + v * VEC);
+      T *ap = reinterpret_cast<T *>(&a);
+      const T *ep = reinterpret_cast<const T *>(&ev);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        const T val = ap[c] * (di * ep[c]);
+        ap[c] = val;
+        acc[0] += static_cast<double>(val) * val;
+      }
+      *reinterpret_cast<V *>(rp + v * VEC) = a;
+    }
+  }
+  dev::block_sum<1, 256>(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) scale_all_kernel(T *A, size_t count_vec, T s) {
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = Vec16<T>::N;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count_vec;
+       i += static_cast<size_t>(gridDim.x) * 256) {
+    V a = reinterpret_cast<V *>(A)[i];
+    T *ap = reinterpret_cast<T *>(&a);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) ap[c] *= s;
+    reinterpret_cast<V *>(A)[i] = a;
+  }
+}
+
+template <typename T>
+class DenseSolver final : public SolverBase {
+ public:
+  DenseSolver(int ord, size_t m, size_t n, const void *A, int mem, const PogsAmdOptions *opt,
+              const PogsAmdDist *dist) {
+    const double t0 = wall_s();
+    ctx_.init(opt ? opt->device : -1, opt ? opt->profile != 0 : false);
+    m_ = static_cast<int>(m);
+    n_ = static_cast<int>(n);
+    POGS_CHECK(m > 0 && n > 0 && m < (1u << 31) && n < (1u << 31), "bad dimensions");
+    if (dist && dist->world > 1) {
+      ctx_.dist.init(dist->rank, dist->world, dist->unique_id);
+      ctx_.m_global = dist->m_global;
+    } else {
+      ctx_.m_global = m;
+    }
+    tall_ = ctx_.m_global > n;   // projector_direct_dense.cpp:53,122,128
+    POGS_CHECK(tall_ || ctx_.dist.world() == 1, "row sharding needs m > n (SURVEY.md section 8(e))");
+    constexpr int VEC = Vec16<T>::N;
+    n_pad_ = static_cast<int>(round_up(n, VEC));
+    k_ = tall_ ? n_ : m_;
+    k_pad_ = static_cast<int>(round_up(k_, VEC));
+    lda_ = n_pad_;
+    planA_ = make_stream_plan<T>(n_pad_, ctx_.num_cu);
+    POGS_CHECK(planA_.ok, "n too large for the register-tiled streaming kernel");
+    upload(ord, A, mem);
+    ctx_.stats.t_h2d_s = wall_s() - t0;
+    alloc_state();
+    equilibrate();
+    norm_est();
+    factor();
+    ctx_.sync();
+    ctx_.stats.t_init_s = wall_s() - t0;
+  }
+
+  int dtype() const override { return sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64; }
+  PogsAmdStats &stats() override { return ctx_.stats; }
+
+  int solve(const FnHost &f, const FnHost &g, const SolveParams &p, void *x, void *y, void *l, void *mu,
+            double *optval, unsigned *final_iter) override {
+    const double t0 = wall_s();
+    load_problem(f, g, p);
+    cold_start();
+    ctx_.sync();
+    const double t1 = wall_s();
+    if (p.verbose > 1 && ctx_.dist.rank() == 0)
+      std::printf(" Iter | pri res | pri tol | dua res | dua tol |   gap   | eps gap\n");
+    while (!iteration(p.verbose)) {}
+    ctx_.sync();
+    const double t2 = wall_s();
+    const int status = epilogue(x, y, l, mu, optval);
+    *final_iter = ctl_.k;
+    PogsAmdStats &st = ctx_.stats;
+    st.t_loop_s = t2 - t1;
+    st.t_total_s = st.t_init_s + (wall_s() - t0);
+    st.iterations = ctl_.k + 1;
+    st.exact_iters = ctl_.exact_iters;
+    st.rho_updates = ctl_.rho_updates;
+    st.rho_final = ctl_.rho;
+    collect_stream_timer();
+    if (p.verbose > 0 && ctx_.dist.rank() == 0)
+      std::printf("POGS-AMD dense/direct: status %d, iter %u, init %.3e s, loop %.3e s\n", status, ctl_.k,
+                  st.t_init_s, st.t_loop_s);
+    return status;
+  }
+
+  void begin_run(const FnHost &f, const FnHost &g, const SolveParams &p) override {
+    load_problem(f, g, p);
+    cold_start();
+    ctx_.sync();
+  }
+
+  void iterate(unsigned iters, double *seconds, unsigned *solves) override {
+    unsigned done = 0;
+    ctx_.sync();
+    const double t0 = wall_s();
+    for (unsigned i = 0; i < iters; ++i) {
+      if (ctl_.finished) {
+        cold_start();
+        ++done;
+      }
+      iteration(0);
+    }
+    ctx_.sync();
+    const double t1 = wall_s();
+    if (seconds) *seconds = t1 - t0;
+    if (solves) *solves = done;
+    ctx_.stats.t_loop_s += t1 - t0;
+    ctx_.stats.iterations += iters;
+    collect_stream_timer();
+  }
+
+  void get_equil(void *A_eq, void *d, void *e, double *nrmA) override {
+    ctx_.sync();
+    if (A_eq)
+      POGS_HIP_CHECK(hipMemcpy2D(A_eq, n_ * sizeof(T), A_.p, lda_ * sizeof(T), n_ * sizeof(T), m_,
+                                 hipMemcpyDeviceToHost));
+    if (d) POGS_HIP_CHECK(hipMemcpy(d, d_.p, m_ * sizeof(T), hipMemcpyDeviceToHost));
+    if (e) POGS_HIP_CHECK(hipMemcpy(e, e_.p, n_ * sizeof(T), hipMemcpyDeviceToHost));
+    if (nrmA) *nrmA = nrmA_;
+  }
+
+  // (x, y) = Proj_{y = A x}(x0, y0), projector_direct_dense.cpp:122-127.
+  void project(const void *x0, const void *y0, double, void *x, void *y) override {
+    hipStream_t s = ctx_.stream;
+    POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, x0, n_ * sizeof(T), hipMemcpyHostToDevice, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, y0, m_ * sizeof(T), hipMemcpyHostToDevice, s));
+    if (tall_) {
+      gemv_t_partials(ytemp_.p);
+      finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, 0, 0);
+      solve_gram(rhs_.p, xtemp_.p, GemvNOp<T>{1, 0, x_[0].p}, nullptr);
+      StreamArgs<T> a = argsA();
+      a.xin = x_[0].p;
+      launch_stream<T, true, false, false, kFull>(planA_, a, GemvNOp<T>{1, 0, y_[0].p}, s);
+    } else {
+      // projector_direct_dense.cpp:128-135: t = (A A^T + I)^{-1} (A x0 - y0); x = x0 - A^T t; y = y0 + t
+      StreamArgs<T> a = argsA();
+      a.xin = xtemp_.p;
+      launch_stream<T, true, false, false, kFull>(planA_, a, ResidOp<T>{ytemp_.p, rhs_.p}, s);
+      solve_gram(rhs_.p, static_cast<const T *>(nullptr), GemvNOp<T>{1, 0, tmpn_.p}, nullptr);
+      launch_axpby<T>(m_, static_cast<T>(1), ytemp_.p, static_cast<T>(0), y_[0].p, s);
+      launch_axpby<T>(m_, static_cast<T>(1), tmpn_.p, static_cast<T>(1), y_[0].p, s);
+      gemv_t_partials(tmpn_.p);
+      launch_axpby<T>(n_, static_cast<T>(1), xtemp_.p, static_cast<T>(0), x_[0].p, s);
+      finish_cols(StoreColOp<T>{static_cast<T>(-1), static_cast<T>(1), x_[0].p, n_}, nullptr, 0, 0);
+    }
+    POGS_HIP_CHECK(hipMemcpyAsync(x, x_[0].p, n_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(y, y_[0].p, m_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    ctx_.sync();
+  }
+
+  void mul(char trans, double alpha, const void *x, double beta, void *y) override {
+    hipStream_t s = ctx_.stream;
+    const bool tr = (trans == 't' || trans == 'T');
+    if (!tr) {
+      POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, x, n_ * sizeof(T), hipMemcpyHostToDevice, s));
+      POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, y, m_ * sizeof(T), hipMemcpyHostToDevice, s));
+      StreamArgs<T> a = argsA();
+      a.xin = xtemp_.p;
+      launch_stream<T, true, false, false, kFull>(planA_, a,
+                                                  GemvNOp<T>{static_cast<T>(alpha), static_cast<T>(beta), ytemp_.p}, s);
+      POGS_HIP_CHECK(hipMemcpyAsync(y, ytemp_.p, m_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    } else {
+      POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, x, m_ * sizeof(T), hipMemcpyHostToDevice, s));
+      POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, y, n_ * sizeof(T), hipMemcpyHostToDevice, s));
+      gemv_t_partials(ytemp_.p);
+      if (ctx_.dist.world() > 1) {
+        finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, 0, 0);
+        launch_axpby<T>(n_, static_cast<T>(alpha), rhs_.p, static_cast<T>(beta), xtemp_.p, s);
+      } else {
+        finish_cols(StoreColOp<T>{static_cast<T>(alpha), static_cast<T>(beta), xtemp_.p, n_}, nullptr, 0, 0);
+      }
+      POGS_HIP_CHECK(hipMemcpyAsync(y, xtemp_.p, n_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    }
+    ctx_.sync();
+  }
+
+ private:
+  // ---- setup ---------------------------------------------------------------
+  void upload(int ord, const void *A, int mem) {
+    hipStream_t s = ctx_.stream;
+    A_.alloc(static_cast<size_t>(m_) * lda_);
+    const hipMemcpyKind kind = (mem == POGS_AMD_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (ord == ROW_MAJ) {
+      if (lda_ != static_cast<size_t>(n_)) A_.zero(s);
+      POGS_HIP_CHECK(hipMemcpy2DAsync(A_.p, lda_ * sizeof(T), A, n_ * sizeof(T), n_ * sizeof(T), m_, kind, s));
+    } else {
+      // column-major m x n == row-major n x m: stage and transpose on the device.
+      DevBuf<T> stage;
+      const T *src = static_cast<const T *>(A);
+      if (mem != POGS_AMD_DEVICE) {
+        stage.alloc(static_cast<size_t>(m_) * n_);
+        POGS_HIP_CHECK(hipMemcpyAsync(stage.p, A, static_cast<size_t>(m_) * n_ * sizeof(T), kind, s));
+        src = stage.p;
+      }
+      if (lda_ != static_cast<size_t>(n_)) A_.zero(s);
+      launch_transpose<T>(src, m_, n_, m_, A_.p, lda_, s);
+      ctx_.sync();
+    }
+    ctx_.sync();
+  }
+
+  void alloc_state() {
+    hipStream_t s = ctx_.stream;
+    const size_t np = n_pad_;
+    for (int i = 0; i < 2; ++i) { x_[i].alloc(np); y_[i].alloc(m_); x_[i].zero(s); y_[i].zero(s); }
+    xt_.alloc(np); yt_.alloc(m_); xtemp_.alloc(np); ytemp_.alloc(m_);
+    const size_t kp = std::max<size_t>(np, k_pad_);
+    x12_.alloc(np); y12_.alloc(m_); rhs_.alloc(kp); tvec_.alloc(kp); tmpn_.alloc(kp);
+    xt_.zero(s); yt_.zero(s); xtemp_.zero(s); ytemp_.zero(s); x12_.zero(s); y12_.zero(s);
+    rhs_.zero(s); tvec_.zero(s); tmpn_.zero(s);
+    d_.alloc(m_); e_.alloc(np); e_.zero(s);
+    xout_.alloc(np); yout_.alloc(m_); lout_.alloc(m_); muout_.alloc(np);
+    f_.alloc(m_); g_.alloc(n_); fs_.alloc(m_); gs_.alloc(n_);
+    colpart_.alloc(static_cast<size_t>(planA_.grid_max) * np);
+    const size_t vb = vec_blocks(n_) + vec_blocks(m_);
+    ctx_.ensure_spart(std::max<size_t>(static_cast<size_t>(planA_.grid_max) * 4 + 4096, vb * 3 + 64));
+  }
+
+  StreamArgs<T> argsA() const {
+    StreamArgs<T> a;
+    a.A = A_.p; a.lda = lda_; a.m = m_; a.n_pad = n_pad_;
+    a.xin = nullptr; a.xin_add = nullptr; a.xin_nrm2 = nullptr;
+    a.col_partials = colpart_.p; a.scalar_partials = ctx_.spart.p;
+    return a;
+  }
+
+  // Second stage of a column-sum pass.  With row shards the totals are
+  // all-reduced (together with scalar slots [yslot, yslot+count) if count > 0)
+  // before op runs.
+  template <typename ColOp>
+  void finish_cols(const ColOp &op, double *colop_scalar_out, int yslot, int yslot_count,
+                   int nparts_override = -1) {
+    hipStream_t s = ctx_.stream;
+    const int nparts = nparts_override > 0 ? nparts_override : stream_grid<false, true>(planA_, m_);
+    double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 4;  // separate scratch region
+    if (ctx_.dist.world() == 1) {
+      launch_reduce_cols<T, ColOp>(colpart_.p, nparts, n_pad_, op, sp, s);
+    } else {
+      launch_reduce_cols<T, StoreColOp<T>>(colpart_.p, nparts, n_pad_, StoreColOp<T>{1, 0, tmpn_.p, n_}, sp, s);
+      if (yslot_count > 0) ctx_.dist.allreduce2<T>(tmpn_.p, n_pad_, ctx_.S.p + yslot, yslot_count, s);
+      else ctx_.dist.allreduce(tmpn_.p, n_pad_, s);
+      launch_reduce_cols<T, ColOp>(tmpn_.p, 1, n_pad_, op, sp, s);
+    }
+    if (ColOp::NS > 0 && colop_scalar_out) {
+      SumJob j{sp, reduce_cols_grid(n_pad_, Vec16<T>::N), ColOp::NS, colop_scalar_out};
+      launch_sum_jobs(&j, 1, s);
+    }
+  }
+
+  // col partials <- A^T u (ACC-only pass)
+  void gemv_t_partials(const T *u) {
+    StreamArgs<T> a = argsA();
+    ctx_.stream_timer.begin(ctx_.stream);
+    launch_stream<T, false, true, false, kFull>(planA_, a, GemvTOp<T>{1, u}, ctx_.stream);
+    ctx_.stream_timer.end(ctx_.stream);
+  }
+
+  void sum_row_scalars(int grid, int ns, double *out) {
+    SumJob j{ctx_.spart.p, grid, ns, out};
+    launch_sum_jobs(&j, 1, ctx_.stream);
+  }
+
+  // MatrixDense::Equil without materialising A.^2 (matrix_dense.cpp:116-200,
+  // equil_helper.h:140-164): 51 passes over A instead of 100.
+  void equilibrate() {
+    hipStream_t s = ctx_.stream;
+    PhaseTimer pt(s);
+    const double mg = static_cast<double>(ctx_.m_global), nn = n_;
+    const T ce = static_cast<T>(1e-4) * static_cast<T>(mg + nn) / static_cast<T>(mg);   // equil_helper.h:152-153
+    const T cd = static_cast<T>(1e-4) * static_cast<T>(mg + nn) / static_cast<T>(nn);   // :159-160
+    const int gridACC = stream_grid<false, true>(planA_, m_);
+    const int gridBOTH = stream_grid<true, true>(planA_, m_);
+    StreamArgs<T> a = argsA();
+    launch_stream<T, false, true, true, kFull>(planA_, a, OnesOp<T>{}, s);
+    finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_}, nullptr, 0, 0, gridACC);
+    for (int k = 0; k < 50; ++k) {
+      a.xin = e_.p;
+      if (k < 49) {
+        launch_stream<T, true, true, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
+        finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_}, nullptr, 0, 0, gridBOTH);
+      } else {
+        launch_stream<T, true, false, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
+      }
+    }
+    ctx_.stats.matvecs_init += 51;
+    launch_sqrt_inplace<T>(d_.p, m_, s);                                  // matrix_dense.cpp:176-177
+    launch_sqrt_inplace<T>(e_.p, n_, s);
+    const int sgrid = std::min(m_, ctx_.num_cu * 8);
+    hipLaunchKernelGGL(scale_de_kernel<T>, dim3(sgrid), dim3(256), 0, s, A_.p, lda_, m_, n_pad_, d_.p, e_.p,
+                       ctx_.spart.p);
+    sum_row_scalars(sgrid, 1, ctx_.S.p + kFro2);
+    if (ctx_.dist.world() > 1) ctx_.dist.allreduce(ctx_.S.p + kFro2, 1, s);
+    const double *S = ctx_.fetch_scalars();
+    const T normA = static_cast<T>(std::sqrt(S[kFro2])) /
+                    std::sqrt(static_cast<T>(std::min<double>(mg, nn)));   // :215-218
+    const size_t nvec = static_cast<size_t>(m_) * lda_ / Vec16<T>::N;
+    hipLaunchKernelGGL(scale_all_kernel<T>, dim3(ctx_.num_cu * 8), dim3(256), 0, s, A_.p, nvec,
+                       static_cast<T>(1) / normA);                         // :186
+    const T invs = static_cast<T>(1) / std::sqrt(normA);                   // :191-192
+    launch_scal<T>(d_.p, invs, m_, s);
+    launch_scal<T>(e_.p, invs, n_, s);
+    ctx_.stats.equil_ms = pt.stop_ms();
+  }
+
+  // Norm2Est (equil_helper.h:107-135), one fused pass per power iteration.
+  void norm_est() {
+    hipStream_t s = ctx_.stream;
+    PhaseTimer pt(s);
+    std::vector<T> x0(n_pad_, 0);
+    rand_uniform_host(x0.data(), n_);
+    POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, x0.data(), n_pad_ * sizeof(T), hipMemcpyHostToDevice, s));
+    ctx_.sync();
+    T *xa = xtemp_.p, *xb = rhs_.p;
+    const T kTol = static_cast<T>(1e-4);
+    T norm_est = 0, last;
+    const int grid = stream_grid<true, true>(planA_, m_);
+    unsigned i = 0;
+    for (i = 0; i < 50; ++i) {
+      last = norm_est;
+      StreamArgs<T> a = argsA();
+      a.xin = xa;
+      a.xin_nrm2 = (i == 0) ? nullptr : ctx_.S.p + kPowX2;
+      launch_stream<T, true, true, false, kFull>(planA_, a, PowerRowOp<T>{}, s);
+      sum_row_scalars(grid, 1, ctx_.S.p + kPowSx2);
+      // kPowX2 is read by the pass above (x normalisation) and rewritten here.
+      // with shards |Sx|^2 travels in the same RCCL group as the column totals
+      finish_cols(PowerColOp<T>{xb, n_}, ctx_.S.p + kPowX2, kPowSx2, 1, grid);
+      const double *S = ctx_.fetch_scalars();
+      const T normx = static_cast<T>(std::sqrt(S[kPowX2]));
+      const T normSx = static_cast<T>(std::sqrt(S[kPowSx2]));
+      norm_est = normx / normSx;
+      std::swap(xa, xb);
+      ctx_.stats.matvecs_init += 1;
+      if (std::abs(last - norm_est) < kTol * norm_est) { ++i; break; }
+    }
+    nrmA_ = norm_est;
+    ctx_.stats.nrmA = nrmA_;
+    ctx_.stats.norm_est_iters = i;
+    // leave the work vectors clean
+    xtemp_.zero(s);
+    rhs_.zero(s);
+    ctx_.stats.normest_ms = pt.stop_ms();
+  }
+
+  // ProjectorDirect::Init + the first-call factorisation (s = 1 always,
+  // pogs.cpp:293,296): G = A^T A (m > n) or A A^T (m <= n) on MFMA tiles,
+  // L L^T = G + I, W = L^{-1}, U = W^T.
+  void factor() {
+    hipStream_t s = ctx_.stream;
+    const size_t ld = k_pad_;
+    planW_ = make_stream_plan<T>(k_pad_, ctx_.num_cu);
+    POGS_CHECK(planW_.ok, "min(m, n) too large for the register-tiled streaming kernel");
+    DevBuf<T> G(static_cast<size_t>(k_) * ld);
+    G.zero(s);
+    {
+      PhaseTimer pt(s);
+      if (tall_) {
+        GemmArgs<T> g{n_, n_, m_, A_.p, lda_, A_.p, lda_, G.p, ld, static_cast<T>(1), static_cast<T>(0)};
+        launch_gemm<T>(true, true, true, g, s);
+      } else {
+        GemmArgs<T> g{m_, m_, n_, A_.p, lda_, A_.p, lda_, G.p, ld, static_cast<T>(1), static_cast<T>(0)};
+        launch_gemm<T>(false, false, true, g, s);
+      }
+      if (ctx_.dist.world() > 1) ctx_.dist.allreduce(G.p, static_cast<size_t>(k_) * ld, s);
+      ctx_.stats.gram_ms = pt.stop_ms();
+      ctx_.stats.gram_flops = static_cast<double>(tall_ ? m_ : n_) * k_ * k_;
+    }
+    launch_add_diag<T>(G.p, ld, k_, static_cast<T>(1), s);               // projector_direct_dense.cpp:118-119
+    W_.alloc(static_cast<size_t>(k_) * ld);
+    W_.zero(s);
+    {
+      PhaseTimer pt(s);
+      cholesky_lower<T>(G.p, ld, k_, W_.p, ld, s);
+      ctx_.stats.chol_ms = pt.stop_ms();
+    }
+    {
+      PhaseTimer pt(s);
+      DevBuf<T> tmp(static_cast<size_t>(k_) * ld);
+      trtri_lower<T>(G.p, ld, k_, W_.p, ld, tmp.p, s);
+      U_.alloc(static_cast<size_t>(k_) * ld);
+      U_.zero(s);
+      launch_transpose<T>(W_.p, ld, k_, k_, U_.p, ld, s);
+      ctx_.stats.trtri_ms = pt.stop_ms();
+    }
+    ctx_.sync();
+  }
+
+  // x_out-functor( U (W (rhs + add)) ): the two triangular products that replace
+  // linalg_cholesky_svx (gsl_linalg.h:57-61).
+  template <typename TailOp>
+  void solve_gram(const T *rhs, const T *add, const TailOp &tail, double *tail_scalars) {
+    hipStream_t s = ctx_.stream;
+    StreamArgs<T> a;
+    a.A = W_.p; a.lda = k_pad_; a.m = k_; a.n_pad = k_pad_;
+    a.xin = rhs; a.xin_add = add; a.xin_nrm2 = nullptr;
+    a.col_partials = nullptr; a.scalar_partials = ctx_.spart.p;
+    launch_stream<T, true, false, false, kLower>(planW_, a, GemvNOp<T>{1, 0, tvec_.p}, s);
+    a.A = U_.p;
+    a.xin = tvec_.p; a.xin_add = nullptr;
+    launch_stream<T, true, false, false, kUpper>(planW_, a, tail, s);
+    if (TailOp::NS > 0 && tail_scalars) {
+      SumJob j{ctx_.spart.p, stream_grid<true, false>(planW_, k_), TailOp::NS, tail_scalars};
+      launch_sum_jobs(&j, 1, s);
+    }
+  }
+
+  // ---- per-solve -----------------------------------------------------------
+  void load_problem(const FnHost &f, const FnHost &g, const SolveParams &p) {
+    hipStream_t s = ctx_.stream;
+    auto up = [&](FnBuf<T> &dst, const FnHost &src, int cnt) {
+      POGS_HIP_CHECK(hipMemcpyAsync(dst.h.p, src.h, cnt * sizeof(int), hipMemcpyHostToDevice, s));
+      POGS_HIP_CHECK(hipMemcpyAsync(dst.a.p, src.a, cnt * sizeof(T), hipMemcpyHostToDevice, s));
+      POGS_HIP_CHECK(hipMemcpyAsync(dst.b.p, src.b, cnt * sizeof(T), hipMemcpyHostToDevice, s));
+      POGS_HIP_CHECK(hipMemcpyAsync(dst.c.p, src.c, cnt * sizeof(T), hipMemcpyHostToDevice, s));
+      POGS_HIP_CHECK(hipMemcpyAsync(dst.d.p, src.d, cnt * sizeof(T), hipMemcpyHostToDevice, s));
+      POGS_HIP_CHECK(hipMemcpyAsync(dst.e.p, src.e, cnt * sizeof(T), hipMemcpyHostToDevice, s));
+    };
+    up(f_, f, m_);
+    up(g_, g, n_);
+    // scaled copies: h and b shared with the originals (pogs.cpp:608-617)
+    launch_scale_objective<T>(f_.view(), fs_.a.p, fs_.c.p, fs_.d.p, fs_.e.p, d_.p, m_, true, s);
+    launch_scale_objective<T>(g_.view(), gs_.a.p, gs_.c.p, gs_.d.p, gs_.e.p, e_.p, n_, false, s);
+    ctl_ = AdmmControl<T>();
+    ctl_.abs_tol = static_cast<T>(p.abs_tol);
+    ctl_.rel_tol = static_cast<T>(p.rel_tol);
+    ctl_.max_iter = p.max_iter;
+    ctl_.adaptive_rho = p.adaptive_rho;
+    ctl_.gap_stop = p.gap_stop;
+    ctl_.rho0 = static_cast<T>(p.rho);
+    ctl_.m_glob = ctx_.m_global;
+    ctl_.n = n_;
+    ctx_.sync();  // the host coefficient arrays may be freed by the caller afterwards
+  }
+  FnView<T> fview() const { return FnView<T>{f_.h.p, fs_.a.p, f_.b.p, fs_.c.p, fs_.d.p, fs_.e.p}; }
+  FnView<T> gview() const { return FnView<T>{g_.h.p, gs_.a.p, g_.b.p, gs_.c.p, gs_.d.p, gs_.e.p}; }
+
+  void cold_start() {  // z = 0, zt = 0 (pogs.cpp:71-73,121-126)
+    hipStream_t s = ctx_.stream;
+    for (int i = 0; i < 2; ++i) { x_[i].zero(s); y_[i].zero(s); }
+    xt_.zero(s); yt_.zero(s); xtemp_.zero(s); ytemp_.zero(s);
+    cur_ = 0;
+    zt_scale_ = 1;
+    ctl_.reset();
+  }
+
+  // One ADMM iteration (pogs.cpp:253-470).  Returns true when the solve stops.
+  bool iteration(unsigned verbose) {
+    hipStream_t s = ctx_.stream;
+    const int nw = cur_ ^ 1;
+    const bool multi = ctx_.dist.world() > 1;
+    // (1) prox + gap/tolerance sums + over-relaxation
+    AdmmPreArgs<T> pa;
+    pa.n_x = n_; pa.n_y = m_;
+    pa.g = gview(); pa.f = fview();
+    pa.x_cur = x_[cur_].p; pa.y_cur = y_[cur_].p;
+    pa.xt = xt_.p; pa.yt = yt_.p;
+    pa.zt_scale = zt_scale_;
+    pa.x12 = x12_.p; pa.y12 = y12_.p;
+    pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
+    pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
+    pa.partials = ctx_.spart.p;
+    pa.blocks_x = vec_blocks(n_);
+    launch_admm_pre<T>(pa, s);
+    {
+      SumJob j[2] = {{ctx_.spart.p, pa.blocks_x, 3, ctx_.S.p + kGapX},
+                     {ctx_.spart.p + static_cast<size_t>(pa.blocks_x) * 3, vec_blocks(m_), 3, ctx_.S.p + kGapY}};
+      launch_sum_jobs(j, 2, s);
+    }
+    if (tall_) {
+      // (2) projection: x = (G + I)^{-1} (xtemp + A^T ytemp), y = A x   (projector_direct_dense.cpp:122-127)
+      gemv_t_partials(ytemp_.p);
+      finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, kGapY, 3);   // with shards: gap/norm sums ride along
+      solve_gram(rhs_.p, xtemp_.p, ProjTailOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p}, ctx_.S.p + kDXprev2);
+      StreamArgs<T> a = argsA();
+      a.xin = x_[nw].p;
+      ctx_.stream_timer.begin(s);
+      launch_stream<T, true, false, false, kFull>(planA_, a,
+                                                  ProjTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p}, s);
+      ctx_.stream_timer.end(s);
+      sum_row_scalars(stream_grid<true, false>(planA_, m_), 2, ctx_.S.p + kDYprev2);
+      if (multi) ctx_.dist.allreduce(ctx_.S.p + kDYprev2, 2, s);
+    } else {
+      // (2') m <= n: t = (A A^T + I)^{-1} (A xtemp - ytemp); x = xtemp - A^T t; y = ytemp + t   (:128-135)
+      StreamArgs<T> a = argsA();
+      a.xin = xtemp_.p;
+      ctx_.stream_timer.begin(s);
+      launch_stream<T, true, false, false, kFull>(planA_, a, ResidOp<T>{ytemp_.p, rhs_.p}, s);
+      ctx_.stream_timer.end(s);
+      solve_gram(rhs_.p, static_cast<const T *>(nullptr),
+                 ProjTailAddOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p}, ctx_.S.p + kDYprev2);
+      gemv_t_partials(tmpn_.p);
+      finish_cols(ProjTailColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_}, ctx_.S.p + kDXprev2, 0, 0);
+    }
+    ctx_.stats.matvecs += 2;
+    const double *S = ctx_.fetch_scalars();
+    ctl_.set_pre(S);
+    bool exact = false;
+    if (ctl_.set_approx(S, nrmA_)) {
+      // (3) exact residuals in one fused pass (pogs.cpp:352-376)
+      StreamArgs<T> a = argsA();
+      a.xin = x12_.p;
+      ctx_.stream_timer.begin(s);
+      launch_stream<T, true, true, false, kFull>(planA_, a,
+                                                 ExactRowOp<T>{y12_.p, yt_.p, y_[cur_].p, zt_scale_}, s);
+      ctx_.stream_timer.end(s);
+      const int grid = stream_grid<true, true>(planA_, m_);
+      sum_row_scalars(grid, 1, ctx_.S.p + kExactR2);
+      finish_cols(ExactColOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_, n_}, ctx_.S.p + kExactS2, kExactR2, 1, grid);
+      ctx_.stats.matvecs += 1;
+      S = ctx_.fetch_scalars();
+      ctl_.set_exact(S);
+      exact = true;
+    }
+    const bool stop = ctl_.check_stop(exact);
+    if (verbose > 1 && ctx_.dist.rank() == 0 &&
+        ((verbose > 2 && ctl_.k % 10 == 0) || ctl_.k % 100 == 0 || ctl_.converged))
+      std::printf("%5u : %.2e  %.2e  %.2e  %.2e  %.2e  %.2e\n", ctl_.k, (double)ctl_.nrm_r, (double)ctl_.eps_pri,
+                  (double)ctl_.nrm_s, (double)ctl_.eps_dua, (double)ctl_.gap, (double)ctl_.eps_gap);
+    if (stop) return true;
+    // (4) dual update already sits in xtemp/ytemp (ProjTailOp): swap roles.
+    std::swap(xt_, xtemp_);
+    std::swap(yt_, ytemp_);
+    cur_ = nw;
+    zt_scale_ = ctl_.adapt();
+    ++ctl_.k;
+    return false;
+  }
+
+  // optval, status, un-scaling, copy out (pogs.cpp:473-482, 510-518, 567-570).
+  int epilogue(void *x, void *y, void *l, void *mu, double *optval) {
+    hipStream_t s = ctx_.stream;
+    const int by = vec_blocks(m_), bx = vec_blocks(n_);
+    launch_func_eval<T>(m_, fview(), y12_.p, ctx_.spart.p, s);
+    launch_func_eval<T>(n_, gview(), x12_.p, ctx_.spart.p + by, s);
+    SumJob j[2] = {{ctx_.spart.p, by, 1, ctx_.S.p + kFvalF}, {ctx_.spart.p + by, bx, 1, ctx_.S.p + kFvalG}};
+    launch_sum_jobs(j, 2, s);
+    if (ctx_.dist.world() > 1) ctx_.dist.allreduce(ctx_.S.p + kFvalF, 1, s);
+    UnscaleArgs<T> u;
+    u.n_x = n_; u.n_y = m_;
+    u.x12 = x12_.p; u.y12 = y12_.p; u.xt = xt_.p; u.yt = yt_.p;
+    u.xprev = x_[cur_].p; u.yprev = y_[cur_].p; u.d = d_.p; u.e = e_.p;
+    u.zt_scale = zt_scale_; u.rho = ctl_.rho;
+    u.x_out = xout_.p; u.y_out = yout_.p; u.l_out = lout_.p; u.mu_out = muout_.p;
+    launch_unscale<T>(u, s);
+    POGS_HIP_CHECK(hipMemcpyAsync(x, xout_.p, n_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(y, yout_.p, m_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(l, lout_.p, m_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (mu) POGS_HIP_CHECK(hipMemcpyAsync(mu, muout_.p, n_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    const double *S = ctx_.fetch_scalars();
+    *optval = static_cast<double>(static_cast<T>(S[kFvalF]) + static_cast<T>(S[kFvalG]));
+    return ctl_.status();
+  }
+
+  void collect_stream_timer() {
+    if (!ctx_.stream_timer.enabled()) return;
+    unsigned long long cnt = 0;
+    ctx_.stats.stream_ms += ctx_.stream_timer.collect_ms(&cnt);
+    ctx_.stats.stream_launches += cnt;
+    ctx_.stats.stream_bytes += static_cast<double>(cnt) * m_ * n_ * sizeof(T);
+  }
+
+  Ctx ctx_;
+  int m_ = 0, n_ = 0, n_pad_ = 0, k_ = 0, k_pad_ = 0;
+  bool tall_ = true;
+  size_t lda_ = 0;
+  StreamPlan planA_, planW_;
+  DevBuf<T> A_, W_, U_, d_, e_, colpart_;
+  DevBuf<T> x_[2], y_[2], xt_, yt_, xtemp_, ytemp_, x12_, y12_, rhs_, tvec_, tmpn_;
+  DevBuf<T> xout_, yout_, lout_, muout_;
+  FnBuf<T> f_, g_, fs_, gs_;
+  AdmmControl<T> ctl_;
+  int cur_ = 0;
+  T zt_scale_ = 1;
+  T nrmA_ = 0;
+};
+
+}  // namespace
+
+SolverBase *make_dense_solver(int dtype, int ord, size_t m, size_t n, const void *A, int mem,
+                              const PogsAmdOptions *opt, const PogsAmdDist *dist) {
+  if (dtype == POGS_AMD_F32) return new DenseSolver<float>(ord, m, n, A, mem, opt, dist);
+  if (dtype == POGS_AMD_F64) return new DenseSolver<double>(ord, m, n, A, mem, opt, dist);
+  throw Error("unknown dtype");
+}
+
+}  // namespace pogs_amd

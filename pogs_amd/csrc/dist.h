@@ -1,0 +1,48 @@
+// RCCL (xGMI) sum all-reduce for the row-sharded solve.
+//
+// The reference is single-process (no collective anywhere);
+// this is the MI355X-native addition of SURVEY.md section 8(e): one process per
+// GPU, A row-sharded, and the only data exchanged per iteration is one n-vector
+// (A_k^T y_k partials) plus a handful of scalars.
+//
+// RCCL is bound at run time with dlopen: if the process already has a librccl
+// (PyTorch ships its own copy) that instance is reused, so the library never
+// ends up with two RCCL / HIP runtimes in one address space.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace pogs_amd {
+
+constexpr int kUniqueIdBytes = 128;
+
+class DistComm {
+ public:
+  DistComm() = default;
+  ~DistComm();
+  DistComm(const DistComm &) = delete;
+  DistComm &operator=(const DistComm &) = delete;
+
+  // Collective: every rank calls with the same unique id.
+  void init(int rank, int world, const char *unique_id);
+  bool active() const { return world_ > 1 || comm_ != nullptr; }
+  int rank() const { return rank_; }
+  int world() const { return world_; }
+
+  // In-place sum all-reduce on `stream`.  No-ops when not initialised.
+  void allreduce(float *buf, size_t count, hipStream_t stream) const;
+  void allreduce(double *buf, size_t count, hipStream_t stream) const;
+  // Two buffers as one RCCL group (one launch).
+  template <typename T>
+  void allreduce2(T *buf, size_t count, double *scalars, size_t nscalars, hipStream_t stream) const;
+
+  static void unique_id(char *out);  // fresh id (rank 0)
+
+ private:
+  void reduce_raw(void *buf, size_t count, int dtype, hipStream_t stream) const;
+  int rank_ = 0, world_ = 1;
+  void *comm_ = nullptr;
+};
+
+}  // namespace pogs_amd

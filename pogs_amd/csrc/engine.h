@@ -1,0 +1,291 @@
+// Engine plumbing shared by the dense and sparse solvers: execution context,
+// host-side ADMM control (stopping rules + adaptive rho), solver base class.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <limits>
+#include <memory>
+#include <vector>
+
+#include "../../include/pogs_amd.h"
+#include "common.h"
+#include "dist.h"
+#include "vec_kernels.h"
+
+namespace pogs_amd {
+
+inline double wall_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// HIP-event stopwatch for kernels launched on one stream (profile mode only).
+class EventTimer {
+ public:
+  void enable(bool on) { on_ = on; }
+  bool enabled() const { return on_; }
+  void begin(hipStream_t s) {
+    if (!on_) return;
+    if (used_ == ev_.size()) {
+      hipEvent_t a, b;
+      POGS_HIP_CHECK(hipEventCreate(&a));
+      POGS_HIP_CHECK(hipEventCreate(&b));
+      ev_.push_back({a, b});
+    }
+    POGS_HIP_CHECK(hipEventRecord(ev_[used_].first, s));
+  }
+  void end(hipStream_t s) {
+    if (!on_) return;
+    POGS_HIP_CHECK(hipEventRecord(ev_[used_].second, s));
+    ++used_;
+  }
+  // Sum of elapsed ms over all recorded pairs; the stream must be idle.
+  double collect_ms(unsigned long long *count) {
+    double tot = 0;
+    for (size_t i = 0; i < used_; ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev_[i].first, ev_[i].second) == hipSuccess) tot += ms;
+    }
+    if (count) *count += used_;
+    used_ = 0;
+    return tot;
+  }
+  ~EventTimer() {
+    for (auto &p : ev_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  }
+ private:
+  bool on_ = false;
+  size_t used_ = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_;
+};
+
+// One-shot event pair for setup phases.
+struct PhaseTimer {
+  hipEvent_t a = nullptr, b = nullptr;
+  hipStream_t s;
+  explicit PhaseTimer(hipStream_t st) : s(st) {
+    POGS_HIP_CHECK(hipEventCreate(&a));
+    POGS_HIP_CHECK(hipEventCreate(&b));
+    POGS_HIP_CHECK(hipEventRecord(a, s));
+  }
+  double stop_ms() {
+    POGS_HIP_CHECK(hipEventRecord(b, s));
+    POGS_HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    POGS_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms;
+  }
+  ~PhaseTimer() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+};
+
+struct Ctx {
+  int device = 0;
+  int num_cu = 256;
+  hipStream_t stream = nullptr;
+  DistComm dist;
+  size_t m_global = 0;
+  DevBuf<double> S;            // device scalar block [kNumSlots]
+  PinnedBuf<double> S_host;    // pinned mirror
+  DevBuf<double> spart;        // scalar partial sums scratch
+  size_t spart_cap = 0;
+  EventTimer stream_timer;
+  PogsAmdStats stats;
+
+  void init(int dev, bool profile) {
+    if (dev >= 0) POGS_HIP_CHECK(hipSetDevice(dev));
+    POGS_HIP_CHECK(hipGetDevice(&device));
+    hipDeviceProp_t prop;
+    POGS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    POGS_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    S.alloc(kNumSlots);
+    S.zero(stream);
+    S_host.alloc(kNumSlots);
+    std::memset(&stats, 0, sizeof(stats));
+    stream_timer.enable(profile);
+  }
+  void ensure_spart(size_t count) {
+    if (count > spart_cap) {
+      POGS_HIP_CHECK(hipStreamSynchronize(stream));
+      spart.alloc(count);
+      spart_cap = count;
+    }
+  }
+  // Copies the scalar block to the host and waits for the stream.
+  const double *fetch_scalars() {
+    POGS_HIP_CHECK(hipMemcpyAsync(S_host.p, S.p, kNumSlots * sizeof(double), hipMemcpyDeviceToHost, stream));
+    POGS_HIP_CHECK(hipStreamSynchronize(stream));
+    return S_host.p;
+  }
+  void sync() { POGS_HIP_CHECK(hipStreamSynchronize(stream)); }
+  ~Ctx() {
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+// Host-side scalar logic of PogsImplementation::Solve for a separable objective
+// (kUseExactTol = false): constants pogs.cpp:94-110, tolerances :199-201,270-273,
+// projection tolerance :287-290, stopping rule :379-394, adaptive rho :402-466.
+// Arithmetic is carried out in T exactly where the reference uses T.
+template <typename T>
+struct AdmmControl {
+  // parameters
+  T abs_tol = 0, rel_tol = 0;
+  unsigned max_iter = 0;
+  bool adaptive_rho = true, gap_stop = false;
+  T rho0 = 1;
+  size_t m_glob = 0, n = 0;
+  // state
+  T rho = 1, delta = 0, xi = 1;
+  unsigned k = 0, kd = 0, ku = 0;
+  T prev_nrm_r = 0;
+  T nrm_r = 0, nrm_s = 0, gap = 0, eps_gap = 0, eps_pri = 0, eps_dua = 0;
+  bool converged = false, finished = false;
+  unsigned exact_iters = 0, rho_updates = 0;
+  T sqrtn_atol = 0, sqrtm_atol = 0, sqrtmn_atol = 0;
+
+  static constexpr double kAlphaD = 1.7;
+  T alpha() const { return static_cast<T>(kAlphaD); }
+
+  void reset() {
+    rho = rho0;
+    delta = static_cast<T>(1.05);
+    xi = 1;
+    k = kd = ku = 0;
+    prev_nrm_r = std::numeric_limits<T>::max();
+    converged = finished = false;
+    exact_iters = rho_updates = 0;
+    sqrtn_atol = std::sqrt(static_cast<T>(n)) * abs_tol;
+    sqrtm_atol = std::sqrt(static_cast<T>(m_glob)) * abs_tol;
+    sqrtmn_atol = std::sqrt(static_cast<T>(m_glob + n)) * abs_tol;
+  }
+
+  // After the prox step: S holds the pre-projection sums.
+  void set_pre(const double *S) {
+    gap = std::abs(static_cast<T>(S[kGapX] + S[kGapY]));
+    const T nz = static_cast<T>(std::sqrt(S[kWX2] + S[kWY2]));
+    const T nz12 = static_cast<T>(std::sqrt(S[kHX2] + S[kHY2]));
+    const T ny12 = static_cast<T>(std::sqrt(S[kHY2]));
+    const T nx = static_cast<T>(std::sqrt(S[kWX2]));
+    eps_gap = sqrtmn_atol + rel_tol * nz * nz12;
+    eps_pri = sqrtm_atol + rel_tol * ny12;
+    eps_dua = rho * (sqrtn_atol + rel_tol * nx);
+  }
+  T proj_tol() const {
+    T tol = static_cast<T>(1e-2) * std::pow(std::min(prev_nrm_r, static_cast<T>(1)), static_cast<T>(0.5));
+    return std::max(tol, static_cast<T>(1e-8));
+  }
+  // After the projection: cheap residual bounds; returns whether the exact
+  // residuals must be evaluated.
+  bool set_approx(const double *S, T nrmA) {
+    nrm_s = rho * (nrmA * static_cast<T>(std::sqrt(S[kDYprev2])) + static_cast<T>(std::sqrt(S[kDXprev2])));
+    nrm_r = nrmA * static_cast<T>(std::sqrt(S[kDX12])) + static_cast<T>(std::sqrt(S[kDY12]));
+    return nrm_r < 10 * eps_pri && nrm_s < 10 * eps_dua;
+  }
+  void set_exact(const double *S) {
+    nrm_r = static_cast<T>(std::sqrt(S[kExactR2]));
+    nrm_s = rho * static_cast<T>(std::sqrt(S[kExactS2]));
+    ++exact_iters;
+  }
+  // Returns true when the solve stops at this iteration (k is then final_iter).
+  bool check_stop(bool exact) {
+    converged = exact && nrm_r < eps_pri && nrm_s < eps_dua && (!gap_stop || gap < eps_gap);
+    if (converged || k == max_iter - 1) {
+      finished = true;
+      return true;
+    }
+    return false;
+  }
+  // Adaptive rho; returns the factor zt must be multiplied by (1 = unchanged).
+  T adapt() {
+    T scale = 1;
+    const T kDeltaMin = static_cast<T>(1.05), kGamma = static_cast<T>(1.01), kTau = static_cast<T>(0.8);
+    const T kRhoMin = static_cast<T>(1e-4), kRhoMax = static_cast<T>(1e4), kKappa = static_cast<T>(0.9);
+    const T kOne = 1, kZero = 0;
+    if (adaptive_rho) {
+      const unsigned kRhoUpdateFreq = 50u;
+      const T kRhoChangeMax = static_cast<T>(1.5), kRhoChangeMin = static_cast<T>(0.67);
+      const T kImbalanceThresh = static_cast<T>(10);
+      if (k > 0 && k % kRhoUpdateFreq == 0 && eps_pri > kZero && eps_dua > kZero) {
+        const T pri_n = nrm_r / eps_pri, dua_n = nrm_s / eps_dua;
+        if (pri_n > kZero && dua_n > kZero) {
+          const T imbalance = pri_n / dua_n;
+          if (imbalance > kImbalanceThresh || imbalance < kOne / kImbalanceThresh) {
+            T ratio = std::sqrt(imbalance);
+            ratio = std::max(kRhoChangeMin, std::min(kRhoChangeMax, ratio));
+            T rho_new = rho * ratio;
+            rho_new = std::max(kRhoMin, std::min(kRhoMax, rho_new));
+            if (std::abs(rho_new - rho) / rho > static_cast<T>(0.05)) {
+              scale = rho / rho_new;
+              rho = rho_new;
+              ++rho_updates;
+            }
+          }
+        }
+      } else if (nrm_s < xi * eps_dua && nrm_r > xi * eps_pri && kTau * static_cast<T>(k) > static_cast<T>(kd)) {
+        if (rho < kRhoMax) {
+          rho *= delta;
+          scale = 1 / delta;
+          delta = kGamma * delta;
+          ku = k;
+          ++rho_updates;
+        }
+      } else if (nrm_s > xi * eps_dua && nrm_r < xi * eps_pri && kTau * static_cast<T>(k) > static_cast<T>(ku)) {
+        if (rho > kRhoMin) {
+          rho /= delta;
+          scale = delta;
+          delta = kGamma * delta;
+          kd = k;
+          ++rho_updates;
+        }
+      } else if (nrm_s < xi * eps_dua && nrm_r < xi * eps_pri) {
+        xi *= kKappa;
+      } else {
+        delta = kDeltaMin;
+      }
+    }
+    prev_nrm_r = nrm_r;
+    return scale;
+  }
+  int status() const {
+    if (!converged && k == max_iter - 1) return POGS_MAX_ITER;
+    if (!converged) return POGS_NAN_FOUND;
+    return POGS_SUCCESS;
+  }
+};
+
+struct SolveParams {
+  double rho, abs_tol, rel_tol;
+  unsigned max_iter, verbose;
+  bool adaptive_rho, gap_stop;
+};
+
+struct FnHost {  // host SoA, element type = solver dtype
+  const void *a, *b, *c, *d, *e;
+  const int *h;
+};
+
+// Type-erased solver behind the C handle.
+struct SolverBase {
+  virtual ~SolverBase() {}
+  virtual int dtype() const = 0;
+  virtual int solve(const FnHost &f, const FnHost &g, const SolveParams &p, void *x, void *y, void *l,
+                    void *mu, double *optval, unsigned *final_iter) = 0;
+  virtual void begin_run(const FnHost &f, const FnHost &g, const SolveParams &p) = 0;
+  virtual void iterate(unsigned iters, double *seconds, unsigned *solves) = 0;
+  virtual void get_equil(void *A_eq, void *d, void *e, double *nrmA) = 0;
+  virtual void project(const void *x0, const void *y0, double tol, void *x, void *y) = 0;
+  virtual void mul(char trans, double alpha, const void *x, double beta, void *y) = 0;
+  virtual PogsAmdStats &stats() = 0;
+};
+
+}  // namespace pogs_amd
+
+struct PogsAmdSolver {
+  std::unique_ptr<pogs_amd::SolverBase> impl;
+};

@@ -1,0 +1,57 @@
+// One-time dense factorisation pieces on the matrix cores (gfx950 MFMA):
+//   * gemm:      C = alpha * op(A) op(B) + beta * C, f32 / f64 MFMA 16x16x4 tiles
+//   * gram:      G = A^T A (lower tiles) -- the SYRK of
+//                src/cpu/projector/projector_direct_dense.cpp:62-81
+//   * cholesky:  blocked right-looking L L^T = G (gsl_linalg.h:36-55), with the
+//                diagonal-block inverses kept so the panel solve is a GEMM
+//   * trtri:     W = L^{-1} by recursive doubling, so that the per-iteration
+//                triangular solves (gsl_linalg.h:57-61, two cblas_?trsv) become
+//                two fully parallel triangular matrix-vector products.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace pogs_amd {
+
+template <typename T>
+struct GemmArgs {
+  int M, N, K;
+  const T *A; size_t lda;
+  const T *B; size_t ldb;
+  T *C; size_t ldc;
+  T alpha, beta;
+};
+
+// A_KMAJ: op(A)(i,k) = A[k*lda + i], else A[i*lda + k].
+// B_KMAJ: op(B)(k,j) = B[k*ldb + j], else B[j*ldb + k].
+// lower_only: only tiles with tile_j <= tile_i are computed (M == N).
+// All leading dimensions and sub-matrix offsets must keep 16-byte alignment.
+template <typename T>
+void launch_gemm(bool a_kmaj, bool b_kmaj, bool lower_only, const GemmArgs<T> &g, hipStream_t s);
+
+// Diagonal block size of the blocked Cholesky / first TRTRI level.
+template <typename T> struct CholBlock;
+template <> struct CholBlock<float> { static constexpr int NB = 128; };
+template <> struct CholBlock<double> { static constexpr int NB = 64; };
+
+// G (n x n, lower triangle valid, leading dim ldg) is overwritten by its Cholesky
+// factor L; W (n x n, leading dim ldw, zero-initialised by the caller) receives
+// the inverses of L's diagonal blocks.
+template <typename T>
+void cholesky_lower(T *G, size_t ldg, int n, T *W, size_t ldw, hipStream_t s);
+
+// Completes W = L^{-1} (lower triangular) from the diagonal-block inverses.
+// tmp must hold n * ldw elements.
+template <typename T>
+void trtri_lower(const T *L, size_t ldg, int n, T *W, size_t ldw, T *tmp, hipStream_t s);
+
+// out (cols x rows, ld_out) = in^T, in is rows x cols with ld_in.
+template <typename T>
+void launch_transpose(const T *in, size_t ld_in, int rows, int cols, T *out, size_t ld_out, hipStream_t s);
+
+// G[i][i] += v
+template <typename T>
+void launch_add_diag(T *G, size_t ldg, int n, T v, hipStream_t s);
+
+}  // namespace pogs_amd

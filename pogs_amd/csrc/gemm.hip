@@ -1,0 +1,350 @@
+// MFMA GEMM + blocked Cholesky + triangular inverse (see gemm.h).
+#include "gemm.h"
+
+#include <cmath>
+
+namespace pogs_amd {
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef double doublex4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64: one wavefront computes a
+// 16x16 tile, D = A(16x4) B(4x16) + C.  Lane l supplies A[l&15][l>>4] and
+// B[l>>4][l&15]; it owns 4 results in column l&15 at the rows given by row().
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  using Acc = floatx4;
+  static __device__ __forceinline__ Acc mma(float a, float b, Acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+template <> struct Mma<double> {
+  using Acc = doublex4;
+  static __device__ __forceinline__ Acc mma(double a, double b, Acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LS = 144;  // LDS row stride: 144 = 16 mod 32 (f32) and 288 = 32 mod 64 (f64 dwords)
+constexpr int GT = 256;  // threads per workgroup: 4 waves as 2 x 2, each 64 x 64
+
+template <typename T> struct TileVec {
+  static constexpr int VEC = Vec16<T>::N;
+  static constexpr int NVT = (BM * BK) / VEC / GT;  // 16-byte vectors per thread per operand tile
+};
+
+// Loads a 128 (i) x 16 (k) operand tile into registers, zero-filling out of range.
+template <typename T, bool KMAJ>
+__device__ __forceinline__ void load_tile(const T *__restrict__ P, size_t ld, int i0, int k0, int ilim,
+                                          int klim, typename Vec16<T>::type (&regs)[TileVec<T>::NVT]) {
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = TileVec<T>::VEC;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < TileVec<T>::NVT; ++p) {
+    const int q = t + GT * p;
+    T tmp[VEC];
+    if (KMAJ) {
+      constexpr int per_row = BM / VEC;
+      const int gk = k0 + q / per_row;
+      const int gi = i0 + (q % per_row) * VEC;
+      const T *src = P + static_cast<size_t>(gk) * ld + gi;
+      if (gk < klim && gi + VEC <= ilim) {
+        regs[p] = *reinterpret_cast<const V *>(src);
+        continue;
+      }
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) tmp[c] = (gk < klim && gi + c < ilim) ? src[c] : static_cast<T>(0);
+    } else {
+      constexpr int per_row = BK / VEC;
+      const int gi = i0 + q / per_row;
+      const int gk = k0 + (q % per_row) * VEC;
+      const T *src = P + static_cast<size_t>(gi) * ld + gk;
+      if (gi < ilim && gk + VEC <= klim) {
+        regs[p] = *reinterpret_cast<const V *>(src);
+        continue;
+      }
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) tmp[c] = (gi < ilim && gk + c < klim) ? src[c] : static_cast<T>(0);
+    }
+    regs[p] = *reinterpret_cast<const V *>(tmp);
+  }
+}
+
+// Writes the register tile to LDS as sm[k][i] (row stride LS).
+template <typename T, bool KMAJ>
+__device__ __forceinline__ void store_tile(T *sm, const typename Vec16<T>::type (&regs)[TileVec<T>::NVT]) {
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = TileVec<T>::VEC;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < TileVec<T>::NVT; ++p) {
+    const int q = t + GT * p;
+    if (KMAJ) {
+      constexpr int per_row = BM / VEC;
+      const int k = q / per_row, i = (q % per_row) * VEC;
+      *reinterpret_cast<V *>(sm + k * LS + i) = regs[p];
+    } else {
+      constexpr int per_row = BK / VEC;
+      const int i = q / per_row, k = (q % per_row) * VEC;
+      const T *tp = reinterpret_cast<const T *>(&regs[p]);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) sm[(k + c) * LS + i] = tp[c];
+    }
+  }
+}
+
+template <typename T, bool A_KMAJ, bool B_KMAJ, bool LOWER>
+__global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
+  using V = typename Vec16<T>::type;
+  using Acc = typename Mma<T>::Acc;
+  __shared__ __attribute__((aligned(16))) T sA[BK * LS];
+  __shared__ __attribute__((aligned(16))) T sB[BK * LS];
+
+  int ti, tj;
+  if (LOWER) {
+    const int p = blockIdx.x;
+    ti = static_cast<int>((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > p) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= p) ++ti;
+    tj = p - ti * (ti + 1) / 2;
+  } else {
+    const int tiles_n = (g.N + BN - 1) / BN;
+    ti = blockIdx.x / tiles_n;
+    tj = blockIdx.x % tiles_n;
+  }
+  const int i0 = ti * BM, j0 = tj * BN;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int l15 = lane & 15, lk = lane >> 4;
+
+  Acc acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0;
+
+  V ra[TileVec<T>::NVT], rb[TileVec<T>::NVT];
+  const int nk = (g.K + BK - 1) / BK;
+  load_tile<T, A_KMAJ>(g.A, g.lda, i0, 0, g.M, g.K, ra);
+  load_tile<T, B_KMAJ>(g.B, g.ldb, j0, 0, g.N, g.K, rb);
+  store_tile<T, A_KMAJ>(sA, ra);
+  store_tile<T, B_KMAJ>(sB, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      load_tile<T, A_KMAJ>(g.A, g.lda, i0, (kt + 1) * BK, g.M, g.K, ra);
+      load_tile<T, B_KMAJ>(g.B, g.ldb, j0, (kt + 1) * BK, g.N, g.K, rb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      T af[4], bf[4];
+      const T *pa = sA + (ks * 4 + lk) * LS + wm + l15;
+      const T *pb = sB + (ks * 4 + lk) * LS + wn + l15;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) af[a] = pa[a * 16];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[b] = pb[b * 16];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = Mma<T>::mma(af[a], bf[b], acc[a][b]);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      store_tile<T, A_KMAJ>(sA, ra);
+      store_tile<T, B_KMAJ>(sB, rb);
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = i0 + wm + a * 16 + Mma<T>::row(lane, r);
+        const int col = j0 + wn + b * 16 + l15;
+        if (row < g.M && col < g.N) {
+          T *c = g.C + static_cast<size_t>(row) * g.ldc + col;
+          T v = g.alpha * acc[a][b][r];
+          if (g.beta != static_cast<T>(0)) v += g.beta * *c;
+          *c = v;
+        }
+      }
+}
+
+// Unblocked Cholesky of one NB x NB diagonal block held in LDS, followed by the
+// inverse of the triangular factor.  One workgroup.
+template <typename T, int NB>
+__global__ void __launch_bounds__(256) potrf_inv_kernel(T *G, size_t ldg, int nb, T *Winv, size_t ldw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int LD = NB + 1;
+  T *sL = reinterpret_cast<T *>(smem_raw);
+  T *sX = sL + NB * LD;
+  const int t = threadIdx.x;
+  for (int idx = t; idx < nb * nb; idx += 256) {
+    const int r = idx / nb, c = idx % nb;
+    sL[r * LD + c] = (c <= r) ? G[static_cast<size_t>(r) * ldg + c] : static_cast<T>(0);
+    sX[r * LD + c] = 0;
+  }
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    const T ljj = sqrt(sL[j * LD + j]);
+    __syncthreads();
+    const T inv = static_cast<T>(1) / ljj;
+    for (int i = j + 1 + t; i < nb; i += 256) sL[i * LD + j] *= inv;
+    if (t == 0) sL[j * LD + j] = ljj;
+    __syncthreads();
+    const int w = nb - j - 1;
+    for (int idx = t; idx < w * w; idx += 256) {
+      const int i = j + 1 + idx / w, c = j + 1 + idx % w;
+      if (c <= i) sL[i * LD + c] -= sL[i * LD + j] * sL[c * LD + j];
+    }
+    __syncthreads();
+  }
+  // X = L^{-1}: thread c owns column c (forward substitution), loops kept uniform.
+  if (t < nb) {
+    const int c = t;
+    for (int i = 0; i < nb; ++i) {
+      T acc = 0;
+      for (int p = 0; p < i; ++p) {
+        if (p >= c) acc += sL[i * LD + p] * sX[p * LD + c];
+      }
+      if (i == c) sX[i * LD + c] = static_cast<T>(1) / sL[i * LD + i];
+      else if (i > c) sX[i * LD + c] = -acc / sL[i * LD + i];
+    }
+  }
+  __syncthreads();
+  for (int idx = t; idx < nb * nb; idx += 256) {
+    const int r = idx / nb, c = idx % nb;
+    if (c <= r) {
+      G[static_cast<size_t>(r) * ldg + c] = sL[r * LD + c];
+      Winv[static_cast<size_t>(r) * ldw + c] = sX[r * LD + c];
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_kernel(const T *in, size_t ld_in, int rows, int cols, T *out,
+                                                        size_t ld_out) {
+  __shared__ T tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 32; k += 8) {
+    const int r = by + ty + k, c = bx + tx;
+    tile[ty + k][tx] = (r < rows && c < cols) ? in[static_cast<size_t>(r) * ld_in + c] : static_cast<T>(0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 32; k += 8) {
+    const int r = bx + ty + k, c = by + tx;  // out is cols x rows
+    if (r < cols && c < rows) out[static_cast<size_t>(r) * ld_out + c] = tile[tx][ty + k];
+  }
+}
+
+template <typename T>
+__global__ void add_diag_kernel(T *G, size_t ldg, int n, T v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) G[static_cast<size_t>(i) * ldg + i] += v;
+}
+
+template <typename T, bool A_KMAJ, bool B_KMAJ>
+void launch_gemm_ab(bool lower, const GemmArgs<T> &g, hipStream_t s) {
+  const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+  if (tm <= 0 || tn <= 0 || g.K <= 0) return;
+  if (lower) {
+    const int nt = tm * (tm + 1) / 2;
+    hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, true>), dim3(nt), dim3(GT), 0, s, g);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, false>), dim3(tm * tn), dim3(GT), 0, s, g);
+  }
+}
+
+}  // namespace
+
+template <typename T>
+void launch_gemm(bool a_kmaj, bool b_kmaj, bool lower_only, const GemmArgs<T> &g, hipStream_t s) {
+  if (a_kmaj && b_kmaj) launch_gemm_ab<T, true, true>(lower_only, g, s);
+  else if (!a_kmaj && !b_kmaj) launch_gemm_ab<T, false, false>(lower_only, g, s);
+  else if (!a_kmaj && b_kmaj) launch_gemm_ab<T, false, true>(lower_only, g, s);
+  else launch_gemm_ab<T, true, false>(lower_only, g, s);
+}
+
+template <typename T>
+void cholesky_lower(T *G, size_t ldg, int n, T *W, size_t ldw, hipStream_t s) {
+  constexpr int NB = CholBlock<T>::NB;
+  const size_t smem = 2 * static_cast<size_t>(NB) * (NB + 1) * sizeof(T);
+  POGS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_inv_kernel<T, NB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
+  for (int o = 0; o < n; o += NB) {
+    const int nb = (n - o < NB) ? n - o : NB;
+    T *Gd = G + static_cast<size_t>(o) * ldg + o;
+    T *Wd = W + static_cast<size_t>(o) * ldw + o;
+    hipLaunchKernelGGL((potrf_inv_kernel<T, NB>), dim3(1), dim3(256), smem, s, Gd, ldg, nb, Wd, ldw);
+    const int rem = n - o - nb;
+    if (rem > 0) {
+      T *L21 = G + static_cast<size_t>(o + nb) * ldg + o;
+      // L21 <- A21 * inv(L11)^T, in place: one tile column, each workgroup reads
+      // its own row block completely before it writes it.
+      GemmArgs<T> g1{rem, nb, nb, L21, ldg, Wd, ldw, L21, ldg, static_cast<T>(1), static_cast<T>(0)};
+      launch_gemm<T>(false, false, false, g1, s);
+      // A22 <- A22 - L21 L21^T (lower tiles)
+      T *A22 = G + static_cast<size_t>(o + nb) * ldg + (o + nb);
+      GemmArgs<T> g2{rem, rem, nb, L21, ldg, L21, ldg, A22, ldg, static_cast<T>(-1), static_cast<T>(1)};
+      launch_gemm<T>(false, false, true, g2, s);
+    }
+  }
+}
+
+template <typename T>
+void trtri_lower(const T *L, size_t ldg, int n, T *W, size_t ldw, T *tmp, hipStream_t s) {
+  constexpr int NB = CholBlock<T>::NB;
+  for (long long sz = NB; sz < n; sz *= 2) {
+    for (long long o = 0; o + sz < n; o += 2 * sz) {
+      const int na = static_cast<int>(sz);
+      const int nb = static_cast<int>((n - o - sz < sz) ? n - o - sz : sz);
+      const T *Lba = L + static_cast<size_t>(o + sz) * ldg + o;
+      const T *Waa = W + static_cast<size_t>(o) * ldw + o;
+      const T *Wbb = W + static_cast<size_t>(o + sz) * ldw + (o + sz);
+      T *Wba = W + static_cast<size_t>(o + sz) * ldw + o;
+      // T = L_ba W_aa ; W_ba = -W_bb T
+      GemmArgs<T> g1{nb, na, na, Lba, ldg, Waa, ldw, tmp, ldw, static_cast<T>(1), static_cast<T>(0)};
+      launch_gemm<T>(false, true, false, g1, s);
+      GemmArgs<T> g2{nb, na, nb, Wbb, ldw, tmp, ldw, Wba, ldw, static_cast<T>(-1), static_cast<T>(0)};
+      launch_gemm<T>(false, true, false, g2, s);
+    }
+  }
+}
+
+template <typename T>
+void launch_transpose(const T *in, size_t ld_in, int rows, int cols, T *out, size_t ld_out, hipStream_t s) {
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+  hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, s, in, ld_in, rows, cols, out, ld_out);
+}
+
+template <typename T>
+void launch_add_diag(T *G, size_t ldg, int n, T v, hipStream_t s) {
+  hipLaunchKernelGGL(add_diag_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s, G, ldg, n, v);
+}
+
+#define POGS_INST(T)                                                                           \
+  template void launch_gemm<T>(bool, bool, bool, const GemmArgs<T> &, hipStream_t);            \
+  template void cholesky_lower<T>(T *, size_t, int, T *, size_t, hipStream_t);                 \
+  template void trtri_lower<T>(const T *, size_t, int, T *, size_t, T *, hipStream_t);         \
+  template void launch_transpose<T>(const T *, size_t, int, int, T *, size_t, hipStream_t);    \
+  template void launch_add_diag<T>(T *, size_t, int, T, hipStream_t);
+POGS_INST(float)
+POGS_INST(double)
+#undef POGS_INST
+
+}  // namespace pogs_amd

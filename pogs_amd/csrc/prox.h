@@ -1,0 +1,205 @@
+// Device-side proximal-operator / function library.
+//
+// Behavioural spec: the reference's ProxEval / FuncEval
+// (src/include/prox_lib.h:83-230, 240-349) and scalar helpers
+// (src/include/prox_tools.h:49-149).  Written for the GPU: coefficients are
+// struct-of-arrays (the ABI already supplies them that way,
+// src/interface_c/pogs_c.h:75-91), every function is branch-light and the
+// function id is a per-element runtime value (wave-uniform in every solve_*
+// problem, so the switch does not diverge in practice).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pogs_amd {
+
+enum Fn : int { kAbs = 0, kExp, kHuber, kIdentity, kIndBox01, kIndEq0, kIndGe0, kIndLe0,
+                kLogistic, kMaxNeg0, kMaxPos0, kNegEntr, kNegLog, kRecipr, kSquare, kZero };
+
+// Struct-of-arrays view of m (or n) function objects c*h(a*v-b) + d*v + e*v^2/2.
+template <typename T>
+struct FnView {
+  const int *h;
+  const T *a, *b, *c, *d, *e;
+};
+
+namespace dev {
+
+__device__ __forceinline__ float Exp(float x) { return expf(x); }
+__device__ __forceinline__ double Exp(double x) { return exp(x); }
+__device__ __forceinline__ float Log(float x) { return logf(x); }
+__device__ __forceinline__ double Log(double x) { return log(x); }
+__device__ __forceinline__ float Sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double Sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float Abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double Abs(double x) { return fabs(x); }
+__device__ __forceinline__ float Max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double Max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float Min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double Min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float Pow(float a, float b) { return powf(a, b); }
+__device__ __forceinline__ double Pow(double a, double b) { return pow(a, b); }
+__device__ __forceinline__ float Acos(float a) { return acosf(a); }
+__device__ __forceinline__ double Acos(double a) { return acos(a); }
+__device__ __forceinline__ float Cos(float a) { return cosf(a); }
+__device__ __forceinline__ double Cos(double a) { return cos(a); }
+
+template <typename T> __device__ __forceinline__ T BisectTol();   // prox_tools.h:57-62
+template <> __device__ __forceinline__ float BisectTol<float>() { return 1e-5f; }
+template <> __device__ __forceinline__ double BisectTol<double>() { return 1e-10; }
+
+// W(exp(x)), principal branch, in double (prox_tools.h:98-129; callers cast to
+// double exactly as prox_lib.h:88-100 does).
+__device__ inline double LambertWExp(double x) {
+  double w;
+  if (x > 100.0) {
+    const double log_x = log(x);
+    return -0.36962844 + x - 0.97284858 * log_x + 1.3437973 / log_x;
+  } else if (x < 0.0) {
+    const double p = sqrt(2.0 * (exp(x + 1.0) + 1.0));
+    w = -1.0 + p * (1.0 + p * (-1.0 / 3.0 + p * (11.0 / 72.0)));
+  } else {
+    w = x;
+  }
+  if (x > 1.098612288668110) w -= log(w);
+  for (int i = 0; i < 10; ++i) {
+    const double e = exp(w);
+    double t = w * e - exp(x);
+    const double p = w + 1.0;
+    t /= e * p - 0.5 * (p + 1.0) * t / p;
+    w -= t;
+    if (fabs(t) < 4e-16 * (1.0 + fabs(w))) break;
+  }
+  return w;
+}
+
+// Single positive root of x^3 + p x^2 + q x + r (prox_tools.h:134-149).
+template <typename T>
+__device__ inline T CubicSolve(T p, T q, T r) {
+  const T s = p / 3, s2 = s * s, s3 = s2 * s;
+  const T a = -s2 + q / 3;
+  const T b = s3 - s * q / 2 + r / 2;
+  const T a3 = a * a * a;
+  const T b2 = b * b;
+  if (a3 + b2 >= 0) {
+    const T A = Pow(Sqrt(a3 + b2) - b, static_cast<T>(1) / 3);
+    return -s - a / A + A;
+  } else {
+    const T A = Sqrt(-a3);
+    const T B = Acos(-b / A);
+    const T C = Pow(A, static_cast<T>(1) / 3);
+    return -s + (C - a / C) * Cos(B / 3);
+  }
+}
+
+// Root of sigma(x) + rho (x - v) = 0: guarded Newton then interval halving
+// (prox_lib.h:131-170).
+template <typename T>
+__device__ inline T ProxLogistic(T v, T rho) {
+  const T inv_rho = 1 / rho;
+  T x;
+  if (v < static_cast<T>(-2.5))
+    x = v;
+  else if (v > static_cast<T>(2.5) + inv_rho)
+    x = v - inv_rho;
+  else
+    x = (rho * v - static_cast<T>(0.5)) / (static_cast<T>(0.2) + rho);
+  T l = v - inv_rho, u = v;
+#pragma unroll 1
+  for (int i = 0; i < 5; ++i) {
+    const T inv_ex = 1 / (1 + Exp(-x));
+    const T f = inv_ex + rho * (x - v);
+    const T g = inv_ex * (1 - inv_ex) + rho;
+    if (f < 0) l = x; else u = x;
+    x = x - f / g;
+    x = Min(x, u);
+    x = Max(x, l);
+  }
+#pragma unroll 1
+  for (int i = 0; u - l > BisectTol<T>() && i < 100; ++i) {
+    const T g_rho = 1 / (rho * (1 + Exp(-x))) + (x - v);
+    if (g_rho > 0) {
+      l = Max(l, x - g_rho);
+      u = x;
+    } else {
+      u = Min(u, x - g_rho);
+      l = x;
+    }
+    x = (u + l) / 2;
+  }
+  return x;
+}
+
+// prox_h(v, rho) for the 16 base functions (prox_lib.h:83-204).
+template <typename T>
+__device__ inline T ProxBase(int h, T v, T rho) {
+  const T zero = 0;
+  switch (h) {
+    case kAbs: return Max(zero, v - 1 / rho) - Max(zero, -(v + 1 / rho));
+    case kNegEntr:
+      return static_cast<T>(LambertWExp(static_cast<double>((rho * v - 1) + Log(rho)))) / rho;
+    case kExp: return v - static_cast<T>(LambertWExp(static_cast<double>(v - Log(rho))));
+    case kHuber:
+      return Abs(v) < 1 + 1 / rho ? v * rho / (1 + rho) : v - (v >= 0 ? static_cast<T>(1) : static_cast<T>(-1)) / rho;
+    case kIdentity: return v - 1 / rho;
+    case kIndBox01: return v <= 0 ? zero : (v >= 1 ? static_cast<T>(1) : v);
+    case kIndEq0: return zero;
+    case kIndGe0: return v <= 0 ? zero : v;
+    case kIndLe0: return v >= 0 ? zero : v;
+    case kLogistic: return ProxLogistic(v, rho);
+    case kMaxNeg0: {
+      const T z = v >= 0 ? v : zero;
+      return v + 1 / rho <= 0 ? v + 1 / rho : z;
+    }
+    case kMaxPos0: {
+      const T z = v <= 0 ? v : zero;
+      return v >= 1 / rho ? v - 1 / rho : z;
+    }
+    case kNegLog: return (v + Sqrt(v * v + 4 / rho)) / 2;
+    case kRecipr: return CubicSolve(-Max(v, zero), zero, -1 / rho);
+    case kSquare: return rho * v / (1 + rho);
+    case kZero:
+    default: return v;
+  }
+}
+
+// Prox of c*h(a*v-b) + d*v + e*v^2/2 (prox_lib.h:207-230).
+template <typename T>
+__device__ inline T ProxEval(int h, T a, T b, T c, T d, T e, T v, T rho) {
+  v = a * (v * rho - d) / (e + rho) - b;
+  rho = (e + rho) / (c * a * a);
+  v = ProxBase(h, v, rho);
+  return (v + b) / a;
+}
+
+// c*h(a*x-b) + d*x + e*x^2/2 (prox_lib.h:240-349).
+template <typename T>
+__device__ inline T FuncEval(int h, T a, T b, T c, T d, T e, T x) {
+  const T dx = d * x;
+  const T ex = e * x * x / 2;
+  const T zero = 0;
+  x = a * x - b;
+  switch (h) {
+    case kAbs: x = Abs(x); break;
+    case kNegEntr: x = x <= 0 ? zero : x * Log(x); break;
+    case kExp: x = Exp(x); break;
+    case kHuber: {
+      const T xabs = Abs(x);
+      x = xabs < static_cast<T>(1) ? xabs * xabs / 2 : xabs - static_cast<T>(0.5);
+      break;
+    }
+    case kIdentity: break;
+    case kIndBox01: case kIndEq0: case kIndGe0: case kIndLe0: x = zero; break;
+    case kLogistic: x = Log(1 + Exp(x)); break;
+    case kMaxNeg0: x = Max(zero, -x); break;
+    case kMaxPos0: x = Max(zero, x); break;
+    case kNegLog: x = -Log(Max(zero, x)); break;
+    case kRecipr: x = 1 / Max(zero, x); break;
+    case kSquare: x = x * x / 2; break;
+    case kZero:
+    default: x = zero; break;
+  }
+  return c * x + dx + ex;
+}
+
+}  // namespace dev
+}  // namespace pogs_amd

@@ -1,0 +1,316 @@
+// Row-streaming kernel over a dense row-major matrix: the one HBM-bound kernel
+// behind every pass over A (and over the triangular solve factors).
+//
+// For each block of R rows a workgroup
+//   (1) loads the rows with 16-byte coalesced loads into registers (once),
+//   (2) DOT: forms the R row dot-products with a register-resident vector,
+//       reduces them wave -> workgroup, and hands each to a per-row functor
+//       (which may store it, update row-local ADMM state, accumulate scalars),
+//   (3) ACC: accumulates u_r * row_r into register-resident column sums,
+//       where u_r is the functor's return value.
+// So y = A x, x = A^T y and the fused "y = f(A x); x' = A^T y" all read A from
+// HBM exactly once.  The reference does each of these as separate cblas_?gemv
+// calls (src/cpu/matrix/matrix_dense.cpp:93-113); fusing them halves the
+// matrix traffic of Sinkhorn-Knopp (equil_helper.h:149-163), the power
+// iteration (equil_helper.h:121-123) and the exact-residual evaluation
+// (pogs.cpp:352-376).
+//
+// Column sums are written per workgroup to `col_partials` and combined by
+// reduce_cols (fixed order, no atomics => bit-reproducible).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "reduce.h"
+
+namespace pogs_amd {
+
+enum Tri : int { kFull = 0, kLower = 1, kUpper = 2 };
+
+template <typename T>
+struct StreamArgs {
+  const T *A;              // row-major, leading dimension lda (multiple of 16 B)
+  size_t lda;
+  int m;                   // rows
+  int n_pad;               // columns rounded up to the 16-byte vector width
+  const T *xin;            // DOT: vector of length n_pad
+  const T *xin_add;        // DOT: optional addend (x = xin * scale + xin_add)
+  const double *xin_nrm2;  // DOT: optional device scalar; scale = 1/sqrt(*xin_nrm2)
+  T *col_partials;         // ACC: [gridDim.x][n_pad]
+  double *scalar_partials; // Op::NS > 0: [gridDim.x][Op::NS]
+};
+
+struct StreamPlan {
+  int tpb = 0;   // threads per workgroup: 64, 256 or 1024
+  int nv = 0;    // 16-byte vectors per thread per row
+  int grid_max = 0;
+  bool ok = false;
+};
+
+// Chooses the workgroup shape for rows of n_pad elements.
+template <typename T>
+inline StreamPlan make_stream_plan(int n_pad, int num_cu) {
+  constexpr int VEC = Vec16<T>::N;
+  const int vpr = n_pad / VEC;
+  StreamPlan p;
+  static const int nv64[] = {1, 2, 4};
+  static const int nv256[] = {2, 3, 4, 5, 6, 8, 10, 12, 16};
+  static const int nv1024[] = {5, 6, 8};
+  for (int nv : nv64)
+    if (vpr <= 64 * nv) { p.tpb = 64; p.nv = nv; p.grid_max = num_cu * 8; p.ok = true; return p; }
+  for (int nv : nv256)
+    if (vpr <= 256 * nv) { p.tpb = 256; p.nv = nv; p.grid_max = num_cu * 2; p.ok = true; return p; }
+  for (int nv : nv1024)
+    if (vpr <= 1024 * nv) { p.tpb = 1024; p.nv = nv; p.grid_max = num_cu; p.ok = true; return p; }
+  return p;
+}
+
+namespace dev {
+
+__device__ __forceinline__ float vdot(const float4 &a, const float4 &b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+__device__ __forceinline__ double vdot(const double2 &a, const double2 &b) {
+  return a.x * b.x + a.y * b.y;
+}
+__device__ __forceinline__ void vfma(float4 &acc, float u, const float4 &a) {
+  acc.x += u * a.x; acc.y += u * a.y; acc.z += u * a.z; acc.w += u * a.w;
+}
+__device__ __forceinline__ void vfma(double2 &acc, double u, const double2 &a) {
+  acc.x += u * a.x; acc.y += u * a.y;
+}
+__device__ __forceinline__ float4 vsq(const float4 &a) {
+  return make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
+}
+__device__ __forceinline__ double2 vsq(const double2 &a) { return make_double2(a.x * a.x, a.y * a.y); }
+__device__ __forceinline__ float4 vscale_add(const float4 &a, float s, const float4 &b) {
+  return make_float4(a.x * s + b.x, a.y * s + b.y, a.z * s + b.z, a.w * s + b.w);
+}
+__device__ __forceinline__ double2 vscale_add(const double2 &a, double s, const double2 &b) {
+  return make_double2(a.x * s + b.x, a.y * s + b.y);
+}
+template <typename V> __device__ __forceinline__ V vzero();
+template <> __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <> __device__ __forceinline__ double2 vzero<double2>() { return make_double2(0.0, 0.0); }
+
+}  // namespace dev
+
+template <typename T, int TPB, int NV, int R, bool DOT, bool ACC, bool SQ, int TRI, typename Op>
+__global__ void __launch_bounds__(TPB) stream_rows_kernel(StreamArgs<T> a, Op op) {
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int NW = TPB / 64;
+  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+  __shared__ T s_part[2 * R * NW];
+  __shared__ T s_u[2 * R];
+  __shared__ double s_red[NS * NW];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+  V xv[NV];
+  V acc[NV];
+  if (DOT) {
+    T sc = 1;
+    if (a.xin_nrm2) sc = static_cast<T>(1.0 / sqrt(*a.xin_nrm2));
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * TPB + t) * VEC;
+      V x = dev::vzero<V>();
+      if (col < a.n_pad) {
+        x = *reinterpret_cast<const V *>(a.xin + col);
+        V add = dev::vzero<V>();
+        if (a.xin_add) add = *reinterpret_cast<const V *>(a.xin_add + col);
+        x = dev::vscale_add(x, sc, add);
+      }
+      xv[v] = x;
+    }
+  }
+  if (ACC) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = dev::vzero<V>();
+  }
+  double sacc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
+
+  const int nblk = (a.m + R - 1) / R;
+  int slot = 0;
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x, slot ^= 1) {
+    const int row0 = blk * R;
+    V av[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r;
+      const T *rp = a.A + static_cast<size_t>(row) * a.lda;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int col = (v * TPB + t) * VEC;
+        bool ok = (col < a.n_pad) && (row < a.m);
+        if (TRI == kLower) ok = ok && (col <= row);
+        if (TRI == kUpper) ok = ok && (col + VEC - 1 >= row);
+        V val = dev::vzero<V>();
+        if (ok) val = *reinterpret_cast<const V *>(rp + col);
+        av[r][v] = SQ ? dev::vsq(val) : val;
+      }
+    }
+    if (DOT) {
+      T p[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        T s = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) s += dev::vdot(av[r][v], xv[v]);
+        p[r] = dev::wave_sum(s);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) s_part[(slot * R + r) * NW + wave] = p[r];
+      }
+      __syncthreads();
+      if (t < R) {
+        const int row = row0 + t;
+        T uval = 0;
+        if (row < a.m) {
+          T dot = 0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) dot += s_part[(slot * R + t) * NW + w];
+          uval = op.row(row, dot, sacc);
+        }
+        if (ACC) s_u[slot * R + t] = uval;
+      }
+      if (ACC) __syncthreads();
+    }
+    if (ACC) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        T u;
+        if (DOT) {
+          u = s_u[slot * R + r];
+        } else {
+          u = (row0 + r < a.m) ? op.u(row0 + r) : static_cast<T>(0);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dev::vfma(acc[v], u, av[r][v]);
+      }
+    }
+  }
+  if (ACC) {
+    T *out = a.col_partials + static_cast<size_t>(blockIdx.x) * a.n_pad;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * TPB + t) * VEC;
+      if (col < a.n_pad) *reinterpret_cast<V *>(out + col) = acc[v];
+    }
+  }
+  if (Op::NS > 0) {
+    __syncthreads();
+    dev::block_sum<NS, TPB>(sacc, s_red);
+    if (t == 0) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) a.scalar_partials[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
+    }
+  }
+}
+
+// Rows per workgroup step by mode and workgroup size (register budget: the row
+// tile costs 4*R*NV VGPRs, the x / column-sum vectors 4*NV each).
+template <bool DOT, bool ACC, int TPB>
+struct RowsPerStep {
+  static constexpr int value = (TPB == 1024) ? ((DOT && ACC) ? 1 : 2) : ((DOT && ACC) ? 2 : 4);
+};
+
+// Number of workgroups a launch of this plan uses for m rows.
+template <bool DOT, bool ACC>
+inline int stream_grid(const StreamPlan &p, int m) {
+  const int R = (p.tpb == 1024) ? ((DOT && ACC) ? 1 : 2) : ((DOT && ACC) ? 2 : 4);
+  const int nblk = (m + R - 1) / R;
+  return nblk < p.grid_max ? (nblk > 0 ? nblk : 1) : p.grid_max;
+}
+
+template <typename T, bool DOT, bool ACC, bool SQ, int TRI, typename Op>
+void launch_stream(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hipStream_t s) {
+  POGS_CHECK(p.ok, "matrix too wide for the row-streaming kernel");
+  const int grid = stream_grid<DOT, ACC>(p, a.m);
+#define POGS_STREAM_CASE(TPB_, NV_)                                                             \
+  if (p.tpb == TPB_ && p.nv == NV_) {                                                           \
+    constexpr int R_ = RowsPerStep<DOT, ACC, TPB_>::value;                                      \
+    hipLaunchKernelGGL((stream_rows_kernel<T, TPB_, NV_, R_, DOT, ACC, SQ, TRI, Op>),           \
+                       dim3(grid), dim3(TPB_), 0, s, a, op);                                    \
+    return;                                                                                     \
+  }
+  POGS_STREAM_CASE(64, 1)
+  POGS_STREAM_CASE(64, 2)
+  POGS_STREAM_CASE(64, 4)
+  POGS_STREAM_CASE(256, 2)
+  POGS_STREAM_CASE(256, 3)
+  POGS_STREAM_CASE(256, 4)
+  POGS_STREAM_CASE(256, 5)
+  POGS_STREAM_CASE(256, 6)
+  POGS_STREAM_CASE(256, 8)
+  POGS_STREAM_CASE(256, 10)
+  POGS_STREAM_CASE(256, 12)
+  POGS_STREAM_CASE(256, 16)
+  POGS_STREAM_CASE(1024, 5)
+  POGS_STREAM_CASE(1024, 6)
+  POGS_STREAM_CASE(1024, 8)
+#undef POGS_STREAM_CASE
+  throw Error("no stream kernel instance for plan");
+}
+
+// ---------------------------------------------------------------------------
+// reduce_cols: out-of-kernel second stage of the column sums.
+//   total[j] = sum_b partials[b][j]   (b in fixed order)
+// and hands total[j] to a per-column functor.
+// Workgroup = 256 threads = 32 column-vectors x 8 partial groups.
+// ---------------------------------------------------------------------------
+template <typename T, typename ColOp>
+__global__ void __launch_bounds__(256) reduce_cols_kernel(const T *partials, int nparts, int n_pad,
+                                                          ColOp op, double *scalar_partials) {
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int NS = ColOp::NS > 0 ? ColOp::NS : 1;
+  __shared__ V s_v[8][32];
+  __shared__ double s_red[NS * 4];
+  const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + cx) * VEC;
+  V sum = dev::vzero<V>();
+  if (col < n_pad) {
+    for (int b = g; b < nparts; b += 8) {
+      const V v = *reinterpret_cast<const V *>(partials + static_cast<size_t>(b) * n_pad + col);
+      dev::vfma(sum, static_cast<T>(1), v);
+    }
+  }
+  s_v[g][cx] = sum;
+  __syncthreads();
+  double sacc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
+  if (g == 0 && col < n_pad) {
+    V tot = s_v[0][cx];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) dev::vfma(tot, static_cast<T>(1), s_v[q][cx]);
+    const T *tp = reinterpret_cast<const T *>(&tot);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) op.col(col + i, tp[i], sacc);
+  }
+  if (ColOp::NS > 0) {
+    __syncthreads();
+    dev::block_sum<NS, 256>(sacc, s_red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) scalar_partials[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
+    }
+  }
+}
+
+inline int reduce_cols_grid(int n_pad, int vec) { return (n_pad / vec + 31) / 32; }
+
+template <typename T, typename ColOp>
+void launch_reduce_cols(const T *partials, int nparts, int n_pad, const ColOp &op,
+                        double *scalar_partials, hipStream_t s) {
+  const int grid = reduce_cols_grid(n_pad, Vec16<T>::N);
+  hipLaunchKernelGGL((reduce_cols_kernel<T, ColOp>), dim3(grid), dim3(256), 0, s, partials, nparts,
+                     n_pad, op, scalar_partials);
+}
+
+}  // namespace pogs_amd

@@ -1,0 +1,105 @@
+// Element-wise ADMM kernels with wavefront-reduced scalar outputs.
+// Reference: the vector algebra inside PogsImplementation::Solve
+// (src/cpu/pogs.cpp:254-278, 342-348, 397-399, 473, 510-518), which the CPU
+// path runs as ~25 separate BLAS-1 calls per iteration.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "prox.h"
+
+namespace pogs_amd {
+
+// Device scalar block layout (doubles).  The first kNumYSlots entries are sums
+// over rows (y-sized data): on a row-sharded solve they are all-reduced as one
+// contiguous message.  The rest are sums over columns (replicated).
+enum Slot : int {
+  kGapY = 0, kWY2, kHY2, kDYprev2, kDY12, kExactR2, kPowSx2, kFro2, kFvalF, kCgQ2, kCgR2,
+  kNumYSlots = 12,
+  kGapX = 12, kWX2, kHX2, kDXprev2, kDX12, kExactS2, kPowX2, kFvalG, kCgP2, kCgS2, kCgX2, kCgS02,
+  kNumSlots = 32
+};
+
+template <typename T>
+struct FnBuf {  // owning device SoA of function objects
+  DevBuf<int> h;
+  DevBuf<T> a, b, c, d, e;
+  void alloc(size_t n) { h.alloc(n); a.alloc(n); b.alloc(n); c.alloc(n); d.alloc(n); e.alloc(n); }
+  FnView<T> view() const { return FnView<T>{h.p, a.p, b.p, c.p, d.p, e.p}; }
+};
+
+template <typename T>
+struct AdmmPreArgs {
+  int n_x, n_y;
+  FnView<T> g, f;
+  const T *x_cur, *y_cur;
+  const T *xt, *yt;
+  T zt_scale;
+  T *x12, *y12;
+  T *xtemp, *ytemp;
+  T rho, alpha;
+  double *partials;  // [blocks_x + blocks_y][3]
+  int blocks_x;
+};
+
+// clamp c,e >= 0 (FunctionObj::CheckConsts, prox_lib.h:62-69) and scale by the
+// equilibration (PogsObjectiveSeparable::scale, pogs.cpp:608-617):
+//   divide: a/=s, d/=s, e/=s^2 (f with s=d);  multiply: a*=s, d*=s, e*=s^2 (g with s=e).
+template <typename T>
+void launch_scale_objective(FnView<T> fn, T *a, T *c, T *d, T *e, const T *scale, int n, bool divide,
+                            hipStream_t s);
+
+constexpr int kVecTpb = 256;
+inline int vec_blocks(int n) { return (n + kVecTpb - 1) / kVecTpb; }
+
+// pre-projection step: prox, gap / norm partials, over-relaxation.
+// Writes partials [blocks][3] = {sum w*h, sum w^2, sum h^2}; x blocks first.
+template <typename T>
+void launch_admm_pre(const AdmmPreArgs<T> &a, hipStream_t s);
+
+// element-wise projection tail (CGLS path): see ProjTailOp.  partials [blocks][2].
+template <typename T>
+void launch_admm_tail(int n, const T *znew, const T *zprev, const T *z12, T *ztemp, double *partials,
+                      hipStream_t s);
+
+// partials[b] = sum over the block of FuncEval(f_i, v_i).
+template <typename T>
+void launch_func_eval(int n, FnView<T> f, const T *v, double *partials, hipStream_t s);
+
+// out[i] = ProxEval(f_i, in[i], rho)
+template <typename T>
+void launch_prox_eval(int n, FnView<T> f, T rho, const T *in, T *out, hipStream_t s);
+
+// Un-scaling of the outputs (pogs.cpp:510-518).
+template <typename T>
+struct UnscaleArgs {
+  int n_x, n_y;
+  const T *x12, *y12, *xt, *yt, *xprev, *yprev, *d, *e;
+  T zt_scale, rho;
+  T *x_out, *y_out, *l_out, *mu_out;
+};
+template <typename T>
+void launch_unscale(const UnscaleArgs<T> &a, hipStream_t s);
+
+// Up to 4 independent partial-sum jobs in one launch: out[k] = sum_b partials[b*ns+k].
+struct SumJob {
+  const double *partials;
+  int nparts, ns;
+  double *out;
+};
+void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s);
+
+// Misc vector helpers.
+template <typename T> void launch_fill(T *p, T v, size_t n, hipStream_t s);
+template <typename T> void launch_sqrt_inplace(T *p, size_t n, hipStream_t s);
+template <typename T> void launch_scal(T *p, T alpha, size_t n, hipStream_t s);
+// y = a*x + b*y
+template <typename T> void launch_axpby(size_t n, T a, const T *x, T b, T *y, hipStream_t s);
+// partials[b] = sum (x_i)^2 over block b  (blocks = vec_blocks(n))
+template <typename T> void launch_sumsq(int n, const T *x, double *partials, hipStream_t s);
+// out = total + x12 + c*xt - xprev, partial sum of squares (exact dual residual, multi-GPU form)
+template <typename T>
+void launch_exact_s(int n, const T *total, const T *x12, const T *xt, const T *xprev, T zt_scale,
+                    double *partials, hipStream_t s);
+
+}  // namespace pogs_amd

@@ -1,0 +1,269 @@
+// Element-wise ADMM kernels (see vec_kernels.h).
+#include "vec_kernels.h"
+
+#include "reduce.h"
+#include "stream.h"
+
+namespace pogs_amd {
+
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(kVecTpb) scale_objective_kernel(FnView<T> fn, T *a, T *c, T *d, T *e,
+                                                                  const T *scale, int n, bool divide) {
+  const int i = blockIdx.x * kVecTpb + threadIdx.x;
+  if (i >= n) return;
+  const T s = scale[i];
+  const T zero = 0;
+  T ai = fn.a[i], ci = fn.c[i], di = fn.d[i], ei = fn.e[i];
+  ci = ci < zero ? zero : ci;
+  ei = ei < zero ? zero : ei;
+  if (divide) {
+    ai /= s; di /= s; ei /= s * s;
+  } else {
+    ai *= s; di *= s; ei *= s * s;
+  }
+  a[i] = ai; c[i] = ci; d[i] = di; e[i] = ei;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kVecTpb) admm_pre_kernel(AdmmPreArgs<T> a) {
+  __shared__ double s_red[3 * (kVecTpb / 64)];
+  const bool is_x = static_cast<int>(blockIdx.x) < a.blocks_x;
+  const int blk = is_x ? blockIdx.x : blockIdx.x - a.blocks_x;
+  const int n = is_x ? a.n_x : a.n_y;
+  const FnView<T> fn = is_x ? a.g : a.f;
+  const T *cur = is_x ? a.x_cur : a.y_cur;
+  const T *zt = is_x ? a.xt : a.yt;
+  T *z12 = is_x ? a.x12 : a.y12;
+  T *ztemp = is_x ? a.xtemp : a.ytemp;
+  const int i = blk * kVecTpb + threadIdx.x;
+  double acc[3] = {0.0, 0.0, 0.0};
+  if (i < n) {
+    const T prev = cur[i];
+    const T ztv = a.zt_scale * zt[i];
+    const T v = prev - ztv;                                       // pogs.cpp:257
+    const T h = dev::ProxEval(fn.h[i], fn.a[i], fn.b[i], fn.c[i], fn.d[i], fn.e[i], v, a.rho);  // :263
+    const T w = v - h;                                            // :267
+    z12[i] = h;
+    ztemp[i] = ztv + a.alpha * h + (static_cast<T>(1) - a.alpha) * prev;   // :276-278
+    acc[0] = static_cast<double>(w) * h;                          // :268
+    acc[1] = static_cast<double>(w) * w;
+    acc[2] = static_cast<double>(h) * h;
+  }
+  dev::block_sum<3, kVecTpb>(acc, s_red);
+  if (threadIdx.x == 0) {
+    double *out = a.partials + static_cast<size_t>(blockIdx.x) * 3;
+    out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kVecTpb) admm_tail_kernel(int n, const T *znew, const T *zprev,
+                                                            const T *z12, T *ztemp, double *partials) {
+  __shared__ double s_red[2 * (kVecTpb / 64)];
+  const int i = blockIdx.x * kVecTpb + threadIdx.x;
+  double acc[2] = {0.0, 0.0};
+  if (i < n) {
+    const T zn = znew[i];
+    const T p = zprev[i] - zn, q = z12[i] - zn;
+    acc[0] = static_cast<double>(p) * p;
+    acc[1] = static_cast<double>(q) * q;
+    ztemp[i] -= zn;
+  }
+  dev::block_sum<2, kVecTpb>(acc, s_red);
+  if (threadIdx.x == 0) {
+    partials[static_cast<size_t>(blockIdx.x) * 2 + 0] = acc[0];
+    partials[static_cast<size_t>(blockIdx.x) * 2 + 1] = acc[1];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kVecTpb) func_eval_kernel(int n, FnView<T> f, const T *v, double *partials) {
+  __shared__ double s_red[kVecTpb / 64];
+  const int i = blockIdx.x * kVecTpb + threadIdx.x;
+  double acc[1] = {0.0};
+  if (i < n) acc[0] = static_cast<double>(dev::FuncEval(f.h[i], f.a[i], f.b[i], f.c[i], f.d[i], f.e[i], v[i]));
+  dev::block_sum<1, kVecTpb>(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kVecTpb) prox_eval_kernel(int n, FnView<T> f, T rho, const T *in, T *out) {
+  const int i = blockIdx.x * kVecTpb + threadIdx.x;
+  if (i < n) out[i] = dev::ProxEval(f.h[i], f.a[i], f.b[i], f.c[i], f.d[i], f.e[i], in[i], rho);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kVecTpb) unscale_kernel(UnscaleArgs<T> a, int blocks_x) {
+  const bool is_x = static_cast<int>(blockIdx.x) < blocks_x;
+  const int blk = is_x ? blockIdx.x : blockIdx.x - blocks_x;
+  const int i = blk * kVecTpb + threadIdx.x;
+  if (is_x) {
+    if (i < a.n_x) {
+      const T ei = a.e[i];
+      a.x_out[i] = a.x12[i] * ei;                                               // pogs.cpp:518
+      if (a.mu_out)
+        a.mu_out[i] = -a.rho * (a.zt_scale * a.xt[i] - a.xprev[i] + a.x12[i]) / ei;  // :510-515
+    }
+  } else {
+    if (i < a.n_y) {
+      const T di = a.d[i];
+      a.y_out[i] = a.y12[i] / di;                                               // :517
+      a.l_out[i] = -a.rho * (a.zt_scale * a.yt[i] - a.yprev[i] + a.y12[i]) * di;     // :510-514
+    }
+  }
+}
+
+struct SumJobs {
+  SumJob j[4];
+};
+
+__global__ void __launch_bounds__(256) sum_jobs_kernel(SumJobs jobs) {
+  const SumJob job = jobs.j[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k < job.ns; k += 4) {
+    double s = 0;
+    for (int b = lane; b < job.nparts; b += 64) s += job.partials[static_cast<size_t>(b) * job.ns + k];
+    s = dev::wave_sum(s);
+    if (lane == 0) job.out[k] = s;
+  }
+}
+
+template <typename T>
+__global__ void fill_kernel(T *p, T v, size_t n) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+template <typename T>
+__global__ void sqrt_kernel(T *p, size_t n) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = dev::Sqrt(p[i]);
+}
+template <typename T>
+__global__ void scal_kernel(T *p, T alpha, size_t n) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] *= alpha;
+}
+template <typename T>
+__global__ void axpby_kernel(size_t n, T a, const T *x, T b, T *y) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (b == static_cast<T>(0)) ? a * x[i] : a * x[i] + b * y[i];
+}
+template <typename T>
+__global__ void __launch_bounds__(kVecTpb) sumsq_kernel(int n, const T *x, double *partials) {
+  __shared__ double s_red[kVecTpb / 64];
+  const int i = blockIdx.x * kVecTpb + threadIdx.x;
+  double acc[1] = {0.0};
+  if (i < n) acc[0] = static_cast<double>(x[i]) * x[i];
+  dev::block_sum<1, kVecTpb>(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+template <typename T>
+__global__ void __launch_bounds__(kVecTpb) exact_s_kernel(int n, const T *total, const T *x12, const T *xt,
+                                                          const T *xprev, T zt_scale, double *partials) {
+  __shared__ double s_red[kVecTpb / 64];
+  const int i = blockIdx.x * kVecTpb + threadIdx.x;
+  double acc[1] = {0.0};
+  if (i < n) {
+    const T v = total[i] + x12[i] + zt_scale * xt[i] - xprev[i];
+    acc[0] = static_cast<double>(v) * v;
+  }
+  dev::block_sum<1, kVecTpb>(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+inline dim3 grid1d(size_t n, int tpb = 256) { return dim3(static_cast<unsigned>((n + tpb - 1) / tpb)); }
+
+}  // namespace
+
+template <typename T>
+void launch_scale_objective(FnView<T> fn, T *a, T *c, T *d, T *e, const T *scale, int n, bool divide,
+                            hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(scale_objective_kernel<T>, dim3(vec_blocks(n)), dim3(kVecTpb), 0, s, fn, a, c, d, e,
+                     scale, n, divide);
+}
+
+template <typename T>
+void launch_admm_pre(const AdmmPreArgs<T> &a, hipStream_t s) {
+  const int blocks = a.blocks_x + vec_blocks(a.n_y);
+  hipLaunchKernelGGL(admm_pre_kernel<T>, dim3(blocks), dim3(kVecTpb), 0, s, a);
+}
+
+template <typename T>
+void launch_admm_tail(int n, const T *znew, const T *zprev, const T *z12, T *ztemp, double *partials,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(admm_tail_kernel<T>, dim3(vec_blocks(n)), dim3(kVecTpb), 0, s, n, znew, zprev, z12,
+                     ztemp, partials);
+}
+
+template <typename T>
+void launch_func_eval(int n, FnView<T> f, const T *v, double *partials, hipStream_t s) {
+  hipLaunchKernelGGL(func_eval_kernel<T>, dim3(vec_blocks(n)), dim3(kVecTpb), 0, s, n, f, v, partials);
+}
+
+template <typename T>
+void launch_prox_eval(int n, FnView<T> f, T rho, const T *in, T *out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(prox_eval_kernel<T>, dim3(vec_blocks(n)), dim3(kVecTpb), 0, s, n, f, rho, in, out);
+}
+
+template <typename T>
+void launch_unscale(const UnscaleArgs<T> &a, hipStream_t s) {
+  const int bx = vec_blocks(a.n_x);
+  hipLaunchKernelGGL(unscale_kernel<T>, dim3(bx + vec_blocks(a.n_y)), dim3(kVecTpb), 0, s, a, bx);
+}
+
+void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s) {
+  POGS_CHECK(njobs >= 1 && njobs <= 4, "sum jobs");
+  SumJobs j;
+  for (int i = 0; i < 4; ++i) j.j[i] = jobs[i < njobs ? i : 0];
+  hipLaunchKernelGGL(sum_jobs_kernel, dim3(njobs), dim3(256), 0, s, j);
+}
+
+template <typename T>
+void launch_fill(T *p, T v, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(fill_kernel<T>, grid1d(n), dim3(256), 0, s, p, v, n);
+}
+template <typename T>
+void launch_sqrt_inplace(T *p, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(sqrt_kernel<T>, grid1d(n), dim3(256), 0, s, p, n);
+}
+template <typename T>
+void launch_scal(T *p, T alpha, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(scal_kernel<T>, grid1d(n), dim3(256), 0, s, p, alpha, n);
+}
+template <typename T>
+void launch_axpby(size_t n, T a, const T *x, T b, T *y, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(axpby_kernel<T>, grid1d(n), dim3(256), 0, s, n, a, x, b, y);
+}
+template <typename T>
+void launch_sumsq(int n, const T *x, double *partials, hipStream_t s) {
+  hipLaunchKernelGGL(sumsq_kernel<T>, dim3(vec_blocks(n)), dim3(kVecTpb), 0, s, n, x, partials);
+}
+template <typename T>
+void launch_exact_s(int n, const T *total, const T *x12, const T *xt, const T *xprev, T zt_scale,
+                    double *partials, hipStream_t s) {
+  hipLaunchKernelGGL(exact_s_kernel<T>, dim3(vec_blocks(n)), dim3(kVecTpb), 0, s, n, total, x12, xt, xprev,
+                     zt_scale, partials);
+}
+
+#define POGS_INST(T)                                                                                     \
+  template void launch_scale_objective<T>(FnView<T>, T *, T *, T *, T *, const T *, int, bool, hipStream_t); \
+  template void launch_admm_pre<T>(const AdmmPreArgs<T> &, hipStream_t);                                 \
+  template void launch_admm_tail<T>(int, const T *, const T *, const T *, T *, double *, hipStream_t);   \
+  template void launch_func_eval<T>(int, FnView<T>, const T *, double *, hipStream_t);                   \
+  template void launch_prox_eval<T>(int, FnView<T>, T, const T *, T *, hipStream_t);                     \
+  template void launch_unscale<T>(const UnscaleArgs<T> &, hipStream_t);                                  \
+  template void launch_fill<T>(T *, T, size_t, hipStream_t);                                             \
+  template void launch_sqrt_inplace<T>(T *, size_t, hipStream_t);                                        \
+  template void launch_scal<T>(T *, T, size_t, hipStream_t);                                             \
+  template void launch_axpby<T>(size_t, T, const T *, T, T *, hipStream_t);                              \
+  template void launch_sumsq<T>(int, const T *, double *, hipStream_t);                                  \
+  template void launch_exact_s<T>(int, const T *, const T *, const T *, const T *, T, double *, hipStream_t);
+POGS_INST(float)
+POGS_INST(double)
+#undef POGS_INST
+
+}  // namespace pogs_amd

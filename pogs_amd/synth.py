@@ -1,0 +1,50 @@
+"""Synthetic problem generators for tests and bench.py (numpy default_rng / PCG64).
+
+Recipes follow the reference's own generators:
+dense lasso -- python/benchmarks/problems/lasso.py:40-53; logistic --
+python/benchmarks/problems/logistic.py:27-37 (without its bias term); the
+README problem -- README.md:55-59.  CSR: 50 uniformly drawn column indices per
+row, N(0,1) values, duplicates summed.
+"""
+import numpy as np
+
+
+def readme_lasso():
+    """C1: the README recipe verbatim (legacy numpy RandomState)."""
+    np.random.seed(0)
+    A = np.random.randn(500, 300)
+    b = np.random.randn(500)
+    return A, b, 0.1
+
+
+def dense_lasso(m, n, seed=0, dtype=np.float64, density=0.1, noise=0.1):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((m, n), dtype=dtype)
+    x_true = rng.standard_normal(n) * (rng.random(n) < density)
+    b = A.astype(np.float64) @ x_true + noise * rng.standard_normal(m)
+    return A, b, x_true
+
+
+def dense_logistic(m, n, seed=0, dtype=np.float64, density=0.3):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((m, n), dtype=dtype)
+    w = rng.standard_normal(n) * (rng.random(n) < density)
+    p = 1.0 / (1.0 + np.exp(-(A.astype(np.float64) @ w)))
+    y = 2.0 * (rng.random(m) < p) - 1.0
+    return A, y, w
+
+
+def csr_lasso(m, n, nnz_per_row=50, seed=0, dtype=np.float64, density=0.05, noise=0.1):
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(seed)
+    cols = rng.integers(0, n, size=(m, nnz_per_row))
+    vals = rng.standard_normal((m, nnz_per_row))
+    rows = np.repeat(np.arange(m), nnz_per_row)
+    A = sp.coo_matrix((vals.ravel(), (rows, cols.ravel())), shape=(m, n)).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    A = A.astype(dtype)
+    x_true = rng.standard_normal(n) * (rng.random(n) < density)
+    b = A.astype(np.float64) @ x_true + noise * rng.standard_normal(m)
+    return A, b, x_true

@@ -1,0 +1,42 @@
+"""pytest configuration: the `gpu` marker and one-time builds of the native pieces.
+
+* oracle/liboracle.so (CPU restatement, test infrastructure) is built with make;
+* pogs_amd/libpogs_amd.so (the HIP engine) is cross-compiled with hipcc if stale;
+* oracle/_ref/libpogs_cpu.so (the real reference) is built only where
+  /root/reference exists (the build container).
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+for p in (ROOT, os.path.dirname(__file__)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    import oracle_binding
+
+    oracle_binding.build_oracle()
+    oracle_binding.build_ref()
+    from pogs_amd import build as _build
+
+    if os.path.exists("/opt/rocm/bin/hipcc"):
+        _build.build()
+
+
+def has_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu_available():
+    return has_gpu()

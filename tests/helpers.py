@@ -1,0 +1,65 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+import pogs_amd
+from pogs_amd import graph as G
+
+
+def soa(fv):
+    """FunctionVector -> dict of arrays as oracle_binding expects."""
+    return {k: getattr(fv, k) for k in "habcde"}
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+PROBLEMS = {
+    "lasso": lambda b, n: G.lasso_functions(b, 0.1, n),
+    "ridge": lambda b, n: G.ridge_functions(b, 0.5, n),
+    "elastic_net": lambda b, n: G.elastic_net_functions(b, 0.1, 0.2, n),
+    "logistic": lambda b, n: G.logistic_functions(np.sign(b) + (b == 0), 0.01, n),
+    "logistic0": lambda b, n: G.logistic_functions(np.sign(b) + (b == 0), 0.0, n),
+    "huber": lambda b, n: G.huber_functions(b, 1.0, 0.05, n),
+    "svm": lambda b, n: G.svm_functions(np.sign(b) + (b == 0), 1.0, n),
+    "nonneg_ls": lambda b, n: G.nonneg_ls_functions(b, n),
+}
+
+
+def objective(A, f, g, x):
+    """sum f(Ax) + sum g(x) evaluated in float64 with numpy (independent of every engine)."""
+    y = np.asarray(A @ x, np.float64).ravel()
+    return _fsum(f, y) + _fsum(g, np.asarray(x, np.float64))
+
+
+def _fsum(fv, v):
+    h = fv.h
+    a, b, c, d, e = fv.a, fv.b, fv.c, fv.d, fv.e
+    t = a * v - b
+    out = np.zeros_like(v)
+    F = G.Function
+    for code in np.unique(h):
+        msk = h == code
+        z = t[msk]
+        if code == F.kAbs:
+            r = np.abs(z)
+        elif code == F.kSquare:
+            r = 0.5 * z * z
+        elif code == F.kLogistic:
+            r = np.logaddexp(0, z)
+        elif code == F.kHuber:
+            r = np.where(np.abs(z) < 1, 0.5 * z * z, np.abs(z) - 0.5)
+        elif code == F.kMaxPos0:
+            r = np.maximum(z, 0)
+        elif code == F.kMaxNeg0:
+            r = np.maximum(-z, 0)
+        elif code == F.kIdentity:
+            r = z
+        elif code in (F.kZero, F.kIndGe0, F.kIndLe0, F.kIndEq0, F.kIndBox01):
+            r = np.zeros_like(z)
+        else:
+            raise NotImplementedError(code)
+        out[msk] = r
+    return float(np.sum(c * out + d * v + 0.5 * e * v * v))

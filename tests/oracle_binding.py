@@ -1,0 +1,290 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so) and, when it has been
+built in the build container, the compiled reference (oracle/_ref/libpogs_cpu.so).
+
+TEST INFRASTRUCTURE: importable from tests/, bench.py (cpu_baseline leg) and
+__graft_entry__.smoke() only.  Nothing under pogs_amd/ may import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+_ORACLE_SO = os.path.join(_ORACLE_DIR, "liboracle.so")
+_REF_SO = os.path.join(_ORACLE_DIR, "_ref", "libpogs_cpu.so")
+
+
+class OracleInfo(ctypes.Structure):
+    _fields_ = [
+        ("use_cgls", ctypes.c_int),
+        ("d_out", ctypes.POINTER(ctypes.c_double)),
+        ("e_out", ctypes.POINTER(ctypes.c_double)),
+        ("nrmA", ctypes.c_double),
+        ("norm_est_iters", ctypes.c_uint),
+        ("rho_final", ctypes.c_double),
+        ("exact_iters", ctypes.c_uint),
+        ("cg_iters", ctypes.c_long),
+        ("n_mul", ctypes.c_long),
+        ("t_init", ctypes.c_double),
+        ("t_loop", ctypes.c_double),
+    ]
+
+
+ALLREDUCE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t)
+
+
+def build_oracle(force=False):
+    src = os.path.join(_ORACLE_DIR, "pogs_oracle.cpp")
+    if force or not os.path.exists(_ORACLE_SO) or os.path.getmtime(_ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _ORACLE_SO
+
+
+def build_ref():
+    """Build the real reference if its sources are present (build container only)."""
+    if os.path.exists(_REF_SO):
+        return _REF_SO
+    if not os.path.isdir("/root/reference/src"):
+        return None
+    r = subprocess.call(["make", "-C", _ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return _REF_SO if r == 0 and os.path.exists(_REF_SO) else None
+
+
+_oracle = None
+_ref = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        _oracle = ctypes.CDLL(build_oracle())
+        _oracle.OracleFuncEvalD.restype = ctypes.c_double
+        _oracle.OracleFuncEvalS.restype = ctypes.c_double
+        _oracle.OracleProxRawD.restype = ctypes.c_double
+        _oracle.OracleProxRawD.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double]
+        _oracle.OracleProxRawS.restype = ctypes.c_float
+        _oracle.OracleProxRawS.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_float]
+    return _oracle
+
+
+def ref_lib():
+    """The compiled reference, or None when it is not available/loadable."""
+    global _ref
+    if _ref is None:
+        path = _REF_SO if os.path.exists(_REF_SO) else None
+        if path is None:
+            return None
+        try:
+            _ref = ctypes.CDLL(path)
+        except OSError:
+            return None
+    return _ref
+
+
+def _ct(dtype):
+    return ctypes.c_double if dtype == np.float64 else ctypes.c_float
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _coef_arrays(objs, dtype):
+    """objs = dict(h=int array, a,b,c,d,e arrays) -> contiguous typed arrays."""
+    out = {k: np.ascontiguousarray(objs[k], dtype=dtype) for k in "abcde"}
+    out["h"] = np.ascontiguousarray(objs["h"], dtype=np.int32)
+    return out
+
+
+def _result(x, y, l, optval, final_iter, status, info=None):
+    r = {"x": x, "y": y, "l": l, "optval": optval.value, "iterations": final_iter.value, "status": status}
+    if info is not None:
+        r["info"] = {k: getattr(info, k) for k, _ in OracleInfo._fields_ if k not in ("d_out", "e_out")}
+    return r
+
+
+def _solve_dense(fn, A, f, g, dtype, rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop, order,
+                 info=None):
+    c = _ct(dtype)
+    A = np.ascontiguousarray(A, dtype=dtype) if order == 1 else np.asfortranarray(A, dtype=dtype)
+    m, n = A.shape
+    f = _coef_arrays(f, dtype)
+    g = _coef_arrays(g, dtype)
+    x = np.zeros(n, dtype)
+    y = np.zeros(m, dtype)
+    l = np.zeros(m, dtype)
+    optval = c()
+    final_iter = ctypes.c_uint()
+    args = [ctypes.c_int(order), ctypes.c_size_t(m), ctypes.c_size_t(n), _p(A),
+            _p(f["a"]), _p(f["b"]), _p(f["c"]), _p(f["d"]), _p(f["e"]), _p(f["h"]),
+            _p(g["a"]), _p(g["b"]), _p(g["c"]), _p(g["d"]), _p(g["e"]), _p(g["h"]),
+            c(rho), c(abs_tol), c(rel_tol), ctypes.c_uint(max_iter), ctypes.c_uint(verbose),
+            ctypes.c_int(int(adaptive_rho)), ctypes.c_int(int(gap_stop)),
+            _p(x), _p(y), _p(l), ctypes.byref(optval), ctypes.byref(final_iter)]
+    if info is not None:
+        args.append(ctypes.byref(info))
+    status = fn(*args)
+    return _result(x, y, l, optval, final_iter, status, info)
+
+
+def _solve_sparse(fn, A_csr, f, g, dtype, rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop,
+                  info=None):
+    c = _ct(dtype)
+    m, n = A_csr.shape
+    data = np.ascontiguousarray(A_csr.data, dtype=dtype)
+    ptr = np.ascontiguousarray(A_csr.indptr, dtype=np.int32)
+    ind = np.ascontiguousarray(A_csr.indices, dtype=np.int32)
+    f = _coef_arrays(f, dtype)
+    g = _coef_arrays(g, dtype)
+    x = np.zeros(n, dtype)
+    y = np.zeros(m, dtype)
+    l = np.zeros(m, dtype)
+    optval = c()
+    final_iter = ctypes.c_uint()
+    args = [ctypes.c_int(1), ctypes.c_size_t(m), ctypes.c_size_t(n), ctypes.c_size_t(len(data)),
+            _p(data), _p(ptr), _p(ind),
+            _p(f["a"]), _p(f["b"]), _p(f["c"]), _p(f["d"]), _p(f["e"]), _p(f["h"]),
+            _p(g["a"]), _p(g["b"]), _p(g["c"]), _p(g["d"]), _p(g["e"]), _p(g["h"]),
+            c(rho), c(abs_tol), c(rel_tol), ctypes.c_uint(max_iter), ctypes.c_uint(verbose),
+            ctypes.c_int(int(adaptive_rho)), ctypes.c_int(int(gap_stop)),
+            _p(x), _p(y), _p(l), ctypes.byref(optval), ctypes.byref(final_iter)]
+    if info is not None:
+        args.append(ctypes.byref(info))
+    status = fn(*args)
+    return _result(x, y, l, optval, final_iter, status, info)
+
+
+def oracle_solve(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0,
+                 adaptive_rho=True, gap_stop=True, order=1, use_cgls=False, want_de=False):
+    """Run the oracle through its PogsD/S-shaped entry.  A dense ndarray or scipy CSR."""
+    lib = oracle_lib()
+    info = OracleInfo()
+    info.use_cgls = int(use_cgls)
+    sparse = hasattr(A, "indptr")
+    m, n = A.shape
+    keep = None
+    if want_de:
+        keep = (np.zeros(m), np.zeros(n))
+        info.d_out = keep[0].ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        info.e_out = keep[1].ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    if sparse:
+        fn = lib.OraclePogsSparseD if dtype == np.float64 else lib.OraclePogsSparseS
+        r = _solve_sparse(fn, A, f, g, dtype, rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop, info)
+    else:
+        fn = lib.OraclePogsD if dtype == np.float64 else lib.OraclePogsS
+        r = _solve_dense(fn, A, f, g, dtype, rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop, order,
+                         info)
+    if keep is not None:
+        r["d"], r["e"] = keep
+    return r
+
+
+def ref_solve(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0,
+              adaptive_rho=True, gap_stop=True, order=1):
+    """Run the compiled reference (PogsD/S, PogsSparseD/S).  None if unavailable."""
+    lib = ref_lib()
+    if lib is None:
+        return None
+    sparse = hasattr(A, "indptr")
+    if sparse:
+        fn = lib.PogsSparseD if dtype == np.float64 else lib.PogsSparseS
+        return _solve_sparse(fn, A, f, g, dtype, rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop)
+    fn = lib.PogsD if dtype == np.float64 else lib.PogsS
+    return _solve_dense(fn, A, f, g, dtype, rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop, order)
+
+
+def oracle_solve_shard(A_local, m_global, f_local, g, allreduce, dtype=np.float64, rho=1.0, abs_tol=1e-4,
+                       rel_tol=1e-4, max_iter=2500, verbose=0, adaptive_rho=True, gap_stop=True):
+    """Row-sharded oracle: `allreduce(np.ndarray float64)` sums in place across ranks."""
+    lib = oracle_lib()
+    c = _ct(dtype)
+    A = np.ascontiguousarray(A_local, dtype=dtype)
+    m, n = A.shape
+    f = _coef_arrays(f_local, dtype)
+    gg = _coef_arrays(g, dtype)
+    x = np.zeros(n, dtype)
+    y = np.zeros(m, dtype)
+    l = np.zeros(m, dtype)
+    optval = c()
+    final_iter = ctypes.c_uint()
+    info = OracleInfo()
+
+    def _cb(_ctx, buf, count):
+        arr = np.ctypeslib.as_array(buf, shape=(count,))
+        allreduce(arr)
+
+    cb = ALLREDUCE_FN(_cb)
+    fn = lib.OraclePogsShardD if dtype == np.float64 else lib.OraclePogsShardS
+    status = fn(ctypes.c_size_t(m), ctypes.c_size_t(m_global), ctypes.c_size_t(n), _p(A),
+                _p(f["a"]), _p(f["b"]), _p(f["c"]), _p(f["d"]), _p(f["e"]), _p(f["h"]),
+                _p(gg["a"]), _p(gg["b"]), _p(gg["c"]), _p(gg["d"]), _p(gg["e"]), _p(gg["h"]),
+                c(rho), c(abs_tol), c(rel_tol), ctypes.c_uint(max_iter), ctypes.c_uint(verbose),
+                ctypes.c_int(int(adaptive_rho)), ctypes.c_int(int(gap_stop)),
+                _p(x), _p(y), _p(l), ctypes.byref(optval), ctypes.byref(final_iter), ctypes.byref(info),
+                cb, None)
+    return _result(x, y, l, optval, final_iter, status, info)
+
+
+def oracle_prox(objs, rho, v, dtype=np.float64):
+    lib = oracle_lib()
+    c = _ct(dtype)
+    o = _coef_arrays(objs, dtype)
+    v = np.ascontiguousarray(v, dtype=dtype)
+    out = np.zeros_like(v)
+    fn = lib.OracleProxEvalD if dtype == np.float64 else lib.OracleProxEvalS
+    fn(ctypes.c_size_t(len(v)), _p(o["h"]), _p(o["a"]), _p(o["b"]), _p(o["c"]), _p(o["d"]), _p(o["e"]), c(rho),
+       _p(v), _p(out))
+    return out
+
+
+def oracle_func(objs, v, dtype=np.float64):
+    lib = oracle_lib()
+    o = _coef_arrays(objs, dtype)
+    v = np.ascontiguousarray(v, dtype=dtype)
+    fn = lib.OracleFuncEvalD if dtype == np.float64 else lib.OracleFuncEvalS
+    return fn(ctypes.c_size_t(len(v)), _p(o["h"]), _p(o["a"]), _p(o["b"]), _p(o["c"]), _p(o["d"]), _p(o["e"]), _p(v))
+
+
+def oracle_prox_raw(h, v, rho, dtype=np.float64):
+    lib = oracle_lib()
+    if dtype == np.float64:
+        return lib.OracleProxRawD(int(h), float(v), float(rho))
+    return lib.OracleProxRawS(int(h), float(v), float(rho))
+
+
+def oracle_rand(n, dtype=np.float64):
+    lib = oracle_lib()
+    x = np.zeros(n, dtype)
+    (lib.OracleRandD if dtype == np.float64 else lib.OracleRandS)(_p(x), ctypes.c_size_t(n))
+    return x
+
+
+def oracle_project(A, x0, y0, s=1.0, tol=1e-8, use_cgls=False, dtype=np.float64):
+    lib = oracle_lib()
+    c = _ct(dtype)
+    A = np.ascontiguousarray(A, dtype=dtype)
+    m, n = A.shape
+    x0 = np.ascontiguousarray(x0, dtype=dtype)
+    y0 = np.ascontiguousarray(y0, dtype=dtype)
+    x = np.zeros(n, dtype)
+    y = np.zeros(m, dtype)
+    fn = lib.OracleProjectD if dtype == np.float64 else lib.OracleProjectS
+    fn(ctypes.c_size_t(m), ctypes.c_size_t(n), _p(A), _p(x0), _p(y0), c(s), c(tol), ctypes.c_int(int(use_cgls)),
+       _p(x), _p(y))
+    return x, y
+
+
+def oracle_equil(A, dtype=np.float64):
+    lib = oracle_lib()
+    c = _ct(dtype)
+    A = np.array(A, dtype=dtype, order="C", copy=True)
+    m, n = A.shape
+    d = np.zeros(m, dtype)
+    e = np.zeros(n, dtype)
+    nrm = c()
+    kpow = ctypes.c_uint()
+    fn = lib.OracleEquilD if dtype == np.float64 else lib.OracleEquilS
+    fn(ctypes.c_size_t(m), ctypes.c_size_t(n), _p(A), _p(d), _p(e), ctypes.byref(nrm), ctypes.byref(kpow))
+    return A, d, e, nrm.value, kpow.value

@@ -1,0 +1,323 @@
+"""GPU parity tests for the dense path: HIP engine (through the C ABI) vs the CPU oracle.
+
+Tolerances (SURVEY.md section 8(c) "parity definition"):
+  * prox / function library: rtol 1e-12 (f64), 2e-5 (f32; device expf/logf differ
+    from the host libm by ulps, and ProxLogistic stops its bisection at 1e-5);
+  * equilibration scalings d, e: 1e-10 (f64) / 2e-5 (f32) relative;
+  * full solves at default tolerances: ||dx||/||x|| <= 1e-4, |d optval|/|optval| <= 1e-4,
+    iteration count within +-10% (+-3); fp64 small problems follow the oracle's
+    trajectory, so there the bar is 1e-6 and the same iteration count +-2.
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from helpers import PROBLEMS, objective, relerr, soa
+
+pytestmark = pytest.mark.gpu
+
+
+def _pogs():
+    import pogs_amd
+
+    return pogs_amd
+
+
+def _tol(dtype, f64, f32):
+    return f64 if dtype == np.float64 else f32
+
+
+# --------------------------------------------------------------------------- prox
+ALL_FUNCS = list(range(16))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_prox_library_matches_oracle(dtype):
+    pogs = _pogs()
+    rng = np.random.default_rng(1)
+    n = 4096
+    for h in ALL_FUNCS:
+        fv = pogs.FunctionVector(n, h, a=rng.uniform(0.5, 2.0, n) * rng.choice([-1, 1], n),
+                                 b=rng.normal(0, 0.5, n), c=rng.uniform(0.2, 3.0, n), d=rng.normal(0, 0.3, n),
+                                 e=rng.uniform(0.0, 1.0, n))
+        v = rng.normal(0, 3.0, n)
+        for rho in (0.1, 1.0, 7.5):
+            got = pogs.prox_eval(fv, rho, v, dtype=dtype)
+            want = ob.oracle_prox(soa(fv), rho, v, dtype=dtype)
+            assert np.all(np.isfinite(got) == np.isfinite(want)), (h, rho)
+            ok = np.isfinite(want)
+            rtol = _tol(dtype, 1e-9, 5e-4 if h in (1, 8, 11, 13) else 5e-5)
+            atol = _tol(dtype, 1e-9, 5e-5 if h == 8 else 1e-5)
+            np.testing.assert_allclose(got[ok], want[ok], rtol=rtol, atol=atol, err_msg=f"h={h} rho={rho}")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_func_eval_matches_oracle(dtype):
+    pogs = _pogs()
+    rng = np.random.default_rng(2)
+    n = 5000
+    for h in ALL_FUNCS:
+        fv = pogs.FunctionVector(n, h, a=rng.uniform(0.5, 2.0, n), b=rng.normal(0, 0.5, n),
+                                 c=rng.uniform(0.2, 3.0, n), d=rng.normal(0, 0.3, n), e=rng.uniform(0.0, 1.0, n))
+        v = rng.uniform(0.1, 3.0, n)  # positive: NegLog / Recipr / NegEntr domains
+        got = pogs.func_eval(fv, v, dtype=dtype)
+        want = ob.oracle_func(soa(fv), v, dtype=np.float64)
+        assert got == pytest.approx(want, rel=_tol(dtype, 1e-10, 2e-4)), h
+
+
+def test_prox_known_answers_from_reference_tests():
+    """Closed-form values pinned by the reference's tests/test_proximal.cpp:12-220."""
+    pogs = _pogs()
+    F = pogs.Function
+    cases = [(F.kZero, 5.0, 1.0, 5.0), (F.kIdentity, 5.0, 2.0, 4.5), (F.kAbs, 2.0, 2.0, 1.5),
+             (F.kAbs, 0.3, 2.0, 0.0), (F.kAbs, -2.0, 2.0, -1.5), (F.kAbs, 0.5, 2.0, 0.0), (F.kAbs, 0.0, 2.0, 0.0),
+             (F.kSquare, 6.0, 3.0, 4.5), (F.kSquare, -4.0, 3.0, -3.0), (F.kIndEq0, 5.0, 1.0, 0.0),
+             (F.kIndGe0, 3.0, 1.0, 3.0), (F.kIndGe0, -2.0, 1.0, 0.0), (F.kIndLe0, -3.0, 1.0, -3.0),
+             (F.kIndLe0, 2.0, 1.0, 0.0), (F.kIndBox01, 0.5, 1.0, 0.5), (F.kIndBox01, -0.5, 1.0, 0.0),
+             (F.kIndBox01, 1.5, 1.0, 1.0), (F.kMaxPos0, 3.0, 2.0, 2.5), (F.kMaxPos0, 0.3, 2.0, 0.0),
+             (F.kMaxPos0, -1.0, 2.0, -1.0), (F.kMaxNeg0, -3.0, 2.0, -2.5), (F.kMaxNeg0, -0.3, 2.0, 0.0),
+             (F.kMaxNeg0, 1.0, 2.0, 1.0), (F.kHuber, 0.5, 2.0, 0.5 * 2.0 / 3.0), (F.kHuber, 5.0, 2.0, 4.5),
+             (F.kHuber, -5.0, 2.0, -4.5), (F.kHuber, 0.0, 2.0, 0.0)]
+    for h, v, rho, want in cases:
+        got = pogs.prox_eval(pogs.FunctionVector(1, h), rho, np.array([v]))[0]
+        assert got == pytest.approx(want, abs=1e-12), (h, v, rho)
+    # optimality conditions (test_proximal.cpp:222-262)
+    for v in (2.0, 0.0, -1.0):
+        r = pogs.prox_eval(pogs.FunctionVector(1, F.kExp), 1.0, np.array([v]))[0]
+        assert r + np.exp(r) == pytest.approx(v, abs=1e-6)
+    r = pogs.prox_eval(pogs.FunctionVector(1, F.kNegLog), 2.0, np.array([3.0]))[0]
+    assert r > 0 and r - 1.0 / (2.0 * r) == pytest.approx(3.0, abs=1e-6)
+
+
+# --------------------------------------------------------------------------- setup pieces
+SHAPES = [(500, 300), (1000, 257), (2003, 64), (64, 10), (3000, 1100)]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_equilibration_and_norm_estimate(dtype, shape):
+    pogs = _pogs()
+    m, n = shape
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((m, n)) * rng.uniform(0.1, 10.0, (m, 1)) * rng.uniform(0.1, 10.0, (1, n))
+    with pogs.Solver(A, dtype=dtype) as s:
+        A_eq, d, e, nrmA = s.equilibrated()
+        st = s.stats()
+    A_o, d_o, e_o, nrm_o, kpow_o = ob.oracle_equil(A, dtype=dtype)
+    assert relerr(d, d_o) < _tol(dtype, 1e-10, 3e-5)
+    assert relerr(e, e_o) < _tol(dtype, 1e-10, 3e-5)
+    assert relerr(A_eq, A_o) < _tol(dtype, 1e-10, 3e-5)
+    # Frobenius normalisation: ||A_eq||_F^2 == min(m, n)
+    assert np.sum(A_eq.astype(np.float64) ** 2) == pytest.approx(min(m, n), rel=_tol(dtype, 1e-10, 1e-4))
+    assert nrmA == pytest.approx(nrm_o, rel=2e-3)
+    sig = np.linalg.norm(A_o.astype(np.float64), 2)
+    assert nrmA <= sig * 1.001 and nrmA >= 0.9 * sig
+    assert 1 <= st["norm_est_iters"] <= 50
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_mul_matches_numpy(dtype, shape):
+    pogs = _pogs()
+    m, n = shape
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((m, n))
+    with pogs.Solver(A, dtype=dtype) as s:
+        A_eq, _, _, _ = s.equilibrated()
+        A64 = A_eq.astype(np.float64)
+        x, y = rng.standard_normal(n), rng.standard_normal(m)
+        got = s.mul("n", 1.5, x, -0.5, y)
+        assert relerr(got, 1.5 * A64 @ x - 0.5 * y) < _tol(dtype, 1e-12, 2e-5)
+        got = s.mul("n", 1.0, x, 0.0, y)
+        assert relerr(got, A64 @ x) < _tol(dtype, 1e-12, 2e-5)
+        got = s.mul("t", 2.0, y, 1.0, x)
+        assert relerr(got, 2.0 * A64.T @ y + x) < _tol(dtype, 1e-12, 2e-5)
+        got = s.mul("t", 1.0, y, 0.0, x)
+        assert relerr(got, A64.T @ y) < _tol(dtype, 1e-12, 2e-5)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_projection_kkt(dtype, shape):
+    """The reference's debug-only CheckProjection (src/cpu/include/projector_helper.h:12-41)
+    as a real test: y = A x and A^T (A x - y0) + (x - x0) = 0, plus agreement with
+    the oracle's Cholesky projector."""
+    pogs = _pogs()
+    m, n = shape
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((m, n))
+    x0, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    with pogs.Solver(A, dtype=dtype) as s:
+        A_eq, _, _, _ = s.equilibrated()
+        x, y = s.project(x0, y0)
+    A64 = A_eq.astype(np.float64)
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    eps = _tol(dtype, 1e-10, 2e-4)
+    assert np.linalg.norm(A64 @ x64 - y64) / np.sqrt(m) < eps
+    kkt = A64.T @ (A64 @ x64 - y0) + (x64 - x0)
+    assert np.linalg.norm(kkt) / np.sqrt(n) < eps
+    xo, yo = ob.oracle_project(A_eq, x0, y0, dtype=dtype)
+    assert relerr(x, xo) < _tol(dtype, 1e-9, 1e-4)
+    assert relerr(y, yo) < _tol(dtype, 1e-9, 1e-4)
+
+
+# --------------------------------------------------------------------------- full solves
+def _check_solution(A, f, g, got, want, dtype, tight):
+    assert got["status"] == want["status"] == 0
+    it_g, it_w = got["iterations"], want["iterations"]
+    slack = 2 if tight else max(3, int(0.1 * it_w))
+    assert abs(it_g - it_w) <= slack, (it_g, it_w)
+    xtol = 1e-6 if tight else 1e-4
+    assert relerr(got["x"], want["x"]) < xtol
+    assert relerr(got["y"], want["y"]) < xtol
+    assert relerr(got["l"], want["l"]) < 10 * xtol
+    assert got["optval"] == pytest.approx(want["optval"], rel=1e-4 if not tight else 1e-7)
+    # returned optval is the objective at the returned point (pogs.cpp:473)
+    obj = objective(np.asarray(A, np.float64), f, g, got["x"].astype(np.float64))
+    assert obj == pytest.approx(want["optval"], rel=5e-3, abs=1e-3)
+
+
+def test_c1_readme_lasso_fp64():
+    """C1: solve_lasso dense fp64 500x300, lambda = 0.1 (README.md:55-59)."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, lam = synth.readme_lasso()
+    got = pogs.solve_lasso(A, b, lam)
+    f, g = pogs.graph.lasso_functions(b, lam, 300)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float64)
+    _check_solution(A, f, g, got, want, np.float64, tight=True)
+    # golden numbers of the compiled reference (SURVEY.md section 6 probe)
+    assert got["status"] == 0
+    assert abs(got["iterations"] - 100) <= 2
+    assert got["optval"] == pytest.approx(91.76711931681265, rel=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("problem", list(PROBLEMS))
+def test_solve_families_200x100(problem, dtype):
+    """Each of the seven solve_* encodings (+ unregularised logistic) on 200x100."""
+    pogs = _pogs()
+    rng = np.random.default_rng(7)
+    m, n = 200, 100
+    A = rng.standard_normal((m, n))
+    b = A @ (rng.standard_normal(n) * (rng.random(n) < 0.2)) + 0.1 * rng.standard_normal(m)
+    f, g = PROBLEMS[problem](b, n)
+    got = pogs._solve_graph_form(A, f, g, dtype=dtype)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype)
+    _check_solution(A, f, g, got, want, dtype, tight=(dtype == np.float64))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(2000, 300), (1000, 257), (4000, 1100)])
+def test_lasso_dense_sizes(dtype, shape):
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    m, n = shape
+    A, b, _ = synth.dense_lasso(m, n, seed=11, dtype=dtype)
+    got = pogs.solve_lasso(A, b, 0.1, dtype=dtype)
+    f, g = pogs.graph.lasso_functions(b, 0.1, n)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype)
+    _check_solution(A, f, g, got, want, dtype, tight=False)
+
+
+def test_logistic_fp32_4000x200():
+    """Scaled-down C3 (solve_logistic dense fp32, lambda = 0.01)."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, y, _ = synth.dense_logistic(4000, 200, seed=5, dtype=np.float32)
+    got = pogs.solve_logistic(A, y, 0.01, dtype=np.float32)
+    f, g = pogs.graph.logistic_functions(y, 0.01, 200)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float32)
+    _check_solution(A, f, g, got, want, np.float32, tight=False)
+
+
+def test_tight_tolerance_converges_to_same_point():
+    """abs_tol = rel_tol = 1e-6: both engines land on the same optimum (<= 1e-5)."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.dense_lasso(600, 150, seed=3)
+    got = pogs.solve_lasso(A, b, 0.1, abs_tol=1e-6, rel_tol=1e-6)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 150)
+    want = ob.oracle_solve(A, soa(f), soa(g), abs_tol=1e-6, rel_tol=1e-6)
+    assert got["status"] == 0 and want["status"] == 0
+    assert relerr(got["x"], want["x"]) < 1e-5
+
+
+def test_max_iter_status_and_final_iter():
+    """final_iter is the 0-based index of the last iteration and 3 means max-iter
+    (src/cpu/pogs.cpp:391-393, src/include/pogs.h:31-37; SURVEY.md findings 1-2)."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, lam = synth.readme_lasso()
+    r = pogs.solve_lasso(A, b, lam, max_iter=5)
+    assert r["status"] == 3
+    assert r["iterations"] == 4
+
+
+def test_column_major_input_matches_row_major():
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.dense_lasso(700, 130, seed=2)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 130)
+    with pogs.Solver(A, dtype=np.float64) as s:
+        r1 = s.solve(f, g)
+    with pogs.Solver(A, dtype=np.float64, order=pogs.Ordering.COL_MAJ) as s:
+        r2 = s.solve(f, g)
+    assert r1["iterations"] == r2["iterations"]
+    assert relerr(r2["x"], r1["x"]) < 1e-9
+
+
+def test_handle_reuse_and_mu():
+    """One factorisation, several solves (lambda path); mu = -A^T lambda at the optimum."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.dense_lasso(800, 120, seed=9)
+    with pogs.Solver(A, dtype=np.float64) as s:
+        for lam in (0.5, 0.1):
+            f, g = pogs.graph.lasso_functions(b, lam, 120)
+            r = s.solve(f, g, abs_tol=1e-6, rel_tol=1e-6)
+            one = pogs.solve_lasso(A, b, lam, abs_tol=1e-6, rel_tol=1e-6)
+            assert r["iterations"] == one["iterations"]
+            assert relerr(r["x"], one["x"]) < 1e-12
+            assert np.linalg.norm(r["mu"] + A.T @ r["l"]) / max(np.linalg.norm(r["mu"]), 1e-12) < 1e-3
+
+
+def test_iterate_matches_solve_trajectory():
+    """bench stepping: begin_run + iterate(k) walks the same trajectory as solve()."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.dense_lasso(900, 140, seed=4, dtype=np.float32)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 140)
+    with pogs.Solver(A, dtype=np.float32, profile=True) as s:
+        r = s.solve(f, g)
+        n_it = r["iterations"] + 1
+        s.reset_stats()
+        s.begin_run(f, g)
+        sec, solves = s.iterate(n_it)
+        assert solves == 0
+        sec, solves = s.iterate(n_it)  # second solve restarts from the cold start
+        assert solves == 1
+        st = s.stats()
+        assert st["iterations"] == 2 * n_it
+        assert st["stream_launches"] >= 4 * n_it
+        assert st["stream_ms"] > 0
+
+
+def test_reference_c_interface_lasso_2x2():
+    """tests/test_c_interface.cpp:16-72: PogsD on the 2x2 lasso, status 0, optval >= 0, |Ax - y|_1 < 0.1."""
+    pogs = _pogs()
+    A = np.array([[1.0, 1.0], [1.0, -1.0]])
+    b = np.array([2.0, 0.0])
+    f, g = pogs.graph.lasso_functions(b, 0.1, 2)
+    r = pogs._solve_graph_form(A, f, g, abs_tol=1e-4, rel_tol=1e-3, max_iter=1000, gap_stop=False)
+    assert r["status"] == 0
+    assert r["optval"] >= 0
+    assert np.abs(A @ r["x"] - r["y"]).sum() < 0.1
