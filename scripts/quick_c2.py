@@ -3,6 +3,8 @@ import json
 import sys
 import time
 
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import torch
 

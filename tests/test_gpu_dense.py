@@ -163,8 +163,13 @@ def test_projection_kkt(dtype, shape):
 
 # --------------------------------------------------------------------------- full solves
 def _check_solution(A, f, g, got, want, dtype, tight):
-    assert got["status"] == want["status"] == 0
+    from helpers import _fsum
+
+    assert got["status"] == want["status"]
     it_g, it_w = got["iterations"], want["iterations"]
+    if want["status"] != 0:  # e.g. unbounded problem: both engines must run into max_iter
+        assert it_g == it_w
+        return
     slack = 2 if tight else max(3, int(0.1 * it_w))
     assert abs(it_g - it_w) <= slack, (it_g, it_w)
     xtol = 1e-6 if tight else 1e-4
@@ -172,9 +177,13 @@ def _check_solution(A, f, g, got, want, dtype, tight):
     assert relerr(got["y"], want["y"]) < xtol
     assert relerr(got["l"], want["l"]) < 10 * xtol
     assert got["optval"] == pytest.approx(want["optval"], rel=1e-4 if not tight else 1e-7)
-    # returned optval is the objective at the returned point (pogs.cpp:473)
-    obj = objective(np.asarray(A, np.float64), f, g, got["x"].astype(np.float64))
-    assert obj == pytest.approx(want["optval"], rel=5e-3, abs=1e-3)
+    # optval is sum f(y) + sum g(x) at the returned prox point (pogs.cpp:473), where
+    # y only approximately equals A x; check it independently in float64 numpy.
+    obj = _fsum(f, got["y"].astype(np.float64)) + _fsum(g, got["x"].astype(np.float64))
+    assert obj == pytest.approx(got["optval"], rel=_tol(dtype, 1e-9, 1e-4), abs=_tol(dtype, 1e-9, 1e-4))
+    # and the true objective at x is close to it once converged
+    true_obj = objective(np.asarray(A, np.float64), f, g, got["x"].astype(np.float64))
+    assert true_obj == pytest.approx(got["optval"], rel=0.05, abs=1e-2)
 
 
 def test_c1_readme_lasso_fp64():
