@@ -53,7 +53,6 @@ def build_ref():
 
 
 _oracle = None
-_ref = None
 
 
 def oracle_lib():
@@ -67,20 +66,6 @@ def oracle_lib():
         _oracle.OracleProxRawS.restype = ctypes.c_float
         _oracle.OracleProxRawS.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_float]
     return _oracle
-
-
-def ref_lib():
-    """The compiled reference, or None when it is not available/loadable."""
-    global _ref
-    if _ref is None:
-        path = _REF_SO if os.path.exists(_REF_SO) else None
-        if path is None:
-            return None
-        try:
-            _ref = ctypes.CDLL(path)
-        except OSError:
-            return None
-    return _ref
 
 
 def _ct(dtype):
@@ -181,18 +166,56 @@ def oracle_solve(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4,
     return r
 
 
+def ref_available():
+    return os.path.exists(_REF_SO)
+
+
 def ref_solve(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0,
-              adaptive_rho=True, gap_stop=True, order=1):
-    """Run the compiled reference (PogsD/S, PogsSparseD/S).  None if unavailable."""
-    lib = ref_lib()
-    if lib is None:
+              adaptive_rho=True, gap_stop=True, order=1, timeout=None):
+    """Run the compiled reference (PogsD/S, PogsSparseD/S) in a CLEAN subprocess.
+
+    The reference links MKL; in a process that has PyTorch loaded (its own OpenMP /
+    BLAS symbols) MKL's threading layer mis-binds and the reference returns NaN, so
+    it never shares a process with torch.  Returns None if the reference is not
+    available; raises subprocess.TimeoutExpired on timeout.  The result carries
+    't_total' / 't_init' parsed from the reference's own verbose=1 summary
+    (src/cpu/pogs.cpp:485-490) when verbose >= 1.
+    """
+    import sys
+    import tempfile
+
+    if not ref_available():
         return None
     sparse = hasattr(A, "indptr")
-    if sparse:
-        fn = lib.PogsSparseD if dtype == np.float64 else lib.PogsSparseS
-        return _solve_sparse(fn, A, f, g, dtype, rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop)
-    fn = lib.PogsD if dtype == np.float64 else lib.PogsS
-    return _solve_dense(fn, A, f, g, dtype, rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop, order)
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        inp, outp = os.path.join(td, "in.npz"), os.path.join(td, "out.npz")
+        payload = {"dtype": np.dtype(dtype).name, "params": np.array([rho, abs_tol, rel_tol, max_iter, verbose,
+                                                                      int(adaptive_rho), int(gap_stop), order],
+                                                                     dtype=np.float64)}
+        for k in "habcde":
+            payload["f_" + k] = np.asarray(f[k])
+            payload["g_" + k] = np.asarray(g[k])
+        if sparse:
+            payload.update(sp_data=np.asarray(A.data, dtype=dtype), sp_ptr=np.asarray(A.indptr, np.int32),
+                           sp_ind=np.asarray(A.indices, np.int32), sp_shape=np.array(A.shape))
+        else:
+            np.save(os.path.join(td, "A.npy"), np.asarray(A, dtype=dtype))
+        np.savez(inp, **payload)
+        env = dict(os.environ)
+        env.pop("PYTHONPATH", None)
+        cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_runner.py"), td]
+        proc = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        if proc.returncode != 0 or not os.path.exists(outp):
+            raise RuntimeError("reference runner failed:\n" + proc.stdout[-2000:] + proc.stderr[-2000:])
+        z = np.load(outp)
+        r = {"x": z["x"], "y": z["y"], "l": z["l"], "optval": float(z["optval"]), "iterations": int(z["iterations"]),
+             "status": int(z["status"]), "wall_s": float(z["wall_s"]), "stdout": proc.stdout}
+        import re
+
+        mt = re.search(r"Total = ([0-9.eE+-]+) s, Init = ([0-9.eE+-]+) s", proc.stdout)
+        if mt:
+            r["t_total"], r["t_init"] = float(mt.group(1)), float(mt.group(2))
+        return r
 
 
 def oracle_solve_shard(A_local, m_global, f_local, g, allreduce, dtype=np.float64, rho=1.0, abs_tol=1e-4,

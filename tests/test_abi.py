@@ -1,0 +1,69 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU and exports
+every symbol include/pogs_amd.h declares; enum layouts match the reference's
+(src/interface_c/pogs_c.h:51-69, pinned by tests/test_c_interface.cpp:149-154)."""
+import ctypes
+import os
+import re
+
+import pogs_amd
+from pogs_amd import _lib
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+HEADER = open(os.path.join(ROOT, "include", "pogs_amd.h")).read()
+
+
+def declared_functions():
+    body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    names = re.findall(r"\b(?:int|void|const char \*)\s*(Pogs\w*)\s*\(", body)
+    return sorted(set(names))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    names = declared_functions()
+    assert set(names) == set(_lib.ABI_SYMBOLS), set(names) ^ set(_lib.ABI_SYMBOLS)
+    for n in names:
+        assert getattr(_lib.lib, n) is not None
+    for n in ("PogsD", "PogsS", "PogsSparseD", "PogsSparseS"):  # the reference's graph-form symbols
+        assert n in names
+
+
+def _enum(name):
+    m = re.search(r"enum\s+%s\s*\{(.*?)\}" % name, HEADER, flags=re.S)
+    items = [t.strip() for t in re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S).split(",") if t.strip()]
+    out, nxt = {}, 0
+    for it in items:
+        if "=" in it:
+            k, v = [s.strip() for s in it.split("=")]
+            nxt = int(v)
+        else:
+            k = it
+        out[k] = nxt
+        nxt += 1
+    return out
+
+
+def test_enum_layout_matches_reference():
+    fn = _enum("FUNCTION")
+    assert fn["ABS"] == 0 and fn["SQUARE"] == 14 and fn["ZERO"] == 15  # tests/test_c_interface.cpp:149-154
+    order = ["ABS", "EXP", "HUBER", "IDENTITY", "INDBOX01", "INDEQ0", "INDGE0", "INDLE0", "LOGISTIC", "MAXNEG0",
+             "MAXPOS0", "NEGENTR", "NEGLOG", "RECIPR", "SQUARE", "ZERO"]
+    assert [fn[k] for k in order] == list(range(16))
+    assert _enum("ORD") == {"COL_MAJ": 0, "ROW_MAJ": 1}
+    st = _enum("POGS_STATUS")
+    assert st["POGS_SUCCESS"] == 0 and st["POGS_MAX_ITER"] == 3 and st["POGS_NAN_FOUND"] == 4 and st["POGS_ERROR"] == 6
+    # the Python mirror uses the same numbers (python/pogs/graph.py:114-132)
+    for k, v in pogs_amd.Function.__members__.items():
+        assert fn[k[1:].upper()] == int(v)
+    assert int(pogs_amd.Ordering.ROW_MAJ) == 1
+
+
+def test_struct_sizes_are_stable():
+    assert ctypes.sizeof(_lib.PogsAmdDist) == 4 + 4 + 8 + 128
+    assert ctypes.sizeof(_lib.PogsAmdOptions) == 32
+    assert ctypes.sizeof(_lib.PogsAmdStats) % 8 == 0
+
+
+def test_every_part1_entry_cites_the_reference_interface():
+    for n in ("PogsD", "PogsS", "PogsSparseD", "PogsSparseS"):
+        i = HEADER.index("int %s(" % n)
+        assert "replaces: src/interface_c/pogs_c.h" in HEADER[max(0, i - 400):i]

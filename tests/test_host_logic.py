@@ -1,0 +1,86 @@
+"""CPU tests of the host-side mirror of python/pogs/graph.py: the function encodings
+of the seven solve_* problems equal, array for array, what the reference's own
+Python layer hands to PogsD (captured in tests/golden/python_layer.npz), the API
+surface is the same, and input validation behaves like the reference."""
+import inspect
+import os
+
+import numpy as np
+import pytest
+
+import pogs_amd
+from pogs_amd import graph as G
+
+PL = np.load(os.path.join(os.path.dirname(__file__), "golden", "python_layer.npz"))
+A, b = PL["A"], PL["b"]
+lab = np.sign(b)
+n = A.shape[1]
+
+CASES = {
+    "lasso": lambda: G.lasso_functions(b, 0.1, n),
+    "ridge": lambda: G.ridge_functions(b, 0.5, n),
+    "elastic_net": lambda: G.elastic_net_functions(b, 0.1, 0.2, n),
+    "logistic": lambda: G.logistic_functions(lab, 0.01, n),
+    "logistic0": lambda: G.logistic_functions(lab, 0.0, n),
+    "huber": lambda: G.huber_functions(b, 1.5, 0.05, n),
+    "svm": lambda: G.svm_functions(lab, 1.0, n),
+    "nonneg_ls": lambda: G.nonneg_ls_functions(b, n),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_encodings_equal_reference_python_layer(name):
+    f, g = CASES[name]()
+    fa, ga = f.arrays(np.float64), g.arrays(np.float64)
+    for k in "abcde":
+        np.testing.assert_array_equal(fa[k], PL["%s_f_%s" % (name, k)])
+        np.testing.assert_array_equal(ga[k], PL["%s_g_%s" % (name, k)])
+    np.testing.assert_array_equal(fa["h"], PL["%s_f_h" % name])
+    np.testing.assert_array_equal(ga["h"], PL["%s_g_h" % name])
+    # defaults the reference passes down: rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop
+    np.testing.assert_allclose(PL["%s_scalars" % name], [1.0, 1e-4, 1e-4, 2500, 0, 1, 1])
+
+
+def test_elastic_net_quirk_is_reproduced():
+    """graph.py:522 passes e = lambda2 / 2 while the engine's term is e x^2 / 2."""
+    _, g = G.elastic_net_functions(b, 0.1, 0.2, n)
+    assert np.all(g.e == 0.1) and np.all(g.c == 0.1) and np.all(g.h == int(G.Function.kAbs))
+
+
+def test_solve_signatures_match_reference():
+    expect = {
+        "solve_lasso": ["A", "b", "lambd", "abs_tol", "rel_tol", "max_iter", "verbose", "rho"],
+        "solve_ridge": ["A", "b", "lambd", "abs_tol", "rel_tol", "max_iter", "verbose", "rho"],
+        "solve_elastic_net": ["A", "b", "lambda1", "lambda2", "abs_tol", "rel_tol", "max_iter", "verbose", "rho"],
+        "solve_logistic": ["A", "b", "lambd", "abs_tol", "rel_tol", "max_iter", "verbose", "rho"],
+        "solve_huber": ["A", "b", "delta", "lambd", "abs_tol", "rel_tol", "max_iter", "verbose", "rho"],
+        "solve_svm": ["A", "b", "lambd", "abs_tol", "rel_tol", "max_iter", "verbose", "rho"],
+        "solve_nonneg_ls": ["A", "b", "abs_tol", "rel_tol", "max_iter", "verbose", "rho"],
+    }
+    for name, params in expect.items():
+        sig = inspect.signature(getattr(pogs_amd, name))
+        got = list(sig.parameters)
+        assert got[:len(params)] == params and got[len(params):] == ["dtype"]
+        assert sig.parameters["abs_tol"].default == 1e-4 and sig.parameters["rel_tol"].default == 1e-4
+        assert sig.parameters["max_iter"].default == 2500 and sig.parameters["rho"].default == 1.0
+    assert inspect.signature(pogs_amd.solve_logistic).parameters["lambd"].default == 0.0
+    assert inspect.signature(pogs_amd.solve_svm).parameters["lambd"].default == 1.0
+    assert inspect.signature(pogs_amd.solve_huber).parameters["delta"].default == 1.0
+
+
+def test_function_vector_and_objects_agree():
+    objs = [G.FunctionObj(G.Function.kSquare, 1.0, float(bi), 1.0) for bi in b]
+    fv = G.FunctionVector.from_objs(objs)
+    f, _ = G.lasso_functions(b, 0.1, n)
+    for k in "habcde":
+        np.testing.assert_array_equal(getattr(fv, k), getattr(f, k))
+    sl = f.slice(3, 9)
+    assert len(sl) == 6 and np.array_equal(sl.b, b[3:9])
+
+
+def test_length_validation_like_reference():
+    f, g = G.lasso_functions(b, 0.1, n)
+    with pytest.raises(AssertionError):  # graph.py:292-293
+        G._solve_graph_form(A, f.slice(0, 5), g)
+    with pytest.raises(ValueError):
+        G._solve_graph_form(A, f, g, dtype=np.int32)
