@@ -1,11 +1,916 @@
-// Sparse graph-form ADMM solver with the CGLS projector (placeholder until built).
+// Sparse graph-form ADMM solver with the CGLS projector.
+//
+// Reference call stack being replaced:
+//   PogsSparseD/S -> PogsSparse<T,O> (src/interface_c/pogs_c.cpp:57-108)
+//     MatrixSparse::Init/Mul/Equil (src/cpu/matrix/matrix_sparse.cpp:97-302,
+//       gsl_spblas.h:10-40, gsl_spmat.h:32-93): CSR plus its transpose, both
+//       used as row-gather SpMVs
+//     ProjectorCgls::Project (src/cpu/projector/projector_cgls.cpp:52-88)
+//       -> cgls::Solve (src/cpu/include/cgls.h:200-323)
+//     PogsImplementation::Solve (src/cpu/pogs.cpp:91-581)
+//
+// HBM layout: two CSR structures (A by rows, A^T by rows), int32 indices, plus
+// "row blocks": consecutive rows whose non-zeros fit one LDS tile.  A workgroup
+// streams a row block's values / indices with fully coalesced loads, stages the
+// products val * x[ind] in LDS, then reduces each row from LDS (CSR-stream);
+// rows longer than a tile are reduced by the whole workgroup.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <limits>
+#include <vector>
+
 #include "engine.h"
+#include "reduce.h"
+#include "vec_kernels.h"
 
 namespace pogs_amd {
 
-SolverBase *make_sparse_solver(int, int, size_t, size_t, size_t, const void *, const int *, const int *, int,
-                               const PogsAmdOptions *) {
-  throw Error("sparse path not built yet");
+void rand_uniform_host(float *x, size_t n);
+void rand_uniform_host(double *x, size_t n);
+
+namespace {
+
+constexpr int kSpTpb = 256;
+constexpr int kSpCap = 4096;       // non-zeros staged in LDS per row block
+constexpr int kSpMaxRows = 2048;   // rows per block cap (balance when rows are empty)
+
+// ---------------------------------------------------------------------------
+// Row functors (one thread per finished row; scalars accumulate in doubles)
+// ---------------------------------------------------------------------------
+template <typename T>
+struct SpAxpbyOp {  // y[i] = alpha * dot + beta * yin[i]
+  static constexpr int NS = 0;
+  T alpha, beta;
+  const T *yin;
+  T *y;
+  template <int N>
+  __device__ __forceinline__ void row(int i, T dot, double (&)[N]) const {
+    T v = alpha * dot;
+    if (beta != static_cast<T>(0)) v += beta * yin[i];
+    y[i] = v;
+  }
+};
+
+template <typename T>
+struct SpAxpbyNormOp {  // y[i] = alpha * dot + beta * yin[i]; s0 += y[i]^2
+  static constexpr int NS = 1;
+  T alpha, beta;
+  const T *yin;
+  T *y;
+  template <int N>
+  __device__ __forceinline__ void row(int i, T dot, double (&s)[N]) const {
+    T v = alpha * dot;
+    if (beta != static_cast<T>(0)) v += beta * yin[i];
+    y[i] = v;
+    s[0] += static_cast<double>(v) * v;
+  }
+};
+
+template <typename T>
+struct SpSkOp {  // out[i] = num / (dot + c)   (equil_helper.h:149-162)
+  static constexpr int NS = 0;
+  T num, c;
+  T *out;
+  template <int N>
+  __device__ __forceinline__ void row(int i, T dot, double (&)[N]) const { out[i] = num / (dot + c); }
+};
+
+template <typename T>
+struct SpTailOp {  // ProjTailOp for the y half: see ops.h
+  static constexpr int NS = 2;
+  T *znew;
+  const T *zprev, *z12;
+  T *ztemp;
+  template <int N>
+  __device__ __forceinline__ void row(int i, T dot, double (&s)[N]) const {
+    znew[i] = dot;
+    const T a = zprev[i] - dot, b = z12[i] - dot;
+    s[0] += static_cast<double>(a) * a;
+    s[1] += static_cast<double>(b) * b;
+    ztemp[i] -= dot;
+  }
+};
+
+template <typename T>
+struct SpExactROp {  // r_i = (A x12)_i - y12_i (pogs.cpp:353-364)
+  static constexpr int NS = 1;
+  const T *y12;
+  template <int N>
+  __device__ __forceinline__ void row(int i, T dot, double (&s)[N]) const {
+    const T r = dot - y12[i];
+    s[0] += static_cast<double>(r) * r;
+  }
+};
+
+template <typename T>
+struct SpExactSOp {  // s_j = (A^T u)_j + x12_j + c xt_j - xprev_j (pogs.cpp:366-373)
+  static constexpr int NS = 1;
+  const T *x12, *xt, *xprev;
+  T zt_scale;
+  template <int N>
+  __device__ __forceinline__ void row(int j, T dot, double (&s)[N]) const {
+    const T v = dot + x12[j] + zt_scale * xt[j] - xprev[j];
+    s[0] += static_cast<double>(v) * v;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// SpMV kernel (CSR-stream with LDS staging)
+// ---------------------------------------------------------------------------
+template <typename T>
+struct Csr {
+  const T *val;
+  const int *ind, *ptr, *blocks;
+  int nrows, nblocks;
+};
+
+template <typename T, bool SQ, typename Op>
+__global__ void __launch_bounds__(kSpTpb) spmv_kernel(Csr<T> A, const T *__restrict__ x, const double *x_nrm2,
+                                                      Op op, double *scalar_partials) {
+  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+  __shared__ T s_prod[kSpCap];
+  __shared__ T s_long[kSpTpb / 64];
+  __shared__ double s_red[NS * (kSpTpb / 64)];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  double sacc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
+  T xs = 1;
+  if (x_nrm2) xs = static_cast<T>(1.0 / sqrt(*x_nrm2));
+
+  for (int b = blockIdx.x; b < A.nblocks; b += gridDim.x) {
+    const int r0 = A.blocks[b], r1 = A.blocks[b + 1];
+    const int p0 = A.ptr[r0], p1 = A.ptr[r1];
+    const int cnt = p1 - p0;
+    if (cnt > kSpCap) {
+      // one long row: the whole workgroup strides over it
+      T s = 0;
+      for (int k = t; k < cnt; k += kSpTpb) {
+        T v = A.val[p0 + k];
+        if (SQ) v *= v;
+        s += v * (x[A.ind[p0 + k]] * xs);
+      }
+      s = dev::wave_sum(s);
+      if (lane == 0) s_long[wave] = s;
+      __syncthreads();
+      if (t == 0) {
+        T tot = 0;
+#pragma unroll
+        for (int w = 0; w < kSpTpb / 64; ++w) tot += s_long[w];
+        op.row(r0, tot, sacc);
+      }
+      __syncthreads();
+      continue;
+    }
+    for (int k = t; k < cnt; k += kSpTpb) {
+      T v = A.val[p0 + k];
+      if (SQ) v *= v;
+      s_prod[k] = v * (x[A.ind[p0 + k]] * xs);
+    }
+    __syncthreads();
+    const int nrows = r1 - r0;
+    int tpr = 1;  // threads per row: a power of two <= 64, about a quarter of the mean row length
+    while (tpr < 64 && tpr * 4 < cnt / (nrows > 0 ? nrows : 1)) tpr <<= 1;
+    const int rpp = kSpTpb / tpr, lir = t % tpr, slot = t / tpr;
+    for (int base = 0; base < nrows; base += rpp) {
+      const int r = r0 + base + slot;
+      T s = 0;
+      if (r < r1) {
+        const int a = A.ptr[r] - p0, e = A.ptr[r + 1] - p0;
+        for (int k = a + lir; k < e; k += tpr) s += s_prod[k];
+      }
+      for (int off = tpr >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      if (lir == 0 && r < r1) op.row(r, s, sacc);
+    }
+    __syncthreads();
+  }
+  if (Op::NS > 0) {
+    dev::block_sum<NS, kSpTpb>(sacc, s_red);
+    if (t == 0) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) scalar_partials[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// One-time structure kernels
+// ---------------------------------------------------------------------------
+__global__ void count_cols_kernel(const int *ind, size_t nnz, int *cnt) {
+  for (size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < nnz;
+       k += static_cast<size_t>(gridDim.x) * blockDim.x)
+    atomicAdd(&cnt[ind[k]], 1);
+}
+
+// exclusive scan of cnt[0..n) into ptr[0..n], single workgroup of 1024 threads
+__global__ void __launch_bounds__(1024) scan_kernel(const int *cnt, int n, int *ptr) {
+  __shared__ int s_tot[1024];
+  const int t = threadIdx.x;
+  const int chunk = (n + 1023) / 1024;
+  const int lo = t * chunk, hi = min(n, lo + chunk);
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += cnt[i];
+  s_tot[t] = sum;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over the 1024 chunk totals
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = (t >= off) ? s_tot[t - off] : 0;
+    __syncthreads();
+    s_tot[t] += v;
+    __syncthreads();
+  }
+  int run = (t == 0) ? 0 : s_tot[t - 1];
+  for (int i = lo; i < hi; ++i) {
+    ptr[i] = run;
+    run += cnt[i];
+  }
+  if (t == 1023) ptr[n] = s_tot[1023];
+}
+
+// scatter (row, val) of every non-zero into its column segment (order within a
+// segment is fixed afterwards by sort_segments_kernel)
+template <typename T>
+__global__ void fill_transpose_kernel(const T *val, const int *ind, const int *ptr, int nrows, int *cursor,
+                                      T *tval, int *tind) {
+  const int lane = threadIdx.x & 63;
+  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  for (int r = w; r < nrows; r += nw) {
+    for (int k = ptr[r] + lane; k < ptr[r + 1]; k += 64) {
+      const int pos = atomicAdd(&cursor[ind[k]], 1);
+      tind[pos] = r;
+      tval[pos] = val[k];
+    }
+  }
+}
+
+// Sorts each segment by (index, value position is irrelevant: indices are unique
+// unless the input repeats an entry) with an all-ascending bitonic network, so the
+// transposed matrix is exactly what the reference's stable csr2csc builds
+// (gsl_spmat.h:32-55).  One workgroup per segment; LDS when it fits.
+template <typename T>
+__global__ void __launch_bounds__(256) sort_segments_kernel(const int *ptr, int nseg, int *ind, T *val) {
+  constexpr int CAP = 2048;
+  __shared__ int s_i[CAP];
+  __shared__ T s_v[CAP];
+  for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const int p0 = ptr[seg], len = ptr[seg + 1] - p0;
+    if (len <= 1) continue;
+    const bool lds = len <= CAP;
+    int *ki = lds ? s_i : ind + p0;
+    T *kv = lds ? s_v : val + p0;
+    if (lds) {
+      for (int k = threadIdx.x; k < len; k += 256) { s_i[k] = ind[p0 + k]; s_v[k] = val[p0 + k]; }
+    }
+    __syncthreads();
+    int np2 = 1;
+    while (np2 < len) np2 <<= 1;
+    for (int k = 2; k <= np2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; i < np2; i += 256) {
+          const int l = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);
+          if (l > i && l < len) {  // elements >= len act as +inf and never move
+            const int a = ki[i], b = ki[l];
+            if (a > b) {
+              ki[i] = b; ki[l] = a;
+              const T tv = kv[i]; kv[i] = kv[l]; kv[l] = tv;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (lds) {
+      for (int k = threadIdx.x; k < len; k += 256) { ind[p0 + k] = s_i[k]; val[p0 + k] = s_v[k]; }
+    }
+    __syncthreads();
+  }
+}
+
+// val[k] *= drow[row] * ecol[ind[k]], one wavefront per row; partial sum of squares
+template <typename T>
+__global__ void __launch_bounds__(256) scale_csr_kernel(T *val, const int *ind, const int *ptr, int nrows,
+                                                        const T *drow, const T *ecol, double *partials) {
+  __shared__ double s_red[4];
+  const int lane = threadIdx.x & 63;
+  const int w = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
+  double acc[1] = {0.0};
+  for (int r = w; r < nrows; r += nw) {
+    const T dr = drow[r];
+    for (int k = ptr[r] + lane; k < ptr[r + 1]; k += 64) {
+      const T v = val[k] * (dr * ecol[ind[k]]);
+      val[k] = v;
+      acc[0] += static_cast<double>(v) * v;
+    }
+  }
+  dev::block_sum<1, 256>(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+// ---------------------------------------------------------------------------
+// CGLS vector kernels (cgls.h:255-306); scalars live in a small device block
+// ---------------------------------------------------------------------------
+enum CgSlot : int { kCgGamma = 0, kCgAlpha, kCgBeta, kCgDelta, kCgIndef, kCgNumSlots = 8 };
+
+// alpha = gamma / (|q|^2 + shift |p|^2)   (cgls.h:262-271)
+__global__ void cg_alpha_kernel(double *S, double *cg, double shift, double eps) {
+  const double normq2 = S[kCgQ2], normp2 = S[kCgP2];
+  double delta = normq2 + shift * normp2;
+  if (delta <= 0.0) cg[kCgIndef] = 1.0;
+  if (delta == 0.0) delta = eps;
+  cg[kCgDelta] = delta;
+  cg[kCgAlpha] = cg[kCgGamma] / delta;
+}
+// beta = |s|^2 / gamma_prev; gamma = |s|^2   (cgls.h:288-292)
+__global__ void cg_beta_kernel(double *S, double *cg) {
+  const double g1 = cg[kCgGamma];
+  const double g = S[kCgS2];
+  cg[kCgGamma] = g;
+  cg[kCgBeta] = g / g1;
+}
+
+// x += alpha p (n);  r -= alpha q (m);  partial |x|^2      (cgls.h:274-277, 298)
+template <typename T>
+__global__ void __launch_bounds__(kVecTpb) cg_update_xr_kernel(int n, int m, const double *cg, const T *p, T *x,
+                                                               const T *q, T *r, double *partials, int blocks_x) {
+  __shared__ double s_red[kVecTpb / 64];
+  const T alpha = static_cast<T>(cg[kCgAlpha]);
+  const T neg_alpha = static_cast<T>(-cg[kCgAlpha]);
+  double acc[1] = {0.0};
+  if (static_cast<int>(blockIdx.x) < blocks_x) {
+    const int i = blockIdx.x * kVecTpb + threadIdx.x;
+    if (i < n) {
+      const T v = x[i] + alpha * p[i];
+      x[i] = v;
+      acc[0] = static_cast<double>(v) * v;
+    }
+  } else {
+    const int i = (blockIdx.x - blocks_x) * kVecTpb + threadIdx.x;
+    if (i < m) r[i] += neg_alpha * q[i];
+  }
+  dev::block_sum<1, kVecTpb>(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+// p = s + beta p; partial |p|^2      (cgls.h:295-296)
+template <typename T>
+__global__ void __launch_bounds__(kVecTpb) cg_update_p_kernel(int n, const double *cg, const T *s, T *p,
+                                                              double *partials, bool first) {
+  __shared__ double s_red[kVecTpb / 64];
+  const T beta = first ? static_cast<T>(0) : static_cast<T>(cg[kCgBeta]);
+  const int i = blockIdx.x * kVecTpb + threadIdx.x;
+  double acc[1] = {0.0};
+  if (i < n) {
+    const T v = first ? s[i] : s[i] + beta * p[i];
+    p[i] = v;
+    acc[0] = static_cast<double>(v) * v;
+  }
+  dev::block_sum<1, kVecTpb>(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+// out = a - b, partial |out|^2
+template <typename T>
+__global__ void __launch_bounds__(kVecTpb) sub_norm_kernel(int n, const T *a, const T *b, T *out, double *partials) {
+  __shared__ double s_red[kVecTpb / 64];
+  const int i = blockIdx.x * kVecTpb + threadIdx.x;
+  double acc[1] = {0.0};
+  if (i < n) {
+    const T v = a[i] - b[i];
+    out[i] = v;
+    acc[0] = static_cast<double>(v) * v;
+  }
+  dev::block_sum<1, kVecTpb>(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+// u = y12 + c yt - yprev   (pogs.cpp:366-368, y half)
+template <typename T>
+__global__ void exact_u_kernel(int m, const T *y12, const T *yt, const T *yprev, T c, T *u) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) u[i] = y12[i] + c * yt[i] - yprev[i];
+}
+
+__global__ void set_gamma_kernel(const double *S, double *cg) {
+  cg[kCgGamma] = S[kCgS2];
+  cg[kCgIndef] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
+template <typename T>
+struct DevCsr {
+  DevBuf<T> val;
+  DevBuf<int> ind, ptr, blocks;
+  int nrows = 0, nblocks = 0;
+  size_t nnz = 0;
+  Csr<T> view() const { return Csr<T>{val.p, ind.p, ptr.p, blocks.p, nrows, nblocks}; }
+};
+
+std::vector<int> make_row_blocks(const std::vector<int> &ptr, int nrows) {
+  std::vector<int> blocks;
+  blocks.push_back(0);
+  int start = 0;
+  while (start < nrows) {
+    int end = start;
+    long long cnt = 0;
+    while (end < nrows && end - start < kSpMaxRows) {
+      const long long rn = ptr[end + 1] - ptr[end];
+      if (cnt + rn > kSpCap) break;
+      cnt += rn;
+      ++end;
+    }
+    if (end == start) ++end;  // a single row longer than a tile
+    blocks.push_back(end);
+    start = end;
+  }
+  return blocks;
+}
+
+template <typename T>
+class SparseSolver final : public SolverBase {
+ public:
+  SparseSolver(int ord, size_t m, size_t n, size_t nnz, const void *data, const int *ptr, const int *ind, int mem,
+               const PogsAmdOptions *opt) {
+    const double t0 = wall_s();
+    ctx_.init(opt ? opt->device : -1, opt ? opt->profile != 0 : false);
+    POGS_CHECK(m > 0 && n > 0 && m < (1u << 31) && n < (1u << 31) && nnz < (1ull << 31), "bad dimensions");
+    m_ = static_cast<int>(m);
+    n_ = static_cast<int>(n);
+    nnz_ = nnz;
+    ctx_.m_global = m;
+    build_structure(ord, data, ptr, ind, mem);
+    ctx_.stats.t_h2d_s = wall_s() - t0;
+    alloc_state();
+    equilibrate();
+    norm_est();
+    ctx_.sync();
+    ctx_.stats.t_init_s = wall_s() - t0;
+  }
+
+  int dtype() const override { return sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64; }
+  PogsAmdStats &stats() override { return ctx_.stats; }
+
+  int solve(const FnHost &f, const FnHost &g, const SolveParams &p, void *x, void *y, void *l, void *mu,
+            double *optval, unsigned *final_iter) override {
+    const double t0 = wall_s();
+    load_problem(f, g, p);
+    cold_start();
+    ctx_.sync();
+    const double t1 = wall_s();
+    while (!iteration(p.verbose)) {}
+    ctx_.sync();
+    const double t2 = wall_s();
+    const int status = epilogue(x, y, l, mu, optval);
+    *final_iter = ctl_.k;
+    PogsAmdStats &st = ctx_.stats;
+    st.t_loop_s = t2 - t1;
+    st.t_total_s = st.t_init_s + (wall_s() - t0);
+    st.iterations = ctl_.k + 1;
+    st.exact_iters = ctl_.exact_iters;
+    st.rho_updates = ctl_.rho_updates;
+    st.rho_final = ctl_.rho;
+    collect_timer();
+    if (p.verbose > 0)
+      std::printf("POGS-AMD sparse/cgls: status %d, iter %u, init %.3e s, loop %.3e s, cg %llu, spmv %llu\n", status,
+                  ctl_.k, st.t_init_s, st.t_loop_s, st.cg_iters, st.matvecs);
+    return status;
+  }
+
+  void begin_run(const FnHost &f, const FnHost &g, const SolveParams &p) override {
+    load_problem(f, g, p);
+    cold_start();
+    ctx_.sync();
+  }
+
+  void iterate(unsigned iters, double *seconds, unsigned *solves) override {
+    unsigned done = 0;
+    ctx_.sync();
+    const double t0 = wall_s();
+    for (unsigned i = 0; i < iters; ++i) {
+      if (ctl_.finished) {
+        cold_start();
+        ++done;
+      }
+      iteration(0);
+    }
+    ctx_.sync();
+    const double t1 = wall_s();
+    if (seconds) *seconds = t1 - t0;
+    if (solves) *solves = done;
+    ctx_.stats.t_loop_s += t1 - t0;
+    ctx_.stats.iterations += iters;
+    collect_timer();
+  }
+
+  void get_equil(void *A_eq, void *d, void *e, double *nrmA) override {
+    ctx_.sync();
+    // A_eq: the equilibrated CSR values of the first copy, length nnz
+    if (A_eq) POGS_HIP_CHECK(hipMemcpy(A_eq, A_.val.p, nnz_ * sizeof(T), hipMemcpyDeviceToHost));
+    if (d) POGS_HIP_CHECK(hipMemcpy(d, d_.p, m_ * sizeof(T), hipMemcpyDeviceToHost));
+    if (e) POGS_HIP_CHECK(hipMemcpy(e, e_.p, n_ * sizeof(T), hipMemcpyDeviceToHost));
+    if (nrmA) *nrmA = nrmA_;
+  }
+
+  void project(const void *x0, const void *y0, double tol, void *x, void *y) override {
+    hipStream_t s = ctx_.stream;
+    POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, x0, n_ * sizeof(T), hipMemcpyHostToDevice, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, y0, m_ * sizeof(T), hipMemcpyHostToDevice, s));
+    x_[1].zero(s);  // cold start: x = 0
+    cgls_project(xtemp_.p, ytemp_.p, x_[1].p, static_cast<T>(tol));
+    spmv<false>(A_, x_[1].p, nullptr, SpAxpbyOp<T>{1, 0, nullptr, y_[1].p}, nullptr, 0);
+    POGS_HIP_CHECK(hipMemcpyAsync(x, x_[1].p, n_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(y, y_[1].p, m_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    ctx_.sync();
+  }
+
+  void mul(char trans, double alpha, const void *x, double beta, void *y) override {
+    hipStream_t s = ctx_.stream;
+    const bool tr = (trans == 't' || trans == 'T');
+    const int nin = tr ? m_ : n_, nout = tr ? n_ : m_;
+    DevBuf<T> vin(nin), vout(nout);
+    POGS_HIP_CHECK(hipMemcpyAsync(vin.p, x, nin * sizeof(T), hipMemcpyHostToDevice, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(vout.p, y, nout * sizeof(T), hipMemcpyHostToDevice, s));
+    spmv<false>(tr ? At_ : A_, vin.p, nullptr,
+                SpAxpbyOp<T>{static_cast<T>(alpha), static_cast<T>(beta), vout.p, vout.p}, nullptr, 0);
+    POGS_HIP_CHECK(hipMemcpyAsync(y, vout.p, nout * sizeof(T), hipMemcpyDeviceToHost, s));
+    ctx_.sync();
+  }
+
+ private:
+  // ---- structure -----------------------------------------------------------
+  void build_structure(int ord, const void *data, const int *ptr, const int *ind, int mem) {
+    hipStream_t s = ctx_.stream;
+    // "first" copy = what the caller gave (CSR if ROW_MAJ, CSC = CSR of A^T otherwise)
+    const int r1 = (ord == ROW_MAJ) ? m_ : n_, c1 = (ord == ROW_MAJ) ? n_ : m_;
+    DevCsr<T> first, second;
+    first.nrows = r1;
+    second.nrows = c1;
+    first.nnz = second.nnz = nnz_;
+    const hipMemcpyKind kind = (mem == POGS_AMD_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    first.val.alloc(nnz_); first.ind.alloc(nnz_); first.ptr.alloc(r1 + 1);
+    POGS_HIP_CHECK(hipMemcpyAsync(first.val.p, data, nnz_ * sizeof(T), kind, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(first.ind.p, ind, nnz_ * sizeof(int), kind, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(first.ptr.p, ptr, (r1 + 1) * sizeof(int), kind, s));
+    std::vector<int> hptr(r1 + 1);
+    if (mem == POGS_AMD_DEVICE) {
+      POGS_HIP_CHECK(hipMemcpyAsync(hptr.data(), ptr, (r1 + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+      ctx_.sync();
+    } else {
+      std::memcpy(hptr.data(), ptr, (r1 + 1) * sizeof(int));
+    }
+    POGS_CHECK(hptr[0] == 0 && static_cast<size_t>(hptr[r1]) == nnz_, "ptr does not match nnz");
+    // transpose on the device (gsl_spmat.h:32-55)
+    second.val.alloc(nnz_); second.ind.alloc(nnz_); second.ptr.alloc(c1 + 1);
+    DevBuf<int> cnt(c1 + 1), cursor(c1 + 1);
+    cnt.zero(s);
+    if (nnz_) hipLaunchKernelGGL(count_cols_kernel, dim3(2048), dim3(256), 0, s, first.ind.p, nnz_, cnt.p);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, cnt.p, c1, second.ptr.p);
+    POGS_HIP_CHECK(hipMemcpyAsync(cursor.p, second.ptr.p, (c1 + 1) * sizeof(int), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(fill_transpose_kernel<T>, dim3(2048), dim3(256), 0, s, first.val.p, first.ind.p, first.ptr.p,
+                       r1, cursor.p, second.val.p, second.ind.p);
+    hipLaunchKernelGGL(sort_segments_kernel<T>, dim3(std::min(c1, 65536)), dim3(256), 0, s, second.ptr.p, c1,
+                       second.ind.p, second.val.p);
+    std::vector<int> hptr2(c1 + 1);
+    POGS_HIP_CHECK(hipMemcpyAsync(hptr2.data(), second.ptr.p, (c1 + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+    ctx_.sync();
+    auto set_blocks = [&](DevCsr<T> &M, const std::vector<int> &hp) {
+      std::vector<int> b = make_row_blocks(hp, M.nrows);
+      M.nblocks = static_cast<int>(b.size()) - 1;
+      M.blocks.alloc(b.size());
+      POGS_HIP_CHECK(hipMemcpy(M.blocks.p, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
+    };
+    set_blocks(first, hptr);
+    set_blocks(second, hptr2);
+    if (ord == ROW_MAJ) { A_ = std::move(first); At_ = std::move(second); }
+    else { At_ = std::move(first); A_ = std::move(second); }
+    first_is_A_ = (ord == ROW_MAJ);
+  }
+
+  void alloc_state() {
+    hipStream_t s = ctx_.stream;
+    for (int i = 0; i < 2; ++i) { x_[i].alloc(n_); y_[i].alloc(m_); x_[i].zero(s); y_[i].zero(s); }
+    xt_.alloc(n_); yt_.alloc(m_); xtemp_.alloc(n_); ytemp_.alloc(m_); x12_.alloc(n_); y12_.alloc(m_);
+    xt_.zero(s); yt_.zero(s); xtemp_.zero(s); ytemp_.zero(s); x12_.zero(s); y12_.zero(s);
+    d_.alloc(m_); e_.alloc(n_);
+    cg_p_.alloc(n_); cg_s_.alloc(n_); cg_q_.alloc(m_); cg_r_.alloc(m_); cg_b_.alloc(m_); u_.alloc(m_);
+    xout_.alloc(n_); yout_.alloc(m_); lout_.alloc(m_); muout_.alloc(n_);
+    f_.alloc(m_); g_.alloc(n_); fs_.alloc(m_); gs_.alloc(n_);
+    cg_.alloc(kCgNumSlots);
+    cg_.zero(s);
+    spmv_grid_ = ctx_.num_cu * 8;
+    const size_t vb = vec_blocks(n_) + vec_blocks(m_);
+    ctx_.ensure_spart(std::max<size_t>(static_cast<size_t>(spmv_grid_) * 4 + 64, vb * 3 + 64));
+  }
+
+  // y_i = op(sum_k val * x[ind]) over the rows of M; scalar sums land in S[slot..slot+NS)
+  template <bool SQ, typename Op>
+  void spmv(const DevCsr<T> &M, const T *x, const double *x_nrm2, const Op &op, double *scalar_out, int,
+            bool timed = false) {
+    hipStream_t s = ctx_.stream;
+    const int grid = std::max(1, std::min(M.nblocks, spmv_grid_));
+    if (timed) ctx_.stream_timer.begin(s);
+    hipLaunchKernelGGL((spmv_kernel<T, SQ, Op>), dim3(grid), dim3(kSpTpb), 0, s, M.view(), x, x_nrm2, op,
+                       ctx_.spart.p);
+    if (timed) {
+      ctx_.stream_timer.end(s);
+      ++timed_spmvs_;
+    }
+    if (Op::NS > 0 && scalar_out) {
+      SumJob j{ctx_.spart.p, grid, Op::NS, scalar_out};
+      launch_sum_jobs(&j, 1, s);
+    }
+  }
+
+  // MatrixSparse::Equil (matrix_sparse.cpp:158-242): Sinkhorn-Knopp on the squared
+  // entries (squared on the fly), D A E on both copies, Frobenius norm of the first.
+  void equilibrate() {
+    hipStream_t s = ctx_.stream;
+    PhaseTimer pt(s);
+    const double mg = m_, nn = n_;
+    const T ce = static_cast<T>(1e-4) * static_cast<T>(mg + nn) / static_cast<T>(mg);
+    const T cd = static_cast<T>(1e-4) * static_cast<T>(mg + nn) / static_cast<T>(nn);
+    launch_fill<T>(d_.p, static_cast<T>(1), m_, s);
+    launch_fill<T>(e_.p, static_cast<T>(1), n_, s);
+    for (int k = 0; k < 50; ++k) {
+      spmv<true>(At_, d_.p, nullptr, SpSkOp<T>{static_cast<T>(mg), ce, e_.p}, nullptr, 0);
+      spmv<true>(A_, e_.p, nullptr, SpSkOp<T>{static_cast<T>(nn), cd, d_.p}, nullptr, 0);
+    }
+    ctx_.stats.matvecs_init += 100;
+    launch_sqrt_inplace<T>(d_.p, m_, s);
+    launch_sqrt_inplace<T>(e_.p, n_, s);
+    const int g = ctx_.num_cu * 8;
+    double *pa = ctx_.spart.p, *pb = ctx_.spart.p + g;
+    hipLaunchKernelGGL(scale_csr_kernel<T>, dim3(g), dim3(256), 0, s, A_.val.p, A_.ind.p, A_.ptr.p, m_, d_.p, e_.p, pa);
+    hipLaunchKernelGGL(scale_csr_kernel<T>, dim3(g), dim3(256), 0, s, At_.val.p, At_.ind.p, At_.ptr.p, n_, e_.p, d_.p,
+                       pb);
+    SumJob j{first_is_A_ ? pa : pb, g, 1, ctx_.S.p + kFro2};   // first nnz only (matrix_sparse.cpp:257)
+    launch_sum_jobs(&j, 1, s);
+    const double *S = ctx_.fetch_scalars();
+    const T normA = static_cast<T>(std::sqrt(S[kFro2])) /
+                    static_cast<T>(std::sqrt(static_cast<double>(std::min(m_, n_))));
+    launch_scal<T>(A_.val.p, static_cast<T>(1) / normA, nnz_, s);
+    launch_scal<T>(At_.val.p, static_cast<T>(1) / normA, nnz_, s);
+    const T invs = static_cast<T>(1) / std::sqrt(normA);
+    launch_scal<T>(d_.p, invs, m_, s);
+    launch_scal<T>(e_.p, invs, n_, s);
+    ctx_.stats.equil_ms = pt.stop_ms();
+  }
+
+  // Norm2Est (equil_helper.h:107-135)
+  void norm_est() {
+    hipStream_t s = ctx_.stream;
+    PhaseTimer pt(s);
+    std::vector<T> x0(n_);
+    rand_uniform_host(x0.data(), n_);
+    POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, x0.data(), n_ * sizeof(T), hipMemcpyHostToDevice, s));
+    ctx_.sync();
+    const T kTol = static_cast<T>(1e-4);
+    T norm_est = 0, last;
+    unsigned i = 0;
+    for (i = 0; i < 50; ++i) {
+      last = norm_est;
+      // Sx = A (x / |x|);  x' = A^T Sx
+      spmv<false>(A_, xtemp_.p, (i == 0) ? nullptr : ctx_.S.p + kPowX2,
+                  SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p}, ctx_.S.p + kPowSx2, 0);
+      spmv<false>(At_, cg_q_.p, nullptr, SpAxpbyNormOp<T>{1, 0, nullptr, xtemp_.p}, ctx_.S.p + kPowX2, 0);
+      const double *S = ctx_.fetch_scalars();
+      const T normx = static_cast<T>(std::sqrt(S[kPowX2]));
+      const T normSx = static_cast<T>(std::sqrt(S[kPowSx2]));
+      norm_est = normx / normSx;
+      ctx_.stats.matvecs_init += 2;
+      if (std::abs(last - norm_est) < kTol * norm_est) { ++i; break; }
+    }
+    nrmA_ = norm_est;
+    ctx_.stats.nrmA = nrmA_;
+    ctx_.stats.norm_est_iters = i;
+    xtemp_.zero(s);
+    ctx_.stats.normest_ms = pt.stop_ms();
+  }
+
+  // ---- per solve -----------------------------------------------------------
+  void load_problem(const FnHost &f, const FnHost &g, const SolveParams &p) {
+    hipStream_t s = ctx_.stream;
+    auto up = [&](FnBuf<T> &dst, const FnHost &src, int cnt) {
+      POGS_HIP_CHECK(hipMemcpyAsync(dst.h.p, src.h, cnt * sizeof(int), hipMemcpyHostToDevice, s));
+      POGS_HIP_CHECK(hipMemcpyAsync(dst.a.p, src.a, cnt * sizeof(T), hipMemcpyHostToDevice, s));
+      POGS_HIP_CHECK(hipMemcpyAsync(dst.b.p, src.b, cnt * sizeof(T), hipMemcpyHostToDevice, s));
+      POGS_HIP_CHECK(hipMemcpyAsync(dst.c.p, src.c, cnt * sizeof(T), hipMemcpyHostToDevice, s));
+      POGS_HIP_CHECK(hipMemcpyAsync(dst.d.p, src.d, cnt * sizeof(T), hipMemcpyHostToDevice, s));
+      POGS_HIP_CHECK(hipMemcpyAsync(dst.e.p, src.e, cnt * sizeof(T), hipMemcpyHostToDevice, s));
+    };
+    up(f_, f, m_);
+    up(g_, g, n_);
+    launch_scale_objective<T>(f_.view(), fs_.a.p, fs_.c.p, fs_.d.p, fs_.e.p, d_.p, m_, true, s);
+    launch_scale_objective<T>(g_.view(), gs_.a.p, gs_.c.p, gs_.d.p, gs_.e.p, e_.p, n_, false, s);
+    ctl_ = AdmmControl<T>();
+    ctl_.abs_tol = static_cast<T>(p.abs_tol);
+    ctl_.rel_tol = static_cast<T>(p.rel_tol);
+    ctl_.max_iter = p.max_iter;
+    ctl_.adaptive_rho = p.adaptive_rho;
+    ctl_.gap_stop = p.gap_stop;
+    ctl_.rho0 = static_cast<T>(p.rho);
+    ctl_.m_glob = m_;
+    ctl_.n = n_;
+    ctx_.sync();
+  }
+  FnView<T> fview() const { return FnView<T>{f_.h.p, fs_.a.p, f_.b.p, fs_.c.p, fs_.d.p, fs_.e.p}; }
+  FnView<T> gview() const { return FnView<T>{g_.h.p, gs_.a.p, g_.b.p, gs_.c.p, gs_.d.p, gs_.e.p}; }
+
+  void cold_start() {
+    hipStream_t s = ctx_.stream;
+    for (int i = 0; i < 2; ++i) { x_[i].zero(s); y_[i].zero(s); }
+    xt_.zero(s); yt_.zero(s); xtemp_.zero(s); ytemp_.zero(s);
+    cur_ = 0;
+    zt_scale_ = 1;
+    ctl_.reset();
+  }
+
+  void sum_vec_partials(int blocks, double *out) {
+    SumJob j{ctx_.spart.p, blocks, 1, out};
+    launch_sum_jobs(&j, 1, ctx_.stream);
+  }
+
+  // ProjectorCgls::Project up to (not including) the final y = A x
+  // (projector_cgls.cpp:59-75): x holds the warm start on entry, the projected x
+  // on exit.
+  void cgls_project(const T *x0, const T *y0, T *x, T tol) {
+    hipStream_t s = ctx_.stream;
+    const int bx = vec_blocks(n_);
+    const double shift = 1.0;
+    const double kEps = std::numeric_limits<T>::epsilon();
+    // x <- x - x0, |x|^2                                                      (:62)
+    hipLaunchKernelGGL(sub_norm_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, x, x0, x, ctx_.spart.p);
+    sum_vec_partials(bx, ctx_.S.p + kCgX2);
+    // b = y0 - A x0                                                           (:65-68)
+    spmv<false>(A_, x0, nullptr, SpAxpbyOp<T>{static_cast<T>(-1), static_cast<T>(1), y0, cg_b_.p}, nullptr, 0, true);
+    const double *S = ctx_.fetch_scalars();
+    double normx = std::sqrt(S[kCgX2]);
+    // r = b - A x (only if x != 0)                                            (cgls.h:226-233)
+    if (normx > 0.0) {
+      spmv<false>(A_, x, nullptr, SpAxpbyOp<T>{static_cast<T>(-1), static_cast<T>(1), cg_b_.p, cg_r_.p}, nullptr, 0,
+                  true);
+    } else {
+      POGS_HIP_CHECK(hipMemcpyAsync(cg_r_.p, cg_b_.p, m_ * sizeof(T), hipMemcpyDeviceToDevice, s));
+    }
+    // s = A^T r - shift x ; p = s ; gamma = |s|^2                             (cgls.h:236-245)
+    spmv<false>(At_, cg_r_.p, nullptr, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, ctx_.S.p + kCgS2, 0,
+                true);
+    hipLaunchKernelGGL(set_gamma_kernel, dim3(1), dim3(1), 0, s, ctx_.S.p, cg_.p);
+    hipLaunchKernelGGL(cg_update_p_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, cg_.p, cg_s_.p, cg_p_.p,
+                       ctx_.spart.p, true);
+    sum_vec_partials(bx, ctx_.S.p + kCgP2);
+    S = ctx_.fetch_scalars();
+    const double norms0 = std::sqrt(S[kCgS2]);
+    double norms = norms0;
+    const int maxit = (norms < kEps) ? 0 : 500;                               // flag 1 / projector_cgls.cpp:17
+    for (int k = 0; k < maxit; ++k) {
+      // q = A p, |q|^2 ; alpha                                               (cgls.h:257-271)
+      spmv<false>(A_, cg_p_.p, nullptr, SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p}, ctx_.S.p + kCgQ2, 0, true);
+      hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(1), 0, s, ctx_.S.p, cg_.p, shift, kEps);
+      // x += alpha p ; r -= alpha q ; |x|^2                                  (:274-277)
+      const int bm = vec_blocks(m_);
+      hipLaunchKernelGGL(cg_update_xr_kernel<T>, dim3(bx + bm), dim3(kVecTpb), 0, s, n_, m_, cg_.p, cg_p_.p, x,
+                         cg_q_.p, cg_r_.p, ctx_.spart.p, bx);
+      sum_vec_partials(bx, ctx_.S.p + kCgX2);
+      // s = A^T r - shift x ; |s|^2 ; beta ; p = s + beta p ; |p|^2          (:281-296)
+      spmv<false>(At_, cg_r_.p, nullptr, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, ctx_.S.p + kCgS2,
+                  0, true);
+      hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(1), 0, s, ctx_.S.p, cg_.p);
+      hipLaunchKernelGGL(cg_update_p_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, cg_.p, cg_s_.p, cg_p_.p,
+                         ctx_.spart.p, false);
+      sum_vec_partials(bx, ctx_.S.p + kCgP2);
+      S = ctx_.fetch_scalars();
+      norms = std::sqrt(S[kCgS2]);
+      normx = std::sqrt(S[kCgX2]);
+      ++ctx_.stats.cg_iters;
+      const bool converged = (norms <= norms0 * static_cast<double>(tol)) || (normx * static_cast<double>(tol) >= 1.0);
+      if (converged) break;                                                   // :301-305
+    }
+    // x <- x + x0                                                            (projector_cgls.cpp:75)
+    launch_axpby<T>(n_, static_cast<T>(1), x0, static_cast<T>(1), x, s);
+  }
+
+  bool iteration(unsigned verbose) {
+    hipStream_t s = ctx_.stream;
+    const int nw = cur_ ^ 1;
+    AdmmPreArgs<T> pa;
+    pa.n_x = n_; pa.n_y = m_;
+    pa.g = gview(); pa.f = fview();
+    pa.x_cur = x_[cur_].p; pa.y_cur = y_[cur_].p;
+    pa.xt = xt_.p; pa.yt = yt_.p;
+    pa.zt_scale = zt_scale_;
+    pa.x12 = x12_.p; pa.y12 = y12_.p;
+    pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
+    pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
+    pa.partials = ctx_.spart.p;
+    pa.blocks_x = vec_blocks(n_);
+    launch_admm_pre<T>(pa, s);
+    {
+      SumJob j[2] = {{ctx_.spart.p, pa.blocks_x, 3, ctx_.S.p + kGapX},
+                     {ctx_.spart.p + static_cast<size_t>(pa.blocks_x) * 3, vec_blocks(m_), 3, ctx_.S.p + kGapY}};
+      launch_sum_jobs(j, 2, s);
+    }
+    // warm start with the previous x (pogs.cpp:281), then CGLS
+    POGS_HIP_CHECK(hipMemcpyAsync(x_[nw].p, x_[cur_].p, n_ * sizeof(T), hipMemcpyDeviceToDevice, s));
+    cgls_project(xtemp_.p, ytemp_.p, x_[nw].p, ctl_.proj_tol());
+    // y = A x fused with the y-half bookkeeping; x-half element-wise        (projector_cgls.cpp:78)
+    spmv<false>(A_, x_[nw].p, nullptr, SpTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p}, ctx_.S.p + kDYprev2, 0,
+                true);
+    launch_admm_tail<T>(n_, x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, ctx_.spart.p, s);
+    {
+      SumJob j{ctx_.spart.p, vec_blocks(n_), 2, ctx_.S.p + kDXprev2};
+      launch_sum_jobs(&j, 1, s);
+    }
+    const double *S = ctx_.fetch_scalars();
+    ctl_.set_pre(S);
+    bool exact = false;
+    if (ctl_.set_approx(S, nrmA_)) {
+      spmv<false>(A_, x12_.p, nullptr, SpExactROp<T>{y12_.p}, ctx_.S.p + kExactR2, 0, true);
+      hipLaunchKernelGGL(exact_u_kernel<T>, dim3((m_ + 255) / 256), dim3(256), 0, s, m_, y12_.p, yt_.p, y_[cur_].p,
+                         zt_scale_, u_.p);
+      spmv<false>(At_, u_.p, nullptr, SpExactSOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_}, ctx_.S.p + kExactS2, 0,
+                  true);
+      S = ctx_.fetch_scalars();
+      ctl_.set_exact(S);
+      exact = true;
+    }
+    const bool stop = ctl_.check_stop(exact);
+    if (verbose > 1 && ((verbose > 2 && ctl_.k % 10 == 0) || ctl_.k % 100 == 0 || ctl_.converged))
+      std::printf("%5u : %.2e  %.2e  %.2e  %.2e  %.2e  %.2e\n", ctl_.k, (double)ctl_.nrm_r, (double)ctl_.eps_pri,
+                  (double)ctl_.nrm_s, (double)ctl_.eps_dua, (double)ctl_.gap, (double)ctl_.eps_gap);
+    if (stop) return true;
+    std::swap(xt_, xtemp_);
+    std::swap(yt_, ytemp_);
+    cur_ = nw;
+    zt_scale_ = ctl_.adapt();
+    ++ctl_.k;
+    return false;
+  }
+
+  int epilogue(void *x, void *y, void *l, void *mu, double *optval) {
+    hipStream_t s = ctx_.stream;
+    const int by = vec_blocks(m_), bx = vec_blocks(n_);
+    launch_func_eval<T>(m_, fview(), y12_.p, ctx_.spart.p, s);
+    launch_func_eval<T>(n_, gview(), x12_.p, ctx_.spart.p + by, s);
+    SumJob j[2] = {{ctx_.spart.p, by, 1, ctx_.S.p + kFvalF}, {ctx_.spart.p + by, bx, 1, ctx_.S.p + kFvalG}};
+    launch_sum_jobs(j, 2, s);
+    UnscaleArgs<T> u;
+    u.n_x = n_; u.n_y = m_;
+    u.x12 = x12_.p; u.y12 = y12_.p; u.xt = xt_.p; u.yt = yt_.p;
+    u.xprev = x_[cur_].p; u.yprev = y_[cur_].p; u.d = d_.p; u.e = e_.p;
+    u.zt_scale = zt_scale_; u.rho = ctl_.rho;
+    u.x_out = xout_.p; u.y_out = yout_.p; u.l_out = lout_.p; u.mu_out = muout_.p;
+    launch_unscale<T>(u, s);
+    POGS_HIP_CHECK(hipMemcpyAsync(x, xout_.p, n_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(y, yout_.p, m_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(l, lout_.p, m_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    if (mu) POGS_HIP_CHECK(hipMemcpyAsync(mu, muout_.p, n_ * sizeof(T), hipMemcpyDeviceToHost, s));
+    const double *S = ctx_.fetch_scalars();
+    *optval = static_cast<double>(static_cast<T>(S[kFvalF]) + static_cast<T>(S[kFvalG]));
+    return ctl_.status();
+  }
+
+  void collect_timer() {
+    ctx_.stats.matvecs += timed_spmvs_;
+    if (ctx_.stream_timer.enabled()) {
+      unsigned long long cnt = 0;
+      ctx_.stats.stream_ms += ctx_.stream_timer.collect_ms(&cnt);
+      ctx_.stats.stream_launches += cnt;
+      // algorithmic bytes of one SpMV: nnz (s + 4) + 4 (rows + 1) + s (rows + cols)
+      const double per = static_cast<double>(nnz_) * (sizeof(T) + 4) + 4.0 * (0.5 * (m_ + n_) + 1) +
+                         static_cast<double>(sizeof(T)) * (m_ + n_);
+      ctx_.stats.stream_bytes += static_cast<double>(cnt) * per;
+    }
+    timed_spmvs_ = 0;
+  }
+
+  Ctx ctx_;
+  int m_ = 0, n_ = 0;
+  size_t nnz_ = 0;
+  bool first_is_A_ = true;
+  int spmv_grid_ = 2048;
+  unsigned long long timed_spmvs_ = 0;
+  DevCsr<T> A_, At_;
+  DevBuf<T> d_, e_;
+  DevBuf<T> x_[2], y_[2], xt_, yt_, xtemp_, ytemp_, x12_, y12_;
+  DevBuf<T> cg_p_, cg_s_, cg_q_, cg_r_, cg_b_, u_;
+  DevBuf<T> xout_, yout_, lout_, muout_;
+  DevBuf<double> cg_;
+  FnBuf<T> f_, g_, fs_, gs_;
+  AdmmControl<T> ctl_;
+  int cur_ = 0;
+  T zt_scale_ = 1;
+  T nrmA_ = 0;
+};
+
+}  // namespace
+
+SolverBase *make_sparse_solver(int dtype, int ord, size_t m, size_t n, size_t nnz, const void *data, const int *ptr,
+                               const int *ind, int mem, const PogsAmdOptions *opt) {
+  if (dtype == POGS_AMD_F32) return new SparseSolver<float>(ord, m, n, nnz, data, ptr, ind, mem, opt);
+  if (dtype == POGS_AMD_F64) return new SparseSolver<double>(ord, m, n, nnz, data, ptr, ind, mem, opt);
+  throw Error("unknown dtype");
 }
 
 }  // namespace pogs_amd

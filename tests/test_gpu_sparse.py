@@ -1,0 +1,173 @@
+"""GPU parity tests for the sparse path (CSR + transposed CSR SpMV, CGLS projector)
+against the CPU oracle and the golden fixtures of the compiled reference."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle_binding as ob
+from helpers import relerr, soa
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_outputs.npz"))
+
+
+def _pogs():
+    import pogs_amd
+
+    return pogs_amd
+
+
+def _tol(dtype, f64, f32):
+    return f64 if dtype == np.float64 else f32
+
+
+def _rand_csr(m, n, per_row, seed, long_row=None, empty_rows=()):
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = [], [], []
+    for i in range(m):
+        if i in empty_rows:
+            continue
+        k = long_row[1] if (long_row and i == long_row[0]) else int(rng.integers(1, 2 * per_row))
+        c = rng.choice(n, size=min(k, n), replace=False)
+        rows += [i] * len(c)
+        cols += list(c)
+        vals += list(rng.standard_normal(len(c)))
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(m, n))
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_spmv_both_directions_and_structure(dtype):
+    """A and its device-built transpose, incl. empty rows, a row longer than one LDS tile
+    (> 4096 non-zeros) and a column longer than the sort tile."""
+    pogs = _pogs()
+    m, n = 1500, 6000
+    A = _rand_csr(m, n, 12, seed=1, long_row=(7, 5000), empty_rows=(0, 3, 1499))
+    # make column 5 dense-ish (3000 entries) so its transposed segment exceeds the LDS sort tile
+    extra = sp.csr_matrix((np.ones(1400), (np.arange(50, 1450), np.full(1400, 5))), shape=(m, n))
+    A = (A + extra).tocsr()
+    A.sort_indices()
+    rng = np.random.default_rng(2)
+    with pogs.Solver(A, dtype=dtype) as s:
+        vals, d, e, nrmA = s.equilibrated(want_matrix=False) if False else (None, None, None, None)
+        # equilibrated values come back in CSR order of the input
+        buf = np.zeros(A.nnz, dtype)
+        dd, ee = np.zeros(m, dtype), np.zeros(n, dtype)
+        nrm = ctypes.c_double()
+        from pogs_amd import _lib
+
+        assert _lib.lib.PogsAmdGetEquil(s._h, buf.ctypes.data_as(ctypes.c_void_p), dd.ctypes.data_as(ctypes.c_void_p),
+                                        ee.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nrm)) == 0
+        A_eq = sp.csr_matrix((buf.astype(np.float64), A.indices, A.indptr), shape=(m, n))
+        # D A E / normA structure
+        A_chk = sp.diags(dd.astype(np.float64)) @ A.astype(np.float64) @ sp.diags(ee.astype(np.float64))
+        assert relerr(A_eq.data, A_chk.data) < _tol(dtype, 1e-10, 1e-5)
+        assert np.sum(A_eq.data ** 2) == pytest.approx(min(m, n), rel=_tol(dtype, 1e-10, 1e-4))
+        x, y = rng.standard_normal(n), rng.standard_normal(m)
+        assert relerr(s.mul("n", 1.0, x, 0.0, y), A_eq @ x) < _tol(dtype, 1e-12, 2e-5)
+        assert relerr(s.mul("n", -2.0, x, 0.5, y), -2.0 * (A_eq @ x) + 0.5 * y) < _tol(dtype, 1e-12, 2e-5)
+        assert relerr(s.mul("t", 1.0, y, 0.0, x), A_eq.T @ y) < _tol(dtype, 1e-12, 2e-5)
+        assert relerr(s.mul("t", 1.5, y, -1.0, x), 1.5 * (A_eq.T @ y) - x) < _tol(dtype, 1e-12, 2e-5)
+        sig = np.linalg.norm(A_eq.toarray(), 2)
+        assert nrm.value <= sig * 1.001 and nrm.value >= 0.85 * sig
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_cgls_projection_kkt(dtype):
+    pogs = _pogs()
+    from pogs_amd import _lib
+
+    m, n = 900, 400
+    A = _rand_csr(m, n, 10, seed=3)
+    rng = np.random.default_rng(4)
+    x0, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    with pogs.Solver(A, dtype=dtype) as s:
+        buf = np.zeros(A.nnz, dtype)
+        assert _lib.lib.PogsAmdGetEquil(s._h, buf.ctypes.data_as(ctypes.c_void_p), None, None, None) == 0
+        x, y = s.project(x0, y0, tol=_tol(dtype, 1e-10, 1e-6))
+    A64 = sp.csr_matrix((buf.astype(np.float64), A.indices, A.indptr), shape=(m, n))
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    eps = _tol(dtype, 1e-8, 2e-4)
+    assert np.linalg.norm(A64 @ x64 - y64) / np.sqrt(m) < eps
+    assert np.linalg.norm(A64.T @ (A64 @ x64 - y0) + (x64 - x0)) / np.sqrt(n) < eps
+
+
+def _check(got, want, xtol, it_slack):
+    assert got["status"] == want["status"] == 0
+    assert abs(got["iterations"] - want["iterations"]) <= it_slack, (got["iterations"], want["iterations"])
+    assert relerr(got["x"], want["x"]) < xtol
+    assert relerr(got["y"], want["y"]) < xtol
+    assert got["optval"] == pytest.approx(want["optval"], rel=max(xtol, 1e-7))
+
+
+def test_sparse_lasso_fp64_follows_oracle_and_golden():
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.csr_lasso(3000, 800, 20, seed=4, dtype=np.float64)
+    got = pogs.solve_lasso(A, b, 0.1)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 800)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float64)
+    _check(got, want, 1e-6, 2)
+    gold = {k: GOLD["csr3000_f64_" + k] for k in ("x", "y", "optval", "iterations", "status")}
+    assert got["status"] == int(gold["status"]) and abs(got["iterations"] - int(gold["iterations"])) <= 2
+    assert relerr(got["x"], gold["x"]) < 1e-6
+
+
+def test_sparse_lasso_fp32_scaled_c4():
+    """Scaled-down C4: CSR fp32 20000 x 5000, ~50 nnz per row."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.csr_lasso(20000, 5000, 50, seed=3, dtype=np.float32)
+    got = pogs.solve_lasso(A, b, 0.1, dtype=np.float32)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 5000)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float32)
+    _check(got, want, 2e-4, max(5, int(0.1 * want["iterations"])))
+    assert relerr(got["x"], GOLD["csr20000_f32_x"]) < 3e-4
+
+
+@pytest.mark.parametrize("problem", ["ridge", "logistic", "svm", "nonneg_ls"])
+def test_sparse_other_families(problem):
+    pogs = _pogs()
+    from helpers import PROBLEMS
+
+    rng = np.random.default_rng(8)
+    m, n = 1200, 300
+    A = _rand_csr(m, n, 8, seed=9)
+    b = A @ (rng.standard_normal(n) * (rng.random(n) < 0.2)) + 0.1 * rng.standard_normal(m)
+    f, g = PROBLEMS[problem](b, n)
+    got = pogs._solve_graph_form(A, f, g)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float64)
+    _check(got, want, 1e-5, 3)
+
+
+def test_csc_input_through_raw_abi():
+    """ORD = COL_MAJ: data/ptr/ind describe CSC (src/interface_c/pogs_c.h:92-98)."""
+    pogs = _pogs()
+    from pogs_amd import _lib, synth
+
+    A, b, _ = synth.csr_lasso(1000, 300, 10, seed=12, dtype=np.float64)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 300)
+    want = pogs._solve_graph_form(A, f, g)
+    C = A.tocsc()
+    C.sort_indices()
+    fa, ga = f.arrays(np.float64), g.arrays(np.float64)
+    m, n = A.shape
+    x, y, l = np.zeros(n), np.zeros(m), np.zeros(m)
+    optval, fi = ctypes.c_double(), ctypes.c_uint()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    data = np.ascontiguousarray(C.data)
+    ptr = np.ascontiguousarray(C.indptr, np.int32)
+    ind = np.ascontiguousarray(C.indices, np.int32)
+    st = _lib.lib.PogsSparseD(0, m, n, C.nnz, p(data), p(ptr), p(ind), *[p(fa[k]) for k in "abcdeh"],
+                              *[p(ga[k]) for k in "abcdeh"], 1.0, 1e-4, 1e-4, 2500, 0, 1, 1, p(x), p(y), p(l),
+                              ctypes.cast(ctypes.byref(optval), ctypes.c_void_p),
+                              ctypes.cast(ctypes.byref(fi), ctypes.c_void_p))
+    assert st == 0 == want["status"]
+    assert abs(fi.value - want["iterations"]) <= 1
+    assert relerr(x, want["x"]) < 1e-6
