@@ -85,14 +85,15 @@ class DenseSolver final : public SolverBase {
     m_ = static_cast<int>(m);
     n_ = static_cast<int>(n);
     POGS_CHECK(m > 0 && n > 0 && m < (1u << 31) && n < (1u << 31), "bad dimensions");
-    if (dist && dist->world > 1) {
+    if (dist && dist->world >= 1) {   // a 1-rank communicator is allowed (exercises the RCCL path)
       ctx_.dist.init(dist->rank, dist->world, dist->unique_id);
       ctx_.m_global = dist->m_global;
     } else {
       ctx_.m_global = m;
     }
+    multi_ = ctx_.dist.active();
     tall_ = ctx_.m_global > n;   // projector_direct_dense.cpp:53,122,128
-    POGS_CHECK(tall_ || ctx_.dist.world() == 1, "row sharding needs m > n (SURVEY.md section 8(e))");
+    POGS_CHECK(tall_ || !multi_, "row sharding needs m > n (SURVEY.md section 8(e))");
     constexpr int VEC = Vec16<T>::N;
     n_pad_ = static_cast<int>(round_up(n, VEC));
     k_ = tall_ ? n_ : m_;
@@ -221,7 +222,7 @@ class DenseSolver final : public SolverBase {
       POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, x, m_ * sizeof(T), hipMemcpyHostToDevice, s));
       POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, y, n_ * sizeof(T), hipMemcpyHostToDevice, s));
       gemv_t_partials(ytemp_.p);
-      if (ctx_.dist.world() > 1) {
+      if (multi_) {
         finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, 0, 0);
         launch_axpby<T>(n_, static_cast<T>(alpha), rhs_.p, static_cast<T>(beta), xtemp_.p, s);
       } else {
@@ -291,7 +292,7 @@ class DenseSolver final : public SolverBase {
     hipStream_t s = ctx_.stream;
     const int nparts = nparts_override > 0 ? nparts_override : stream_grid<false, true>(planA_, m_);
     double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 4;  // separate scratch region
-    if (ctx_.dist.world() == 1) {
+    if (!multi_) {
       launch_reduce_cols<T, ColOp>(colpart_.p, nparts, n_pad_, op, sp, s);
     } else {
       launch_reduce_cols<T, StoreColOp<T>>(colpart_.p, nparts, n_pad_, StoreColOp<T>{1, 0, tmpn_.p, n_}, sp, s);
@@ -347,7 +348,7 @@ class DenseSolver final : public SolverBase {
     hipLaunchKernelGGL(scale_de_kernel<T>, dim3(sgrid), dim3(256), 0, s, A_.p, lda_, m_, n_pad_, d_.p, e_.p,
                        ctx_.spart.p);
     sum_row_scalars(sgrid, 1, ctx_.S.p + kFro2);
-    if (ctx_.dist.world() > 1) ctx_.dist.allreduce(ctx_.S.p + kFro2, 1, s);
+    if (multi_) ctx_.dist.allreduce(ctx_.S.p + kFro2, 1, s);
     const double *S = ctx_.fetch_scalars();
     const T normA = static_cast<T>(std::sqrt(S[kFro2])) /
                     std::sqrt(static_cast<T>(std::min<double>(mg, nn)));   // :215-218
@@ -419,7 +420,7 @@ class DenseSolver final : public SolverBase {
         GemmArgs<T> g{m_, m_, n_, A_.p, lda_, A_.p, lda_, G.p, ld, static_cast<T>(1), static_cast<T>(0)};
         launch_gemm<T>(false, false, true, g, s);
       }
-      if (ctx_.dist.world() > 1) ctx_.dist.allreduce(G.p, static_cast<size_t>(k_) * ld, s);
+      if (multi_) ctx_.dist.allreduce(G.p, static_cast<size_t>(k_) * ld, s);
       ctx_.stats.gram_ms = pt.stop_ms();
       ctx_.stats.gram_flops = static_cast<double>(tall_ ? m_ : n_) * k_ * k_;
     }
@@ -505,7 +506,7 @@ class DenseSolver final : public SolverBase {
   bool iteration(unsigned verbose) {
     hipStream_t s = ctx_.stream;
     const int nw = cur_ ^ 1;
-    const bool multi = ctx_.dist.world() > 1;
+    const bool multi = multi_;
     // (1) prox + gap/tolerance sums + over-relaxation
     AdmmPreArgs<T> pa;
     pa.n_x = n_; pa.n_y = m_;
@@ -592,7 +593,7 @@ class DenseSolver final : public SolverBase {
     launch_func_eval<T>(n_, gview(), x12_.p, ctx_.spart.p + by, s);
     SumJob j[2] = {{ctx_.spart.p, by, 1, ctx_.S.p + kFvalF}, {ctx_.spart.p + by, bx, 1, ctx_.S.p + kFvalG}};
     launch_sum_jobs(j, 2, s);
-    if (ctx_.dist.world() > 1) ctx_.dist.allreduce(ctx_.S.p + kFvalF, 1, s);
+    if (multi_) ctx_.dist.allreduce(ctx_.S.p + kFvalF, 1, s);
     UnscaleArgs<T> u;
     u.n_x = n_; u.n_y = m_;
     u.x12 = x12_.p; u.y12 = y12_.p; u.xt = xt_.p; u.yt = yt_.p;
@@ -619,7 +620,7 @@ class DenseSolver final : public SolverBase {
 
   Ctx ctx_;
   int m_ = 0, n_ = 0, n_pad_ = 0, k_ = 0, k_pad_ = 0;
-  bool tall_ = true;
+  bool tall_ = true, multi_ = false;
   size_t lda_ = 0;
   StreamPlan planA_, planW_;
   DevBuf<T> A_, W_, U_, d_, e_, colpart_;

@@ -26,7 +26,7 @@ class DistComm {
 
   // Collective: every rank calls with the same unique id.
   void init(int rank, int world, const char *unique_id);
-  bool active() const { return world_ > 1 || comm_ != nullptr; }
+  bool active() const { return comm_ != nullptr; }
   int rank() const { return rank_; }
   int world() const { return world_; }
 

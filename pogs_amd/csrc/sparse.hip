@@ -163,10 +163,27 @@ __global__ void __launch_bounds__(kSpTpb) spmv_kernel(Csr<T> A, const T *__restr
       __syncthreads();
       continue;
     }
-    for (int k = t; k < cnt; k += kSpTpb) {
-      T v = A.val[p0 + k];
-      if (SQ) v *= v;
-      s_prod[k] = v * (x[A.ind[p0 + k]] * xs);
+    // stage val * x[ind] in LDS: 8 independent coalesced value/index loads and 8
+    // gathers in flight per thread
+    constexpr int U = 8;
+    for (int k0 = 0; k0 < cnt; k0 += kSpTpb * U) {
+      T v[U];
+      int id[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u * kSpTpb + t;
+        const bool ok = k < cnt;
+        v[u] = ok ? A.val[p0 + k] : static_cast<T>(0);
+        id[u] = ok ? A.ind[p0 + k] : 0;
+      }
+      T xg[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) xg[u] = x[id[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u * kSpTpb + t;
+        if (k < cnt) s_prod[k] = (SQ ? v[u] * v[u] : v[u]) * (xg[u] * xs);
+      }
     }
     __syncthreads();
     const int nrows = r1 - r0;

@@ -309,7 +309,10 @@ class Solver:
         if dist is not None:
             rank, world, m_global, uid = dist
             dist_s = _lib.PogsAmdDist(rank=rank, world=world, m_global=m_global)
-            ctypes.memmove(dist_s.unique_id, bytes(uid), _lib.UNIQUE_ID_BYTES)
+            uid = bytes(uid)
+            assert len(uid) == _lib.UNIQUE_ID_BYTES
+            # (a c_char array field reads back as an immutable bytes copy: write through the address)
+            ctypes.memmove(ctypes.addressof(dist_s) + _lib.PogsAmdDist.unique_id.offset, uid, _lib.UNIQUE_ID_BYTES)
         self.sparse = (not device_ptr) and HAS_SCIPY and sp.issparse(A)
         if self.sparse:
             A_csr = sp.csr_matrix(A, dtype=self.dtype)

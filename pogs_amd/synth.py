@@ -25,10 +25,16 @@ def dense_lasso(m, n, seed=0, dtype=np.float64, density=0.1, noise=0.1):
     return A, b, x_true
 
 
-def dense_logistic(m, n, seed=0, dtype=np.float64, density=0.3):
+def dense_logistic(m, n, seed=0, dtype=np.float64, density=0.3, logit_std=None):
+    """logit_std=None is the reference recipe (w_true ~ N(0,1) on 30% of the entries).  For
+    large n that makes the logits' spread ~ sqrt(0.3 n), i.e. nearly separable labels, on
+    which the reference algorithm itself runs into max_iter (checked with the compiled
+    reference / oracle at 20000 x 500); logit_std rescales w_true so std(A w) = logit_std."""
     rng = np.random.default_rng(seed)
     A = rng.standard_normal((m, n), dtype=dtype)
     w = rng.standard_normal(n) * (rng.random(n) < density)
+    if logit_std is not None:
+        w *= logit_std / np.sqrt(max(np.sum(w * w), 1e-300))
     p = 1.0 / (1.0 + np.exp(-(A.astype(np.float64) @ w)))
     y = 2.0 * (rng.random(m) < p) - 1.0
     return A, y, w

@@ -330,3 +330,23 @@ def test_reference_c_interface_lasso_2x2():
     assert r["status"] == 0
     assert r["optval"] >= 0
     assert np.abs(A @ r["x"] - r["y"]).sum() < 0.1
+
+
+def test_one_rank_rccl_path_matches_plain_solve():
+    """The row-sharded code path (RCCL all-reduces on the solver's stream) with a 1-rank
+    communicator must reproduce the plain single-GPU solve."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.dense_lasso(1500, 200, seed=13, dtype=np.float32)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 200)
+    with pogs.Solver(A, dtype=np.float32) as s:
+        r0 = s.solve(f, g)
+    uid = pogs.dist_unique_id()
+    assert len(uid) == 128
+    with pogs.Solver(A, dtype=np.float32, dist=(0, 1, 1500, uid)) as s:
+        r1 = s.solve(f, g)
+    assert r0["status"] == r1["status"] == 0
+    assert r0["iterations"] == r1["iterations"]
+    assert relerr(r1["x"], r0["x"]) < 1e-6
+    assert r1["optval"] == pytest.approx(r0["optval"], rel=1e-6)
