@@ -142,6 +142,22 @@ def cpu_baseline(A_host, b, n, budget_s):
     return out
 
 
+def pmc_traffic(m, n):
+    """HBM bytes per launch of the A-streaming kernels from the committed rocprofv3 --pmc summary
+    (profiles/pmc_traffic_c2.json: separate FETCH_SIZE / WRITE_SIZE passes of this same command,
+    gfx950 half-count correction applied; scripts/pmc_summary.py).  None if it does not apply."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_c2.json")
+    if (m, n) != (M_PER_GPU, N_COLS) or not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        v = [e["hbm_bytes_per_launch_corrected"] for k, e in d.items()
+             if "stream_rows_kernel<float" in k and ("GemvTOp" in k or "false, 0, ProjTailOp" in k)]
+        return sum(v) / len(v) if v else None
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -216,7 +232,7 @@ def main():
                        "rows_per_gpu": m, "cols": n, "projector": "direct (MFMA Gram + Cholesky)",
                        "parallelism": "row-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(m, n),
                          "kernel": "stream_rows_kernel (pass over A)", "bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": avg_ms, "launches": st["stream_launches"],
                          "iteration_frac": iter_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},

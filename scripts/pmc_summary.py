@@ -1,0 +1,38 @@
+"""Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, csv output) per kernel.
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (guides/MI355X_MICROARCH.md, HBM section):
+FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so the
+read side is doubled; WRITE_SIZE is taken as is (uncalibrated, and <1 % of the traffic here).
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def load(fn, counter):
+    agg = collections.defaultdict(list)
+    with open(fn) as fh:
+        for row in csv.DictReader(fh):
+            if row["Counter_Name"] != counter:
+                continue
+            name = re.sub(r"pogs_amd::|\(anonymous namespace\)::", "", row["Kernel_Name"])
+            if name.startswith("void at::") or "rocclr" in name:
+                continue
+            agg[name].append(float(row["Counter_Value"]))
+    return agg
+
+
+fetch = load(sys.argv[1], "FETCH_SIZE")
+write = load(sys.argv[2], "WRITE_SIZE")
+out = {}
+for name in sorted(set(fetch) | set(write)):
+    f = fetch.get(name, [0.0])
+    w = write.get(name, [0.0])
+    fe, wr = sum(f) / len(f) * 1024.0, sum(w) / len(w) * 1024.0
+    out[name] = {"launches": len(f), "fetch_size_bytes_raw": fe, "write_size_bytes": wr,
+                 "hbm_bytes_per_launch_corrected": 2.0 * fe + wr}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print("wrote", sys.argv[3], len(out), "kernels")
