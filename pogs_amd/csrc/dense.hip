@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 #include "engine.h"
 #include "gemm.h"
@@ -271,8 +272,15 @@ class DenseSolver final : public SolverBase {
     xout_.alloc(np); yout_.alloc(m_); lout_.alloc(m_); muout_.alloc(np);
     f_.alloc(m_); g_.alloc(n_); fs_.alloc(m_); gs_.alloc(n_);
     colpart_.alloc(static_cast<size_t>(planA_.grid_max) * np);
+    const char *fe = std::getenv("POGS_AMD_FUSED");
+    fused_ok_ = tall_ && stream2_supported(planA_) && !(fe && fe[0] == '0');
+    if (fused_ok_) {
+      colpart2_.alloc(static_cast<size_t>(planA_.grid_max) * np);
+      y12s_.alloc(m_); ytemps_.alloc(m_);
+      y12s_.zero(s); ytemps_.zero(s);
+    }
     const size_t vb = vec_blocks(n_) + vec_blocks(m_);
-    ctx_.ensure_spart(std::max<size_t>(static_cast<size_t>(planA_.grid_max) * 4 + 4096, vb * 3 + 64));
+    ctx_.ensure_spart(std::max<size_t>(static_cast<size_t>(planA_.grid_max) * 6 + 4096, vb * 3 + 64));
   }
 
   StreamArgs<T> argsA() const {
@@ -288,14 +296,15 @@ class DenseSolver final : public SolverBase {
   // before op runs.
   template <typename ColOp>
   void finish_cols(const ColOp &op, double *colop_scalar_out, int yslot, int yslot_count,
-                   int nparts_override = -1) {
+                   int nparts_override = -1, const T *partials_src = nullptr) {
     hipStream_t s = ctx_.stream;
+    const T *colpart = partials_src ? partials_src : colpart_.p;
     const int nparts = nparts_override > 0 ? nparts_override : stream_grid<false, true>(planA_, m_);
-    double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 4;  // separate scratch region
+    double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;  // separate scratch region
     if (!multi_) {
-      launch_reduce_cols<T, ColOp>(colpart_.p, nparts, n_pad_, op, sp, s);
+      launch_reduce_cols<T, ColOp>(colpart, nparts, n_pad_, op, sp, s);
     } else {
-      launch_reduce_cols<T, StoreColOp<T>>(colpart_.p, nparts, n_pad_, StoreColOp<T>{1, 0, tmpn_.p, n_}, sp, s);
+      launch_reduce_cols<T, StoreColOp<T>>(colpart, nparts, n_pad_, StoreColOp<T>{1, 0, tmpn_.p, n_}, sp, s);
       if (yslot_count > 0) ctx_.dist.allreduce2<T>(tmpn_.p, n_pad_, ctx_.S.p + yslot, yslot_count, s);
       else ctx_.dist.allreduce(tmpn_.p, n_pad_, s);
       launch_reduce_cols<T, ColOp>(tmpn_.p, 1, n_pad_, op, sp, s);
@@ -476,6 +485,9 @@ class DenseSolver final : public SolverBase {
     };
     up(f_, f, m_);
     up(g_, g, n_);
+    // the one-pass kernel evaluates prox_f inline: only for the cheap base functions
+    fused_now_ = fused_ok_;
+    for (int i = 0; i < m_ && fused_now_; ++i) fused_now_ = is_cheap_prox(f.h[i]);
     // scaled copies: h and b shared with the originals (pogs.cpp:608-617)
     launch_scale_objective<T>(f_.view(), fs_.a.p, fs_.c.p, fs_.d.p, fs_.e.p, d_.p, m_, true, s);
     launch_scale_objective<T>(g_.view(), gs_.a.p, gs_.c.p, gs_.d.p, gs_.e.p, e_.p, n_, false, s);
@@ -499,11 +511,13 @@ class DenseSolver final : public SolverBase {
     xt_.zero(s); yt_.zero(s); xtemp_.zero(s); ytemp_.zero(s);
     cur_ = 0;
     zt_scale_ = 1;
+    spec_valid_ = false;
     ctl_.reset();
   }
 
   // One ADMM iteration (pogs.cpp:253-470).  Returns true when the solve stops.
   bool iteration(unsigned verbose) {
+    if (fused_now_) return iteration_fused(verbose);
     hipStream_t s = ctx_.stream;
     const int nw = cur_ ^ 1;
     const bool multi = multi_;
@@ -585,6 +599,98 @@ class DenseSolver final : public SolverBase {
     return false;
   }
 
+  // One ADMM iteration as ONE pass over A (two when the previous pass could not
+  // speculate).  Same arithmetic as iteration(): the pass that forms y_{k+1} = A x_{k+1}
+  // also (a) evaluates the exact primal residual of iteration k with a second dot
+  // product, and (b) assuming rho stays, runs the y half of iteration k+1's prox /
+  // over-relaxation per row and accumulates A^T yhat_{k+1} and the exact-dual-residual
+  // column sums for k+1.  If rho changes the speculative results are dropped.
+  bool iteration_fused(unsigned verbose) {
+    hipStream_t s = ctx_.stream;
+    const int nw = cur_ ^ 1;
+    const int bx = vec_blocks(n_), by = vec_blocks(m_);
+    // (A) prox / over-relaxation: x half always, y half unless already speculated
+    AdmmPreArgs<T> pa;
+    pa.n_x = n_; pa.n_y = spec_valid_ ? 0 : m_;
+    pa.g = gview(); pa.f = fview();
+    pa.x_cur = x_[cur_].p; pa.y_cur = y_[cur_].p;
+    pa.xt = xt_.p; pa.yt = yt_.p;
+    pa.zt_scale = zt_scale_;
+    pa.x12 = x12_.p; pa.y12 = y12_.p;
+    pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
+    pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
+    pa.partials = ctx_.spart.p;
+    pa.blocks_x = bx;
+    launch_admm_pre<T>(pa, s);
+    {
+      SumJob j[2] = {{ctx_.spart.p, bx, 3, ctx_.S.p + kGapX},
+                     {ctx_.spart.p + static_cast<size_t>(bx) * 3, by, 3, ctx_.S.p + kGapY}};
+      launch_sum_jobs(j, spec_valid_ ? 1 : 2, s);
+    }
+    int nparts;
+    if (spec_valid_) {
+      POGS_HIP_CHECK(hipMemcpyAsync(ctx_.S.p + kGapY, ctx_.S.p + kSpecGapY, 3 * sizeof(double),
+                                    hipMemcpyDeviceToDevice, s));
+      nparts = stream2_grid<2>(planA_, m_);
+    } else {
+      // (B) column sums A^T yhat_k and A^T (y12 + c yt - yprev)
+      StreamArgs2<T> a2{A_.p, lda_, m_, n_pad_, nullptr, nullptr, colpart_.p, colpart2_.p, ctx_.spart.p};
+      ctx_.stream_timer.begin(s);
+      launch_stream2<T, 0, 2>(planA_, a2, PreAccOp<T>{ytemp_.p, y12_.p, yt_.p, y_[cur_].p, zt_scale_}, s);
+      ctx_.stream_timer.end(s);
+      nparts = stream2_grid<0>(planA_, m_);
+      ctx_.stats.matvecs += 1;
+    }
+    // (C) x = (G + I)^{-1} (xtemp + A^T yhat); exact dual residual from the second sums
+    finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, kGapY, 3, nparts, colpart_.p);
+    finish_cols(ExactColOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_, n_}, ctx_.S.p + kExactS2, 0, 0, nparts,
+                colpart2_.p);
+    solve_gram(rhs_.p, xtemp_.p, ProjTailOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p}, ctx_.S.p + kDXprev2);
+    // (D) the pass over A
+    {
+      StreamArgs2<T> a2{A_.p, lda_, m_, n_pad_, x_[nw].p, x12_.p, colpart_.p, colpart2_.p, ctx_.spart.p};
+      FusedIterOp<T> op{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, fview(), ctl_.rho, ctl_.alpha(), y12s_.p,
+                        ytemps_.p};
+      ctx_.stream_timer.begin(s);
+      launch_stream2<T, 2, 2>(planA_, a2, op, s);
+      ctx_.stream_timer.end(s);
+      const int grid = stream2_grid<2>(planA_, m_);
+      SumJob j[2] = {{ctx_.spart.p, grid, 3, ctx_.S.p + kDYprev2, 6, 0},
+                     {ctx_.spart.p, grid, 3, ctx_.S.p + kSpecGapY, 6, 3}};
+      launch_sum_jobs(j, 2, s);
+      if (multi_) ctx_.dist.allreduce(ctx_.S.p + kDYprev2, 3, s);
+      ctx_.stats.matvecs += 1;
+    }
+    // (E) host decisions (pogs.cpp:270-273, 342-394)
+    const double *S = ctx_.fetch_scalars();
+    ctl_.set_pre(S);
+    bool exact = false;
+    if (ctl_.set_approx(S, nrmA_)) {
+      ctl_.set_exact(S);
+      exact = true;
+    }
+    const bool stop = ctl_.check_stop(exact);
+    if (verbose > 1 && ctx_.dist.rank() == 0 &&
+        ((verbose > 2 && ctl_.k % 10 == 0) || ctl_.k % 100 == 0 || ctl_.converged))
+      std::printf("%5u : %.2e  %.2e  %.2e  %.2e  %.2e  %.2e\n", ctl_.k, (double)ctl_.nrm_r, (double)ctl_.eps_pri,
+                  (double)ctl_.nrm_s, (double)ctl_.eps_dua, (double)ctl_.gap, (double)ctl_.eps_gap);
+    if (stop) return true;
+    std::swap(xt_, xtemp_);
+    std::swap(yt_, ytemp_);            // yt = ytilde_{k+1}
+    cur_ = nw;
+    const T rho_before = ctl_.rho;
+    zt_scale_ = ctl_.adapt();
+    if (ctl_.rho == rho_before && zt_scale_ == static_cast<T>(1)) {
+      std::swap(ytemp_, ytemps_);      // ytemp = speculative yhat_{k+1}
+      std::swap(y12_, y12s_);          // y12 = speculative y12_{k+1}
+      spec_valid_ = true;
+    } else {
+      spec_valid_ = false;
+    }
+    ++ctl_.k;
+    return false;
+  }
+
   // optval, status, un-scaling, copy out (pogs.cpp:473-482, 510-518, 567-570).
   int epilogue(void *x, void *y, void *l, void *mu, double *optval) {
     hipStream_t s = ctx_.stream;
@@ -623,7 +729,8 @@ class DenseSolver final : public SolverBase {
   bool tall_ = true, multi_ = false;
   size_t lda_ = 0;
   StreamPlan planA_, planW_;
-  DevBuf<T> A_, W_, U_, d_, e_, colpart_;
+  DevBuf<T> A_, W_, U_, d_, e_, colpart_, colpart2_, y12s_, ytemps_;
+  bool fused_ok_ = false, fused_now_ = false, spec_valid_ = false;
   DevBuf<T> x_[2], y_[2], xt_, yt_, xtemp_, ytemp_, x12_, y12_, rhs_, tvec_, tmpn_;
   DevBuf<T> xout_, yout_, lout_, muout_;
   FnBuf<T> f_, g_, fs_, gs_;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "prox.h"
 
 namespace pogs_amd {
 
@@ -150,6 +151,80 @@ struct ProjTailAddOp {
     return dot;
   }
   __device__ __forceinline__ T u(int) const { return 0; }
+};
+
+// ---- functors of the one-pass iteration (stream_rows2_kernel) ---------------
+
+// Column-sum-only pass before the projection when the previous pass could not
+// speculate (rho changed / cold start): u0 = yhat_k (A^T yhat, projector_direct_dense.cpp:123),
+// u1 = y12_k + c yt_k - yprev_k (exact dual residual, pogs.cpp:366-369).
+template <typename T>
+struct PreAccOp {
+  static constexpr int NS = 0;
+  struct Pre {};
+  const T *ytemp, *y12, *yt, *ycur;
+  T zt_scale;
+  __device__ __forceinline__ Pre prefetch(int) const { return Pre{}; }
+  template <int N, int ND, int NA>
+  __device__ __forceinline__ void row(int, const Pre &, const T (&)[ND], double (&)[N], T (&)[NA]) const {}
+  template <int NA>
+  __device__ __forceinline__ void uonly(int i, T (&u)[NA]) const {
+    u[0] = ytemp[i];
+    u[1] = y12[i] + zt_scale * yt[i] - ycur[i];
+  }
+};
+
+// The single pass of iteration k (after x_{k+1} is known):
+//   y_{k+1} = dot0; residual sums and dual update as ProjTailOp (pogs.cpp:342-348,397-399);
+//   exact primal residual r_i = dot1 - y12_i with dot1 = (A x12_k)_i (pogs.cpp:353-364);
+//   then, assuming rho stays, the y half of iteration k+1's prox / gap sums /
+//   over-relaxation (pogs.cpp:257-278) and the two column-sum inputs of k+1.
+// Scalars: [ |yprev-y|^2, |y12-y|^2, |A x12 - y12|^2, sum w h, |w|^2, |h|^2 ].
+template <typename T>
+struct FusedIterOp {
+  static constexpr int NS = 6;
+  struct Pre {
+    T ycur, y12, ytemp, a, b, c, d, e;
+    int h;
+  };
+  T *ynew;
+  const T *ycur, *y12;
+  T *ytemp;        // in: yhat_k, out: ytilde_{k+1}
+  FnView<T> f;     // scaled f
+  T rho, alpha;
+  T *y12s, *ytemps;  // speculative y12_{k+1}, yhat_{k+1}
+  __device__ __forceinline__ Pre prefetch(int i) const {
+    Pre p;
+    p.ycur = ycur[i]; p.y12 = y12[i]; p.ytemp = ytemp[i];
+    p.h = f.h[i]; p.a = f.a[i]; p.b = f.b[i]; p.c = f.c[i]; p.d = f.d[i]; p.e = f.e[i];
+    return p;
+  }
+  template <int N, int ND, int NA>
+  __device__ __forceinline__ void row(int i, const Pre &p, const T (&dot)[ND], double (&s)[N], T (&u)[NA]) const {
+    const T yn = dot[0];
+    const T h0 = p.y12;
+    ynew[i] = yn;
+    const T a = p.ycur - yn, b = h0 - yn;
+    s[0] += static_cast<double>(a) * a;
+    s[1] += static_cast<double>(b) * b;
+    const T r = dot[1] - h0;
+    s[2] += static_cast<double>(r) * r;
+    const T ztn = p.ytemp - yn;
+    ytemp[i] = ztn;
+    const T v = yn - ztn;
+    const T h = dev::ProxEvalCheap(p.h, p.a, p.b, p.c, p.d, p.e, v, rho);
+    const T w = v - h;
+    y12s[i] = h;
+    const T yh = ztn + alpha * h + (static_cast<T>(1) - alpha) * yn;
+    ytemps[i] = yh;
+    s[3] += static_cast<double>(w) * h;
+    s[4] += static_cast<double>(w) * w;
+    s[5] += static_cast<double>(h) * h;
+    u[0] = yh;
+    u[1] = h + ztn - yn;
+  }
+  template <int NA>
+  __device__ __forceinline__ void uonly(int, T (&)[NA]) const {}
 };
 
 // ---- column functors ------------------------------------------------------

@@ -171,6 +171,32 @@ __device__ inline T ProxEval(int h, T a, T b, T c, T d, T e, T v, T rho) {
   return (v + b) / a;
 }
 
+// Subset used inside the one-pass streaming kernel, where registers are scarce:
+// every base function whose prox is a few arithmetic operations.  The host
+// only selects that kernel when all f_i are in this set (is_cheap_prox).
+template <typename T>
+__device__ __forceinline__ T ProxEvalCheap(int h, T a, T b, T c, T d, T e, T v, T rho) {
+  v = a * (v * rho - d) / (e + rho) - b;
+  rho = (e + rho) / (c * a * a);
+  const T zero = 0, ir = 1 / rho;
+  T r = v;
+  switch (h) {
+    case kAbs: r = Max(zero, v - ir) - Max(zero, -(v + ir)); break;
+    case kHuber: r = Abs(v) < 1 + ir ? v * rho / (1 + rho) : v - (v >= 0 ? ir : -ir); break;
+    case kIdentity: r = v - ir; break;
+    case kIndBox01: r = v <= 0 ? zero : (v >= 1 ? static_cast<T>(1) : v); break;
+    case kIndEq0: r = zero; break;
+    case kIndGe0: r = v <= 0 ? zero : v; break;
+    case kIndLe0: r = v >= 0 ? zero : v; break;
+    case kMaxNeg0: r = v + ir <= 0 ? v + ir : (v >= 0 ? v : zero); break;
+    case kMaxPos0: r = v >= ir ? v - ir : (v <= 0 ? v : zero); break;
+    case kNegLog: r = (v + Sqrt(v * v + 4 / rho)) / 2; break;
+    case kSquare: r = rho * v / (1 + rho); break;
+    default: break;  // kZero
+  }
+  return (r + b) / a;
+}
+
 // c*h(a*x-b) + d*x + e*x^2/2 (prox_lib.h:240-349).
 template <typename T>
 __device__ inline T FuncEval(int h, T a, T b, T c, T d, T e, T x) {
@@ -202,4 +228,9 @@ __device__ inline T FuncEval(int h, T a, T b, T c, T d, T e, T x) {
 }
 
 }  // namespace dev
+
+inline bool is_cheap_prox(int h) {
+  return h != kExp && h != kLogistic && h != kNegEntr && h != kRecipr;
+}
+
 }  // namespace pogs_amd

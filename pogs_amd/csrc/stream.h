@@ -258,6 +258,207 @@ void launch_stream(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hi
 }
 
 // ---------------------------------------------------------------------------
+// stream_rows2_kernel: the same pass with up to two dot products (two
+// register-resident x vectors) and up to two column-sum accumulators per row.
+// It is what makes a whole ADMM iteration a single pass over A:
+//   dot[0] = A x_{k+1}  (the projection's y),  dot[1] = A x12_k  (exact primal residual),
+//   acc[0] += yhat_{k+1} * row  (next iteration's A^T yhat, speculative),
+//   acc[1] += u2_{k+1}  * row   (next iteration's exact dual residual).
+// ND = 0 is the column-sum-only form (two u values per row from the functor).
+// ---------------------------------------------------------------------------
+template <typename T>
+struct StreamArgs2 {
+  const T *A;
+  size_t lda;
+  int m, n_pad;
+  const T *xin0, *xin1;      // ND dot vectors (length n_pad)
+  T *col_partials0, *col_partials1;  // NA accumulators: [gridDim.x][n_pad] each
+  double *scalar_partials;   // [gridDim.x][Op::NS]
+};
+
+template <typename T, int TPB, int NV, int R, int ND, int NA, typename Op>
+__global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op op) {
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int NW = TPB / 64;
+  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+  constexpr int NDD = ND > 0 ? ND : 1;
+  __shared__ T s_part[2 * R * NDD * NW];
+  __shared__ T s_u[2 * R * NA];
+  __shared__ double s_red[NS * NW];
+  // the second dot vector lives in LDS (dynamic, n_pad elements): it is re-read per
+  // row with conflict-free 16-byte reads and frees 4*NV VGPRs for a second resident wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  T *s_x1 = reinterpret_cast<T *>(s_dyn);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+  V xv[NV];
+  V acc[NA][NV];
+  if (ND > 0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * TPB + t) * VEC;
+      xv[v] = (col < a.n_pad) ? *reinterpret_cast<const V *>(a.xin0 + col) : dev::vzero<V>();
+      if (ND > 1 && col < a.n_pad) *reinterpret_cast<V *>(s_x1 + col) = *reinterpret_cast<const V *>(a.xin1 + col);
+    }
+    if (ND > 1) __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < NA; ++q)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[q][v] = dev::vzero<V>();
+  double sacc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
+
+  const int nblk = (a.m + R - 1) / R;
+  int slot = 0;
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x, slot ^= 1) {
+    const int row0 = blk * R;
+    V av[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r;
+      const T *rp = a.A + static_cast<size_t>(row) * a.lda;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int col = (v * TPB + t) * VEC;
+        V val = dev::vzero<V>();
+        if (col < a.n_pad && row < a.m) val = *reinterpret_cast<const V *>(rp + col);
+        av[r][v] = val;
+      }
+    }
+    // the row functor's own operands (coefficients, y-vectors) are requested now, so
+    // their latency overlaps the row tile's instead of following the reduction
+    typename Op::Pre pre;
+    if (ND > 0 && t < R && row0 + t < a.m) pre = op.prefetch(row0 + t);
+    if (ND > 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        T s0 = 0, s1 = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          s0 += dev::vdot(av[r][v], xv[v]);
+          if (ND > 1) {
+            const int col = (v * TPB + t) * VEC;
+            if (col < a.n_pad) s1 += dev::vdot(av[r][v], *reinterpret_cast<const V *>(s_x1 + col));
+          }
+        }
+        s0 = dev::wave_sum(s0);
+        if (ND > 1) s1 = dev::wave_sum(s1);
+        if (lane == 0) {
+          s_part[((slot * R + r) * NDD + 0) * NW + wave] = s0;
+          if (ND > 1) s_part[((slot * R + r) * NDD + 1) * NW + wave] = s1;
+        }
+      }
+      __syncthreads();
+      if (t < R) {
+        const int row = row0 + t;
+        T uu[NA];
+#pragma unroll
+        for (int q = 0; q < NA; ++q) uu[q] = 0;
+        if (row < a.m) {
+          T dots[NDD];
+#pragma unroll
+          for (int d = 0; d < ND; ++d) {
+            T s = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += s_part[((slot * R + t) * NDD + d) * NW + w];
+            dots[d] = s;
+          }
+          op.row(row, pre, dots, sacc, uu);
+        }
+#pragma unroll
+        for (int q = 0; q < NA; ++q) s_u[(slot * R + t) * NA + q] = uu[q];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      T uu[NA];
+      if (ND > 0) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) uu[q] = s_u[(slot * R + r) * NA + q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) uu[q] = 0;
+        if (row0 + r < a.m) op.uonly(row0 + r, uu);
+      }
+#pragma unroll
+      for (int q = 0; q < NA; ++q)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dev::vfma(acc[q][v], uu[q], av[r][v]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    T *out = (q == 0 ? a.col_partials0 : a.col_partials1) + static_cast<size_t>(blockIdx.x) * a.n_pad;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * TPB + t) * VEC;
+      if (col < a.n_pad) *reinterpret_cast<V *>(out + col) = acc[q][v];
+    }
+  }
+  if (Op::NS > 0) {
+    __syncthreads();
+    dev::block_sum<NS, TPB>(sacc, s_red);
+    if (t == 0) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) a.scalar_partials[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
+    }
+  }
+}
+
+// Whether the two-dot / two-accumulator kernel fits the register file for this plan
+// (row tile 4*R*NV + 2 x vectors 8*NV + 2 accumulators 8*NV VGPRs, R = 1).
+inline bool stream2_supported(const StreamPlan &p) {
+  if (!p.ok) return false;
+  if (p.tpb == 1024) return false;  // 128-VGPR budget: would spill
+  return p.nv <= 10;
+}
+template <int ND>
+inline int stream2_rows(const StreamPlan &p) { return (ND > 0 || p.tpb == 1024) ? 1 : 2; }
+template <int ND>
+inline int stream2_grid(const StreamPlan &p, int m) {
+  const int R = stream2_rows<ND>(p);
+  const int nblk = (m + R - 1) / R;
+  return nblk < p.grid_max ? (nblk > 0 ? nblk : 1) : p.grid_max;
+}
+
+template <typename T, int ND, int NA, typename Op>
+void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, hipStream_t s) {
+  POGS_CHECK(stream2_supported(p), "plan not supported by the two-accumulator kernel");
+  const int grid = stream2_grid<ND>(p, a.m);
+#define POGS_STREAM2_CASE(TPB_, NV_)                                                            \
+  if (p.tpb == TPB_ && p.nv == NV_) {                                                           \
+    constexpr int R_ = (ND > 0 || TPB_ == 1024) ? 1 : 2;                                        \
+    const size_t lds = (ND > 1) ? static_cast<size_t>(a.n_pad) * sizeof(T) : 0;                 \
+    static size_t attr_bytes = 48 * 1024;                                                       \
+    if (lds > attr_bytes) {                                                                     \
+      POGS_HIP_CHECK(hipFuncSetAttribute(                                                       \
+          reinterpret_cast<const void *>(&stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>),   \
+          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                  \
+      attr_bytes = lds;                                                                         \
+    }                                                                                           \
+    hipLaunchKernelGGL((stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>), dim3(grid),         \
+                       dim3(TPB_), lds, s, a, op);                                              \
+    return;                                                                                     \
+  }
+  POGS_STREAM2_CASE(64, 1)
+  POGS_STREAM2_CASE(64, 2)
+  POGS_STREAM2_CASE(64, 4)
+  POGS_STREAM2_CASE(256, 2)
+  POGS_STREAM2_CASE(256, 3)
+  POGS_STREAM2_CASE(256, 4)
+  POGS_STREAM2_CASE(256, 5)
+  POGS_STREAM2_CASE(256, 6)
+  POGS_STREAM2_CASE(256, 8)
+  POGS_STREAM2_CASE(256, 10)
+#undef POGS_STREAM2_CASE
+  throw Error("no stream2 kernel instance for plan");
+}
+
+// ---------------------------------------------------------------------------
 // reduce_cols: out-of-kernel second stage of the column sums.
 //   total[j] = sum_b partials[b][j]   (b in fixed order)
 // and hands total[j] to a per-column functor.
@@ -275,7 +476,17 @@ __global__ void __launch_bounds__(256) reduce_cols_kernel(const T *partials, int
   const int col = (blockIdx.x * 32 + cx) * VEC;
   V sum = dev::vzero<V>();
   if (col < n_pad) {
-    for (int b = g; b < nparts; b += 8) {
+    // 8 independent loads in flight per thread (the partials sit in L2 / Infinity Cache)
+    int b = g;
+    for (; b + 56 < nparts; b += 64) {
+      V v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        v[q] = *reinterpret_cast<const V *>(partials + static_cast<size_t>(b + 8 * q) * n_pad + col);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dev::vfma(sum, static_cast<T>(1), v[q]);
+    }
+    for (; b < nparts; b += 8) {
       const V v = *reinterpret_cast<const V *>(partials + static_cast<size_t>(b) * n_pad + col);
       dev::vfma(sum, static_cast<T>(1), v);
     }

@@ -17,6 +17,7 @@ enum Slot : int {
   kGapY = 0, kWY2, kHY2, kDYprev2, kDY12, kExactR2, kPowSx2, kFro2, kFvalF, kCgQ2, kCgR2,
   kNumYSlots = 12,
   kGapX = 12, kWX2, kHX2, kDXprev2, kDX12, kExactS2, kPowX2, kFvalG, kCgP2, kCgS2, kCgX2, kCgS02,
+  kSpecGapY = 24, kSpecWY2, kSpecHY2,   // next iteration's y-half sums from the one-pass kernel
   kNumSlots = 32
 };
 
@@ -86,6 +87,8 @@ struct SumJob {
   const double *partials;
   int nparts, ns;
   double *out;
+  int stride = 0;   // doubles between consecutive partial records (0: ns)
+  int offset = 0;   // first scalar of the record to sum
 };
 void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s);
 

@@ -122,9 +122,10 @@ struct SumJobs {
 __global__ void __launch_bounds__(256) sum_jobs_kernel(SumJobs jobs) {
   const SumJob job = jobs.j[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int stride = job.stride > 0 ? job.stride : job.ns;
   for (int k = wave; k < job.ns; k += 4) {
     double s = 0;
-    for (int b = lane; b < job.nparts; b += 64) s += job.partials[static_cast<size_t>(b) * job.ns + k];
+    for (int b = lane; b < job.nparts; b += 64) s += job.partials[static_cast<size_t>(b) * stride + job.offset + k];
     s = dev::wave_sum(s);
     if (lane == 0) job.out[k] = s;
   }

@@ -316,7 +316,7 @@ def test_iterate_matches_solve_trajectory():
         assert solves == 1
         st = s.stats()
         assert st["iterations"] == 2 * n_it
-        assert st["stream_launches"] >= 4 * n_it
+        assert st["stream_launches"] >= 2 * n_it  # >= one pass over A per iteration
         assert st["stream_ms"] > 0
 
 
