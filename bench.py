@@ -170,9 +170,12 @@ def main():
     from pogs_amd import graph as G
 
     dist_arg = None
-    if world > 1:
+    force_dist = os.environ.get("POGS_AMD_FORCE_DIST", "0") == "1"  # exercise the RCCL path with 1 rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
+        if force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl")
         uid = torch.zeros(128, dtype=torch.uint8, device=dev)
         if rank == 0:
@@ -182,7 +185,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_arg is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -209,7 +212,7 @@ def main():
     solver.iterate(args.steps)
     barrier()
     elapsed = time.time() - t0
-    if world > 1:
+    if dist_arg is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -250,7 +253,7 @@ def main():
                                         "sample": "failed: %r" % (e,)}
         print(json.dumps(line))
     solver.close()
-    if world > 1:
+    if dist_arg is not None:
         dist.barrier()
         dist.destroy_process_group()
 
