@@ -276,6 +276,8 @@ class DenseSolver final : public SolverBase {
     fused_ok_ = tall_ && stream2_supported(planA_) && !(fe && fe[0] == '0');
     if (fused_ok_) {
       colpart2_.alloc(static_cast<size_t>(planA_.grid_max) * np);
+      pair_.alloc(2 * np);
+      pair_.zero(s);
       y12s_.alloc(m_); ytemps_.alloc(m_);
       y12s_.zero(s); ytemps_.zero(s);
     }
@@ -422,12 +424,33 @@ class DenseSolver final : public SolverBase {
     G.zero(s);
     {
       PhaseTimer pt(s);
-      if (tall_) {
-        GemmArgs<T> g{n_, n_, m_, A_.p, lda_, A_.p, lda_, G.p, ld, static_cast<T>(1), static_cast<T>(0)};
-        launch_gemm<T>(true, true, true, g, s);
-      } else {
-        GemmArgs<T> g{m_, m_, n_, A_.p, lda_, A_.p, lda_, G.p, ld, static_cast<T>(1), static_cast<T>(0)};
-        launch_gemm<T>(false, false, true, g, s);
+      // split-K so the tile count is >> the number of workgroup slots (tail effect) and the
+      // K-sum is accumulated in chunks; slabs are added in fixed order (deterministic).
+      const int kdim = tall_ ? m_ : n_;
+      const long long tiles = static_cast<long long>((k_ + 127) / 128) * ((k_ + 127) / 128 + 1) / 2;
+      // chunks of <= ~6k rows keep the fp32 K-accumulation error near 5e-6 relative (a
+      // sequential fp32 sum over 1e5 rows costs ~30 % more ADMM iterations at C2); at
+      // most 8 GB of slabs.
+      const size_t slab = static_cast<size_t>(k_) * ld;
+      int ksplit = 1;
+      while (ksplit < 32 && kdim / (ksplit * 2) >= 2048 && (kdim / ksplit > 6400 || tiles * ksplit < 16LL * ctx_.num_cu * 3) &&
+             slab * sizeof(T) * (ksplit * 2) <= (8ull << 30))
+        ksplit *= 2;
+      DevBuf<T> slabs;
+      T *dst = G.p;
+      if (ksplit > 1) {
+        slabs.alloc(slab * ksplit);
+        slabs.zero(s);
+        dst = slabs.p;
+      }
+      GemmArgs<T> g{k_, k_, kdim, A_.p, lda_, A_.p, lda_, dst, ld, static_cast<T>(1), static_cast<T>(0)};
+      g.ksplit = ksplit;
+      g.kchunk = static_cast<int>(round_up((kdim + ksplit - 1) / ksplit, 16));
+      g.csplit_stride = slab;
+      launch_gemm<T>(tall_, tall_, true, g, s);
+      if (ksplit > 1) {
+        launch_sum_slabs<T>(slabs.p, slab, ksplit, G.p, slab, s);
+        ctx_.sync();   // slabs are freed at scope exit
       }
       if (multi_) ctx_.dist.allreduce(G.p, static_cast<size_t>(k_) * ld, s);
       ctx_.stats.gram_ms = pt.stop_ms();
@@ -642,9 +665,23 @@ class DenseSolver final : public SolverBase {
       ctx_.stats.matvecs += 1;
     }
     // (C) x = (G + I)^{-1} (xtemp + A^T yhat); exact dual residual from the second sums
-    finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, kGapY, 3, nparts, colpart_.p);
-    finish_cols(ExactColOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_, n_}, ctx_.S.p + kExactS2, 0, 0, nparts,
-                colpart2_.p);
+    if (!multi_) {
+      finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, 0, 0, nparts, colpart_.p);
+      finish_cols(ExactColOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_, n_}, ctx_.S.p + kExactS2, 0, 0, nparts,
+                  colpart2_.p);
+    } else {
+      // row shards: both n-vectors and the three gap/norm sums travel in ONE RCCL group
+      double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
+      T *both = pair_.p;
+      launch_reduce_cols<T, StoreColOp<T>>(colpart_.p, nparts, n_pad_, StoreColOp<T>{1, 0, both, n_}, sp, s);
+      launch_reduce_cols<T, StoreColOp<T>>(colpart2_.p, nparts, n_pad_, StoreColOp<T>{1, 0, both + n_pad_, n_}, sp, s);
+      ctx_.dist.allreduce2<T>(both, 2 * static_cast<size_t>(n_pad_), ctx_.S.p + kGapY, 3, s);
+      launch_reduce_cols<T, StoreColOp<T>>(both, 1, n_pad_, StoreColOp<T>{1, 0, rhs_.p, n_}, sp, s);
+      launch_reduce_cols<T, ExactColOp<T>>(both + n_pad_, 1, n_pad_,
+                                           ExactColOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_, n_}, sp, s);
+      SumJob j{sp, reduce_cols_grid(n_pad_, Vec16<T>::N), 1, ctx_.S.p + kExactS2};
+      launch_sum_jobs(&j, 1, s);
+    }
     solve_gram(rhs_.p, xtemp_.p, ProjTailOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p}, ctx_.S.p + kDXprev2);
     // (D) the pass over A
     {
@@ -729,7 +766,7 @@ class DenseSolver final : public SolverBase {
   bool tall_ = true, multi_ = false;
   size_t lda_ = 0;
   StreamPlan planA_, planW_;
-  DevBuf<T> A_, W_, U_, d_, e_, colpart_, colpart2_, y12s_, ytemps_;
+  DevBuf<T> A_, W_, U_, d_, e_, colpart_, colpart2_, pair_, y12s_, ytemps_;
   bool fused_ok_ = false, fused_now_ = false, spec_valid_ = false;
   DevBuf<T> x_[2], y_[2], xt_, yt_, xtemp_, ytemp_, x12_, y12_, rhs_, tvec_, tmpn_;
   DevBuf<T> xout_, yout_, lout_, muout_;

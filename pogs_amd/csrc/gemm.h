@@ -21,6 +21,12 @@ struct GemmArgs {
   const T *B; size_t ldb;
   T *C; size_t ldc;
   T alpha, beta;
+  // split-K (ksplit > 1): unit u computes rows [ks*kchunk, (ks+1)*kchunk) of the K range into
+  // C + ks*csplit_stride, so one launch keeps every CU busy to the end and the K-sum is formed
+  // in chunks (better fp32 accumulation); the caller adds the ksplit slabs in fixed order.
+  int ksplit = 1;
+  int kchunk = 0;
+  size_t csplit_stride = 0;
 };
 
 // A_KMAJ: op(A)(i,k) = A[k*lda + i], else A[i*lda + k].
@@ -49,6 +55,10 @@ void trtri_lower(const T *L, size_t ldg, int n, T *W, size_t ldw, T *tmp, hipStr
 // out (cols x rows, ld_out) = in^T, in is rows x cols with ld_in.
 template <typename T>
 void launch_transpose(const T *in, size_t ld_in, int rows, int cols, T *out, size_t ld_out, hipStream_t s);
+
+// out[i] = sum_s in[s * stride + i], s in fixed order (combines split-K slabs)
+template <typename T>
+void launch_sum_slabs(const T *in, size_t stride, int nslabs, T *out, size_t count, hipStream_t s);
 
 // G[i][i] += v
 template <typename T>

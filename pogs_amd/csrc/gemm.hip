@@ -106,17 +106,30 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
   __shared__ __attribute__((aligned(16))) T sA[BK * LS];
   __shared__ __attribute__((aligned(16))) T sB[BK * LS];
 
+  // XCD-aware unit order: workgroup b runs on XCD b % 8 (observed dispatch order); give each
+  // XCD a contiguous range of units so neighbouring tiles (shared operand panels, same K
+  // range) meet in one L2.  Units beyond the real count exit.
+  const int tm_ = (g.M + BM - 1) / BM, tn_ = (g.N + BN - 1) / BN;
+  const int ntiles = LOWER ? tm_ * (tm_ + 1) / 2 : tm_ * tn_;
+  const int nunits = ntiles * g.ksplit;
+  const int per_xcd = (nunits + kNumXcd - 1) / kNumXcd;
+  const int unit = static_cast<int>(blockIdx.x % kNumXcd) * per_xcd + static_cast<int>(blockIdx.x / kNumXcd);
+  if (unit >= nunits || static_cast<int>(blockIdx.x / kNumXcd) >= per_xcd) return;
+  const int ks = unit / ntiles;
+  const int tile = unit % ntiles;
+  const int kbeg = (g.ksplit > 1) ? ks * g.kchunk : 0;
+  const int kend = (g.ksplit > 1) ? ((kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K) : g.K;
+  T *Cout = g.C + static_cast<size_t>(ks) * g.csplit_stride;
   int ti, tj;
   if (LOWER) {
-    const int p = blockIdx.x;
+    const int p = tile;
     ti = static_cast<int>((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
     while (ti * (ti + 1) / 2 > p) --ti;
     while ((ti + 1) * (ti + 2) / 2 <= p) ++ti;
     tj = p - ti * (ti + 1) / 2;
   } else {
-    const int tiles_n = (g.N + BN - 1) / BN;
-    ti = blockIdx.x / tiles_n;
-    tj = blockIdx.x % tiles_n;
+    ti = tile / tn_;
+    tj = tile % tn_;
   }
   const int i0 = ti * BM, j0 = tj * BN;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -132,16 +145,16 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
       for (int r = 0; r < 4; ++r) acc[a][b][r] = 0;
 
   V ra[TileVec<T>::NVT], rb[TileVec<T>::NVT];
-  const int nk = (g.K + BK - 1) / BK;
-  load_tile<T, A_KMAJ>(g.A, g.lda, i0, 0, g.M, g.K, ra);
-  load_tile<T, B_KMAJ>(g.B, g.ldb, j0, 0, g.N, g.K, rb);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg, g.M, kend, ra);
+  load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg, g.N, kend, rb);
   store_tile<T, A_KMAJ>(sA, ra);
   store_tile<T, B_KMAJ>(sB, rb);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) {
-      load_tile<T, A_KMAJ>(g.A, g.lda, i0, (kt + 1) * BK, g.M, g.K, ra);
-      load_tile<T, B_KMAJ>(g.B, g.ldb, j0, (kt + 1) * BK, g.N, g.K, rb);
+      load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg + (kt + 1) * BK, g.M, kend, ra);
+      load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg + (kt + 1) * BK, g.N, kend, rb);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
@@ -174,7 +187,7 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
         const int row = i0 + wm + a * 16 + Mma<T>::row(lane, r);
         const int col = j0 + wn + b * 16 + l15;
         if (row < g.M && col < g.N) {
-          T *c = g.C + static_cast<size_t>(row) * g.ldc + col;
+          T *c = Cout + static_cast<size_t>(row) * g.ldc + col;
           T v = g.alpha * acc[a][b][r];
           if (g.beta != static_cast<T>(0)) v += g.beta * *c;
           *c = v;
@@ -182,55 +195,62 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
       }
 }
 
-// Unblocked Cholesky of one NB x NB diagonal block held in LDS, followed by the
-// inverse of the triangular factor.  One workgroup.
+// Cholesky of one NB x NB diagonal block held in LDS (right-looking, 2 barriers per
+// column, 16 x 16 thread layout for the rank-1 updates: no integer divisions), then the
+// inverse of the triangular factor by forward substitution, one column per thread
+// with four independent accumulators to pipeline the LDS reads.  One workgroup.
 template <typename T, int NB>
 __global__ void __launch_bounds__(256) potrf_inv_kernel(T *G, size_t ldg, int nb, T *Winv, size_t ldw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int LD = NB + 1;
   T *sL = reinterpret_cast<T *>(smem_raw);
   T *sX = sL + NB * LD;
+  __shared__ T s_diag[NB];
   const int t = threadIdx.x;
-  for (int idx = t; idx < nb * nb; idx += 256) {
-    const int r = idx / nb, c = idx % nb;
-    sL[r * LD + c] = (c <= r) ? G[static_cast<size_t>(r) * ldg + c] : static_cast<T>(0);
-    sX[r * LD + c] = 0;
-  }
-  __syncthreads();
+  const int tx = t & 15, ty = t >> 4;
+  for (int r = ty; r < nb; r += 16)
+    for (int c = tx; c < nb; c += 16) {
+      sL[r * LD + c] = (c <= r) ? G[static_cast<size_t>(r) * ldg + c] : static_cast<T>(0);
+      sX[r * LD + c] = 0;
+    }
   for (int j = 0; j < nb; ++j) {
-    const T ljj = sqrt(sL[j * LD + j]);
     __syncthreads();
+    const T ljj = sqrt(sL[j * LD + j]);
     const T inv = static_cast<T>(1) / ljj;
     for (int i = j + 1 + t; i < nb; i += 256) sL[i * LD + j] *= inv;
-    if (t == 0) sL[j * LD + j] = ljj;
+    if (t == 0) s_diag[j] = ljj;
     __syncthreads();
-    const int w = nb - j - 1;
-    for (int idx = t; idx < w * w; idx += 256) {
-      const int i = j + 1 + idx / w, c = j + 1 + idx % w;
-      if (c <= i) sL[i * LD + c] -= sL[i * LD + j] * sL[c * LD + j];
-    }
-    __syncthreads();
-  }
-  // X = L^{-1}: thread c owns column c (forward substitution), loops kept uniform.
-  if (t < nb) {
-    const int c = t;
-    for (int i = 0; i < nb; ++i) {
-      T acc = 0;
-      for (int p = 0; p < i; ++p) {
-        if (p >= c) acc += sL[i * LD + p] * sX[p * LD + c];
-      }
-      if (i == c) sX[i * LD + c] = static_cast<T>(1) / sL[i * LD + i];
-      else if (i > c) sX[i * LD + c] = -acc / sL[i * LD + i];
+    for (int i = j + 1 + ty; i < nb; i += 16) {
+      const T lij = sL[i * LD + j];
+      for (int c = j + 1 + tx; c <= i; c += 16) sL[i * LD + c] -= lij * sL[c * LD + j];
     }
   }
   __syncthreads();
-  for (int idx = t; idx < nb * nb; idx += 256) {
-    const int r = idx / nb, c = idx % nb;
-    if (c <= r) {
+  if (t < nb) sL[t * LD + t] = s_diag[t];
+  __syncthreads();
+  if (t < nb) {
+    const int c = t;
+    sX[c * LD + c] = static_cast<T>(1) / sL[c * LD + c];
+    for (int i = c + 1; i < nb; ++i) {
+      const T *li = sL + i * LD;
+      T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      int p = c;
+      for (; p + 3 < i; p += 4) {
+        a0 += li[p] * sX[p * LD + c];
+        a1 += li[p + 1] * sX[(p + 1) * LD + c];
+        a2 += li[p + 2] * sX[(p + 2) * LD + c];
+        a3 += li[p + 3] * sX[(p + 3) * LD + c];
+      }
+      for (; p < i; ++p) a0 += li[p] * sX[p * LD + c];
+      sX[i * LD + c] = -((a0 + a1) + (a2 + a3)) / li[i];
+    }
+  }
+  __syncthreads();
+  for (int r = ty; r < nb; r += 16)
+    for (int c = tx; c <= r; c += 16) {
       G[static_cast<size_t>(r) * ldg + c] = sL[r * LD + c];
       Winv[static_cast<size_t>(r) * ldw + c] = sX[r * LD + c];
     }
-  }
 }
 
 template <typename T>
@@ -253,6 +273,25 @@ __global__ void __launch_bounds__(256) transpose_kernel(const T *in, size_t ld_i
 }
 
 template <typename T>
+__global__ void __launch_bounds__(256) sum_slabs_kernel(const T *in, size_t stride, int nslabs, T *out,
+                                                        size_t count_vec) {
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = Vec16<T>::N;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count_vec;
+       i += static_cast<size_t>(gridDim.x) * 256) {
+    V acc = *reinterpret_cast<const V *>(in + i * VEC);
+    T *ap = reinterpret_cast<T *>(&acc);
+    for (int sl = 1; sl < nslabs; ++sl) {
+      const V v = *reinterpret_cast<const V *>(in + static_cast<size_t>(sl) * stride + i * VEC);
+      const T *vp = reinterpret_cast<const T *>(&v);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) ap[c] += vp[c];
+    }
+    *reinterpret_cast<V *>(out + i * VEC) = acc;
+  }
+}
+
+template <typename T>
 __global__ void add_diag_kernel(T *G, size_t ldg, int n, T v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) G[static_cast<size_t>(i) * ldg + i] += v;
@@ -262,11 +301,14 @@ template <typename T, bool A_KMAJ, bool B_KMAJ>
 void launch_gemm_ab(bool lower, const GemmArgs<T> &g, hipStream_t s) {
   const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
   if (tm <= 0 || tn <= 0 || g.K <= 0) return;
+  GemmArgs<T> gg = g;
+  if (gg.ksplit < 1) gg.ksplit = 1;
+  const int nt = (lower ? tm * (tm + 1) / 2 : tm * tn) * gg.ksplit;
+  const int grid = (nt + kNumXcd - 1) / kNumXcd * kNumXcd;
   if (lower) {
-    const int nt = tm * (tm + 1) / 2;
-    hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, true>), dim3(nt), dim3(GT), 0, s, g);
+    hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, true>), dim3(grid), dim3(GT), 0, s, gg);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, false>), dim3(tm * tn), dim3(GT), 0, s, g);
+    hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, false>), dim3(grid), dim3(GT), 0, s, gg);
   }
 }
 
@@ -333,6 +375,12 @@ void launch_transpose(const T *in, size_t ld_in, int rows, int cols, T *out, siz
 }
 
 template <typename T>
+void launch_sum_slabs(const T *in, size_t stride, int nslabs, T *out, size_t count, hipStream_t s) {
+  const size_t nvec = count / Vec16<T>::N;
+  hipLaunchKernelGGL(sum_slabs_kernel<T>, dim3(2048), dim3(256), 0, s, in, stride, nslabs, out, nvec);
+}
+
+template <typename T>
 void launch_add_diag(T *G, size_t ldg, int n, T v, hipStream_t s) {
   hipLaunchKernelGGL(add_diag_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s, G, ldg, n, v);
 }
@@ -342,6 +390,7 @@ void launch_add_diag(T *G, size_t ldg, int n, T v, hipStream_t s) {
   template void cholesky_lower<T>(T *, size_t, int, T *, size_t, hipStream_t);                 \
   template void trtri_lower<T>(const T *, size_t, int, T *, size_t, T *, hipStream_t);         \
   template void launch_transpose<T>(const T *, size_t, int, int, T *, size_t, hipStream_t);    \
+  template void launch_sum_slabs<T>(const T *, size_t, int, T *, size_t, hipStream_t);       \
   template void launch_add_diag<T>(T *, size_t, int, T, hipStream_t);
 POGS_INST(float)
 POGS_INST(double)
