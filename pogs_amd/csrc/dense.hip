@@ -106,7 +106,7 @@ class DenseSolver final : public SolverBase {
     ctx_.stats.t_h2d_s = wall_s() - t0;
     alloc_state();
     equilibrate();
-    norm_est();
+    if (!tall_) norm_est();   // m > n: estimated from the Gram matrix inside factor()
     factor();
     ctx_.sync();
     ctx_.stats.t_init_s = wall_s() - t0;
@@ -412,6 +412,51 @@ class DenseSolver final : public SolverBase {
     ctx_.stats.normest_ms = pt.stop_ms();
   }
 
+  // Norm2Est (equil_helper.h:107-135) for m > n, run on G = A^T A instead of A: the
+  // iteration x <- A^T (A x) is x <- G x and |A x|^2 = x^T G x, so each power step reads
+  // the n x n lower triangle (0.2 GB at C2) instead of A (4 GB).  Same start vector, same
+  // normalisation and stopping rule; G is already summed over shards.
+  void norm_est_gram(T *G, size_t ld) {
+    hipStream_t s = ctx_.stream;
+    PhaseTimer pt(s);
+    launch_zero_upper<T>(G, ld, n_, s);
+    std::vector<T> x0(n_pad_, 0);
+    rand_uniform_host(x0.data(), n_);
+    POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, x0.data(), n_pad_ * sizeof(T), hipMemcpyHostToDevice, s));
+    ctx_.sync();
+    T *xa = xtemp_.p, *xb = rhs_.p;
+    const T kTol = static_cast<T>(1e-4);
+    T norm_est = 0, last;
+    const int grid = stream_grid<true, true>(planW_, n_);
+    double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
+    unsigned i = 0;
+    for (i = 0; i < 50; ++i) {
+      last = norm_est;
+      const double *nrm = (i == 0) ? nullptr : ctx_.S.p + kPowX2;
+      StreamArgs<T> a;
+      a.A = G; a.lda = ld; a.m = n_; a.n_pad = n_pad_;
+      a.xin = xa; a.xin_add = nullptr; a.xin_nrm2 = nrm;
+      a.col_partials = colpart_.p; a.scalar_partials = ctx_.spart.p;
+      launch_stream<T, true, true, false, kLower>(planW_, a, SymRowOp<T>{G, ld, xa, nrm, tvec_.p}, s);
+      launch_reduce_cols<T, SymColOp<T>>(colpart_.p, grid, n_pad_, SymColOp<T>{tvec_.p, xa, nrm, xb, n_}, sp, s);
+      SumJob j{sp, reduce_cols_grid(n_pad_, Vec16<T>::N), 2, ctx_.S.p + kPowX2};   // -> kPowX2, kPowXGx
+      launch_sum_jobs(&j, 1, s);
+      const double *S = ctx_.fetch_scalars();
+      const T normx = static_cast<T>(std::sqrt(S[kPowX2]));
+      const T normSx = static_cast<T>(std::sqrt(S[kPowXGx]));
+      norm_est = normx / normSx;
+      std::swap(xa, xb);
+      if (std::abs(last - norm_est) < kTol * norm_est) { ++i; break; }
+    }
+    nrmA_ = norm_est;
+    ctx_.stats.nrmA = nrmA_;
+    ctx_.stats.norm_est_iters = i;
+    xtemp_.zero(s);
+    rhs_.zero(s);
+    tvec_.zero(s);
+    ctx_.stats.normest_ms = pt.stop_ms();
+  }
+
   // ProjectorDirect::Init + the first-call factorisation (s = 1 always,
   // pogs.cpp:293,296): G = A^T A (m > n) or A A^T (m <= n) on MFMA tiles,
   // L L^T = G + I, W = L^{-1}, U = W^T.
@@ -456,6 +501,7 @@ class DenseSolver final : public SolverBase {
       ctx_.stats.gram_ms = pt.stop_ms();
       ctx_.stats.gram_flops = static_cast<double>(tall_ ? m_ : n_) * k_ * k_;
     }
+    if (tall_) norm_est_gram(G.p, ld);
     launch_add_diag<T>(G.p, ld, k_, static_cast<T>(1), s);               // projector_direct_dense.cpp:118-119
     W_.alloc(static_cast<size_t>(k_) * ld);
     W_.zero(s);

@@ -60,6 +60,10 @@ void launch_transpose(const T *in, size_t ld_in, int rows, int cols, T *out, siz
 template <typename T>
 void launch_sum_slabs(const T *in, size_t stride, int nslabs, T *out, size_t count, hipStream_t s);
 
+// zero the strictly upper triangle of an n x n matrix
+template <typename T>
+void launch_zero_upper(T *G, size_t ldg, int n, hipStream_t s);
+
 // G[i][i] += v
 template <typename T>
 void launch_add_diag(T *G, size_t ldg, int n, T v, hipStream_t s);

@@ -292,6 +292,13 @@ __global__ void __launch_bounds__(256) sum_slabs_kernel(const T *in, size_t stri
 }
 
 template <typename T>
+__global__ void zero_upper_kernel(T *G, size_t ldg, int n) {
+  const int r = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n && c > r) G[static_cast<size_t>(r) * ldg + c] = 0;
+}
+
+template <typename T>
 __global__ void add_diag_kernel(T *G, size_t ldg, int n, T v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) G[static_cast<size_t>(i) * ldg + i] += v;
@@ -381,6 +388,11 @@ void launch_sum_slabs(const T *in, size_t stride, int nslabs, T *out, size_t cou
 }
 
 template <typename T>
+void launch_zero_upper(T *G, size_t ldg, int n, hipStream_t s) {
+  hipLaunchKernelGGL(zero_upper_kernel<T>, dim3((n + 255) / 256, n), dim3(256), 0, s, G, ldg, n);
+}
+
+template <typename T>
 void launch_add_diag(T *G, size_t ldg, int n, T v, hipStream_t s) {
   hipLaunchKernelGGL(add_diag_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s, G, ldg, n, v);
 }
@@ -391,6 +403,7 @@ void launch_add_diag(T *G, size_t ldg, int n, T v, hipStream_t s) {
   template void trtri_lower<T>(const T *, size_t, int, T *, size_t, T *, hipStream_t);         \
   template void launch_transpose<T>(const T *, size_t, int, int, T *, size_t, hipStream_t);    \
   template void launch_sum_slabs<T>(const T *, size_t, int, T *, size_t, hipStream_t);       \
+  template void launch_zero_upper<T>(T *, size_t, int, hipStream_t);                           \
   template void launch_add_diag<T>(T *, size_t, int, T, hipStream_t);
 POGS_INST(float)
 POGS_INST(double)

@@ -153,6 +153,28 @@ struct ProjTailAddOp {
   __device__ __forceinline__ T u(int) const { return 0; }
 };
 
+// Power iteration on the Gram matrix stored as its lower triangle (strict upper part
+// zero): one DOT+ACC pass gives L x (dot) and L^T x (column sums); G x = L x + L^T x - D x.
+// x is held un-normalised; sc = 1/|x| comes from the device scalar written by the
+// previous iteration.
+template <typename T>
+struct SymRowOp {
+  static constexpr int NS = 0;
+  const T *G;
+  size_t ld;
+  const T *x;
+  const double *x_nrm2;   // nullable: first iteration uses x as is
+  T *lowdot;              // out: (L x)_i - G_ii x_i
+  template <int N>
+  __device__ __forceinline__ T row(int i, T dot, double (&)[N]) const {
+    const T sc = x_nrm2 ? static_cast<T>(1.0 / sqrt(*x_nrm2)) : static_cast<T>(1);
+    const T xi = x[i] * sc;
+    lowdot[i] = dot - G[static_cast<size_t>(i) * ld + i] * xi;
+    return xi;
+  }
+  __device__ __forceinline__ T u(int) const { return 0; }
+};
+
 // ---- functors of the one-pass iteration (stream_rows2_kernel) ---------------
 
 // Column-sum-only pass before the projection when the previous pass could not
@@ -305,6 +327,28 @@ struct ProjTailColOp {
       s[0] += static_cast<double>(a) * a;
       s[1] += static_cast<double>(b) * b;
       ztemp[j] -= zn;
+    }
+  }
+};
+
+// x'_j = (L^T x)_j + lowdot_j = (G x)_j; accumulates |x'|^2 and x^T G x (= |A x|^2).
+template <typename T>
+struct SymColOp {
+  static constexpr int NS = 2;
+  const T *lowdot, *x;
+  const double *x_nrm2;
+  T *xnext;
+  int n;
+  template <int N>
+  __device__ __forceinline__ void col(int j, T total, double (&s)[N]) const {
+    if (j < n) {
+      const T sc = x_nrm2 ? static_cast<T>(1.0 / sqrt(*x_nrm2)) : static_cast<T>(1);
+      const T v = total + lowdot[j];
+      xnext[j] = v;
+      s[0] += static_cast<double>(v) * v;
+      s[1] += static_cast<double>(x[j] * sc) * v;
+    } else {
+      xnext[j] = 0;
     }
   }
 };

@@ -16,8 +16,8 @@ namespace pogs_amd {
 enum Slot : int {
   kGapY = 0, kWY2, kHY2, kDYprev2, kDY12, kExactR2, kPowSx2, kFro2, kFvalF, kCgQ2, kCgR2,
   kNumYSlots = 12,
-  kGapX = 12, kWX2, kHX2, kDXprev2, kDX12, kExactS2, kPowX2, kFvalG, kCgP2, kCgS2, kCgX2, kCgS02,
-  kSpecGapY = 24, kSpecWY2, kSpecHY2,   // next iteration's y-half sums from the one-pass kernel
+  kGapX = 12, kWX2, kHX2, kDXprev2, kDX12, kExactS2, kPowX2, kPowXGx, kFvalG, kCgP2, kCgS2, kCgX2,
+  kSpecGapY = 26, kSpecWY2, kSpecHY2,   // next iteration's y-half sums from the one-pass kernel
   kNumSlots = 32
 };
 
