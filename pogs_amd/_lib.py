@@ -58,7 +58,9 @@ class PogsAmdStats(ctypes.Structure):
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d["spec_hits"], d["spec_misses"] = self.reserved[0], self.reserved[1]
+        return d
 
 
 def _dense_sig(real):

@@ -284,6 +284,7 @@ int PogsAmdResetStats(PogsAmdSolver *s) {
     st.t_loop_s = 0; st.iterations = 0; st.exact_iters = 0; st.rho_updates = 0;
     st.cg_iters = 0; st.matvecs = 0;
     st.stream_ms = 0; st.stream_launches = 0; st.stream_bytes = 0;
+    st.reserved[0] = 0; st.reserved[1] = 0;
     return 0;
   });
 }

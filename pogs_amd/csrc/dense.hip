@@ -732,8 +732,11 @@ class DenseSolver final : public SolverBase {
     // (D) the pass over A
     {
       StreamArgs2<T> a2{A_.p, lda_, m_, n_pad_, x_[nw].p, x12_.p, colpart_.p, colpart2_.p, ctx_.spart.p};
-      FusedIterOp<T> op{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, fview(), ctl_.rho, ctl_.alpha(), y12s_.p,
-                        ytemps_.p};
+      // speculate on the rho the adaptive rule is expected to choose (the previous
+      // iteration's residuals stand in for this one's)
+      ctl_.predict(&rho_pred_, &zs_pred_);
+      FusedIterOp<T> op{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, fview(), rho_pred_, ctl_.alpha(), zs_pred_,
+                        y12s_.p, ytemps_.p};
       ctx_.stream_timer.begin(s);
       launch_stream2<T, 2, 2>(planA_, a2, op, s);
       ctx_.stream_timer.end(s);
@@ -761,14 +764,15 @@ class DenseSolver final : public SolverBase {
     std::swap(xt_, xtemp_);
     std::swap(yt_, ytemp_);            // yt = ytilde_{k+1}
     cur_ = nw;
-    const T rho_before = ctl_.rho;
     zt_scale_ = ctl_.adapt();
-    if (ctl_.rho == rho_before && zt_scale_ == static_cast<T>(1)) {
+    if (ctl_.rho == rho_pred_ && zt_scale_ == zs_pred_) {
       std::swap(ytemp_, ytemps_);      // ytemp = speculative yhat_{k+1}
       std::swap(y12_, y12s_);          // y12 = speculative y12_{k+1}
       spec_valid_ = true;
+      ctx_.stats.reserved[0] += 1;     // speculation hits
     } else {
       spec_valid_ = false;
+      ctx_.stats.reserved[1] += 1;     // misses
     }
     ++ctl_.k;
     return false;
@@ -814,6 +818,7 @@ class DenseSolver final : public SolverBase {
   StreamPlan planA_, planW_;
   DevBuf<T> A_, W_, U_, d_, e_, colpart_, colpart2_, pair_, y12s_, ytemps_;
   bool fused_ok_ = false, fused_now_ = false, spec_valid_ = false;
+  T rho_pred_ = 1, zs_pred_ = 1;
   DevBuf<T> x_[2], y_[2], xt_, yt_, xtemp_, ytemp_, x12_, y12_, rhs_, tvec_, tmpn_;
   DevBuf<T> xout_, yout_, lout_, muout_;
   FnBuf<T> f_, g_, fs_, gs_;

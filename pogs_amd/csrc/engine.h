@@ -252,6 +252,14 @@ struct AdmmControl {
     prev_nrm_r = nrm_r;
     return scale;
   }
+  // What adapt() would do at this iteration if the residuals equalled the previous
+  // iteration's (they drift slowly): returns the predicted (rho, zt scale) without
+  // touching the state.  Used to speculate across a rho change (dense.hip).
+  void predict(T *rho_out, T *scale_out) const {
+    AdmmControl<T> c = *this;   // nrm_r, nrm_s, eps_* still hold the previous iteration's values
+    *scale_out = c.adapt();
+    *rho_out = c.rho;
+  }
   int status() const {
     if (!converged && k == max_iter - 1) return POGS_MAX_ITER;
     if (!converged) return POGS_NAN_FOUND;

@@ -103,8 +103,10 @@ template <typename T, bool A_KMAJ, bool B_KMAJ, bool LOWER>
 __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
   using V = typename Vec16<T>::type;
   using Acc = typename Mma<T>::Acc;
-  __shared__ __attribute__((aligned(16))) T sA[BK * LS];
-  __shared__ __attribute__((aligned(16))) T sB[BK * LS];
+  // two LDS stages per operand: the next k-tile is written while the current one is read,
+  // one barrier per k-tile
+  __shared__ __attribute__((aligned(16))) T sA[2][BK * LS];
+  __shared__ __attribute__((aligned(16))) T sB[2][BK * LS];
 
   // XCD-aware unit order: workgroup b runs on XCD b % 8 (observed dispatch order); give each
   // XCD a contiguous range of units so neighbouring tiles (shared operand panels, same K
@@ -148,10 +150,11 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
   const int nk = (kend - kbeg + BK - 1) / BK;
   load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg, g.M, kend, ra);
   load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg, g.N, kend, rb);
-  store_tile<T, A_KMAJ>(sA, ra);
-  store_tile<T, B_KMAJ>(sB, rb);
+  store_tile<T, A_KMAJ>(sA[0], ra);
+  store_tile<T, B_KMAJ>(sB[0], rb);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
     if (kt + 1 < nk) {
       load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg + (kt + 1) * BK, g.M, kend, ra);
       load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg + (kt + 1) * BK, g.N, kend, rb);
@@ -159,8 +162,8 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
       T af[4], bf[4];
-      const T *pa = sA + (ks * 4 + lk) * LS + wm + l15;
-      const T *pb = sB + (ks * 4 + lk) * LS + wn + l15;
+      const T *pa = sA[cur] + (ks * 4 + lk) * LS + wm + l15;
+      const T *pb = sB[cur] + (ks * 4 + lk) * LS + wn + l15;
 #pragma unroll
       for (int a = 0; a < 4; ++a) af[a] = pa[a * 16];
 #pragma unroll
@@ -170,12 +173,11 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = Mma<T>::mma(af[a], bf[b], acc[a][b]);
     }
-    __syncthreads();
     if (kt + 1 < nk) {
-      store_tile<T, A_KMAJ>(sA, ra);
-      store_tile<T, B_KMAJ>(sB, rb);
-      __syncthreads();
+      store_tile<T, A_KMAJ>(sA[cur ^ 1], ra);
+      store_tile<T, B_KMAJ>(sB[cur ^ 1], rb);
     }
+    __syncthreads();
   }
 
 #pragma unroll

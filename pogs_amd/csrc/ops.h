@@ -213,7 +213,8 @@ struct FusedIterOp {
   const T *ycur, *y12;
   T *ytemp;        // in: yhat_k, out: ytilde_{k+1}
   FnView<T> f;     // scaled f
-  T rho, alpha;
+  T rho, alpha;    // rho: the PREDICTED rho of iteration k+1
+  T zs;            // predicted lazy scale of ytilde_{k+1} (rho_k / rho_{k+1})
   T *y12s, *ytemps;  // speculative y12_{k+1}, yhat_{k+1}
   __device__ __forceinline__ Pre prefetch(int i) const {
     Pre p;
@@ -233,17 +234,18 @@ struct FusedIterOp {
     s[2] += static_cast<double>(r) * r;
     const T ztn = p.ytemp - yn;
     ytemp[i] = ztn;
-    const T v = yn - ztn;
+    const T zts = zs * ztn;
+    const T v = yn - zts;
     const T h = dev::ProxEvalCheap(p.h, p.a, p.b, p.c, p.d, p.e, v, rho);
     const T w = v - h;
     y12s[i] = h;
-    const T yh = ztn + alpha * h + (static_cast<T>(1) - alpha) * yn;
+    const T yh = zts + alpha * h + (static_cast<T>(1) - alpha) * yn;
     ytemps[i] = yh;
     s[3] += static_cast<double>(w) * h;
     s[4] += static_cast<double>(w) * w;
     s[5] += static_cast<double>(h) * h;
     u[0] = yh;
-    u[1] = h + ztn - yn;
+    u[1] = h + zts - yn;
   }
   template <int NA>
   __device__ __forceinline__ void uonly(int, T (&)[NA]) const {}

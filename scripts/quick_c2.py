@@ -30,7 +30,7 @@ st = s.stats()
 print(json.dumps({"create_s": t1 - t0, "solve_s": t2 - t1, "status": r["status"], "iters": r["iterations"],
                   "optval": r["optval"], **st}, indent=1))
 it = st["iterations"]
-print("it/s", it / st["t_loop_s"], "ms/iter", 1e3 * st["t_loop_s"] / it)
+print("it/s", it / st["t_loop_s"], "ms/iter", 1e3 * st["t_loop_s"] / it, "spec hits/misses", st.get("spec_hits"), st.get("spec_misses"))
 if st["stream_launches"]:
     avg = st["stream_ms"] / st["stream_launches"]
     print("stream kernel avg ms", avg, "GB/s", st["stream_bytes"] / st["stream_launches"] / (avg * 1e-3) / 1e9)
