@@ -151,9 +151,10 @@ def pmc_traffic(m, n):
         return None
     try:
         d = json.load(open(path))
-        v = [e["hbm_bytes_per_launch_corrected"] for k, e in d.items()
-             if "stream_rows_kernel<float" in k and ("GemvTOp" in k or "false, 0, ProjTailOp" in k)]
-        return sum(v) / len(v) if v else None
+        # launch-weighted mean over the kernels that stream A inside the ADMM loop
+        sel = [e for k, e in d.items() if "stream_rows2_kernel<float" in k]
+        n = sum(e["launches"] for e in sel)
+        return sum(e["hbm_bytes_per_launch_corrected"] * e["launches"] for e in sel) / n if n else None
     except Exception:
         return None
 
@@ -236,7 +237,7 @@ def main():
                        "parallelism": "row-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(m, n),
-                         "kernel": "stream_rows_kernel (pass over A)", "bytes_per_launch": bytes_per_launch,
+                         "kernel": "stream_rows2_kernel<FusedIterOp> (the one pass over A per iteration)", "bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": avg_ms, "launches": st["stream_launches"],
                          "iteration_frac": iter_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS},
             "time_to_converge_s": init_s + solve_s, "init_s": init_s, "loop_s": st_solve["t_loop_s"],
