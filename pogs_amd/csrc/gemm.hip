@@ -146,39 +146,46 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[a][b][r] = 0;
 
-  V ra[TileVec<T>::NVT], rb[TileVec<T>::NVT];
-  const int nk = (kend - kbeg + BK - 1) / BK;
-  load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg, g.M, kend, ra);
-  load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg, g.N, kend, rb);
-  store_tile<T, A_KMAJ>(sA[0], ra);
-  store_tile<T, B_KMAJ>(sB[0], rb);
+  // Two register stages + two LDS stages: the global loads of k-tile t+2 are issued two
+  // compute phases before they are written to LDS.  The k-tile count is rounded up to an
+  // even number (load_tile zero-fills past kend), which keeps the loop body branch-free.
+  V ra0[TileVec<T>::NVT], rb0[TileVec<T>::NVT], ra1[TileVec<T>::NVT], rb1[TileVec<T>::NVT];
+  const int nk = ((kend - kbeg + BK - 1) / BK + 1) & ~1;
+#define POGS_GEMM_COMPUTE(CA, CB)                                                        \
+  _Pragma("unroll") for (int ks = 0; ks < BK / 4; ++ks) {                                \
+    T af[4], bf[4];                                                                      \
+    const T *pa = (CA) + (ks * 4 + lk) * LS + wm + l15;                                  \
+    const T *pb = (CB) + (ks * 4 + lk) * LS + wn + l15;                                  \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) af[a] = pa[a * 16];                    \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) bf[b] = pb[b * 16];                    \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                        \
+      _Pragma("unroll") for (int b = 0; b < 4; ++b)                                      \
+        acc[a][b] = Mma<T>::mma(af[a], bf[b], acc[a][b]);                                \
+  }
+  load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg, g.M, kend, ra0);
+  load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg, g.N, kend, rb0);
+  store_tile<T, A_KMAJ>(sA[0], ra0);
+  store_tile<T, B_KMAJ>(sB[0], rb0);
+  load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg + BK, g.M, kend, ra0);
+  load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg + BK, g.N, kend, rb0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg + (kt + 1) * BK, g.M, kend, ra);
-      load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg + (kt + 1) * BK, g.N, kend, rb);
-    }
-#pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      T af[4], bf[4];
-      const T *pa = sA[cur] + (ks * 4 + lk) * LS + wm + l15;
-      const T *pb = sB[cur] + (ks * 4 + lk) * LS + wn + l15;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) af[a] = pa[a * 16];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) bf[b] = pb[b * 16];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = Mma<T>::mma(af[a], bf[b], acc[a][b]);
-    }
-    if (kt + 1 < nk) {
-      store_tile<T, A_KMAJ>(sA[cur ^ 1], ra);
-      store_tile<T, B_KMAJ>(sB[cur ^ 1], rb);
-    }
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even phase: LDS[0] = tile kt, stage 0 = tile kt+1 (in flight), request tile kt+2
+    load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg + (kt + 2) * BK, g.M, kend, ra1);
+    load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg + (kt + 2) * BK, g.N, kend, rb1);
+    POGS_GEMM_COMPUTE(sA[0], sB[0])
+    store_tile<T, A_KMAJ>(sA[1], ra0);
+    store_tile<T, B_KMAJ>(sB[1], rb0);
+    __syncthreads();
+    // odd phase: LDS[1] = tile kt+1, stage 1 = tile kt+2 (in flight), request tile kt+3
+    load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg + (kt + 3) * BK, g.M, kend, ra0);
+    load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg + (kt + 3) * BK, g.N, kend, rb0);
+    POGS_GEMM_COMPUTE(sA[1], sB[1])
+    store_tile<T, A_KMAJ>(sA[0], ra1);
+    store_tile<T, B_KMAJ>(sB[0], rb1);
     __syncthreads();
   }
+#undef POGS_GEMM_COMPUTE
 
 #pragma unroll
   for (int a = 0; a < 4; ++a)
