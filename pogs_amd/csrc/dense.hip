@@ -16,7 +16,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <limits>
 
+#include "cg_kernels.h"
 #include "engine.h"
 #include "gemm.h"
 #include "ops.h"
@@ -95,6 +97,10 @@ class DenseSolver final : public SolverBase {
     multi_ = ctx_.dist.active();
     tall_ = ctx_.m_global > n;   // projector_direct_dense.cpp:53,122,128
     POGS_CHECK(tall_ || !multi_, "row sharding needs m > n (SURVEY.md section 8(e))");
+    // dense + CGLS: instantiated by the reference (pogs.cpp:1983-1984) but not reachable from
+    // its C ABI; offered here as an option (no Gram / factorisation, any shape)
+    use_cgls_ = opt && opt->projector == POGS_AMD_PROJ_CGLS;
+    POGS_CHECK(!(use_cgls_ && multi_), "the CGLS projector is single-GPU");
     constexpr int VEC = Vec16<T>::N;
     n_pad_ = static_cast<int>(round_up(n, VEC));
     k_ = tall_ ? n_ : m_;
@@ -106,8 +112,8 @@ class DenseSolver final : public SolverBase {
     ctx_.stats.t_h2d_s = wall_s() - t0;
     alloc_state();
     equilibrate();
-    if (!tall_) norm_est();   // m > n: estimated from the Gram matrix inside factor()
-    factor();
+    if (!tall_ || use_cgls_) norm_est();   // direct, m > n: estimated from the Gram matrix inside factor()
+    if (!use_cgls_) factor();
     ctx_.sync();
     ctx_.stats.t_init_s = wall_s() - t0;
   }
@@ -180,11 +186,17 @@ class DenseSolver final : public SolverBase {
   }
 
   // (x, y) = Proj_{y = A x}(x0, y0), projector_direct_dense.cpp:122-127.
-  void project(const void *x0, const void *y0, double, void *x, void *y) override {
+  void project(const void *x0, const void *y0, double tol, void *x, void *y) override {
     hipStream_t s = ctx_.stream;
     POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, x0, n_ * sizeof(T), hipMemcpyHostToDevice, s));
     POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, y0, m_ * sizeof(T), hipMemcpyHostToDevice, s));
-    if (tall_) {
+    if (use_cgls_) {
+      x_[0].zero(s);
+      cgls_project(xtemp_.p, ytemp_.p, x_[0].p, static_cast<T>(tol), nullptr);
+      StreamArgs<T> a = argsA();
+      a.xin = x_[0].p;
+      launch_stream<T, true, false, false, kFull>(planA_, a, GemvNOp<T>{1, 0, y_[0].p}, s);
+    } else if (tall_) {
       gemv_t_partials(ytemp_.p);
       finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, 0, 0);
       solve_gram(rhs_.p, xtemp_.p, GemvNOp<T>{1, 0, x_[0].p}, nullptr);
@@ -272,8 +284,12 @@ class DenseSolver final : public SolverBase {
     xout_.alloc(np); yout_.alloc(m_); lout_.alloc(m_); muout_.alloc(np);
     f_.alloc(m_); g_.alloc(n_); fs_.alloc(m_); gs_.alloc(n_);
     colpart_.alloc(static_cast<size_t>(planA_.grid_max) * np);
+    if (use_cgls_) {
+      cg_p_.alloc(np); cg_s_.alloc(np); cg_q_.alloc(m_); cg_r_.alloc(m_); cg_.alloc(kCgNumSlots);
+      cg_p_.zero(s); cg_s_.zero(s); cg_.zero(s);
+    }
     const char *fe = std::getenv("POGS_AMD_FUSED");
-    fused_ok_ = tall_ && stream2_supported(planA_) && !(fe && fe[0] == '0');
+    fused_ok_ = tall_ && !use_cgls_ && stream2_supported(planA_) && !(fe && fe[0] == '0');
     if (fused_ok_) {
       colpart2_.alloc(static_cast<size_t>(planA_.grid_max) * np);
       pair_.alloc(2 * np);
@@ -282,7 +298,7 @@ class DenseSolver final : public SolverBase {
       y12s_.zero(s); ytemps_.zero(s);
     }
     const size_t vb = vec_blocks(n_) + vec_blocks(m_);
-    ctx_.ensure_spart(std::max<size_t>(static_cast<size_t>(planA_.grid_max) * 6 + 4096, vb * 3 + 64));
+    ctx_.ensure_spart(static_cast<size_t>(planA_.grid_max) * 6 + std::max<size_t>(4096, vb * 3 + 64));
   }
 
   StreamArgs<T> argsA() const {
@@ -541,6 +557,71 @@ class DenseSolver final : public SolverBase {
     }
   }
 
+  // ProjectorCgls::Project on the dense operator up to (not including) the final y = A x
+  // (projector_cgls.cpp:59-75, cgls.h:200-323).  x: warm start in, projected x out.
+  // Ax_warm: A times the warm start if the caller has it (inside the ADMM loop it is the
+  // previous y), which replaces the two initial matrix passes by vector algebra.
+  void cgls_project(const T *x0, const T *y0, T *x, T tol, const T *Ax_warm) {
+    hipStream_t s = ctx_.stream;
+    const int bx = vec_blocks(n_);
+    const double shift = 1.0;
+    const double kEps = std::numeric_limits<T>::epsilon();
+    double *vp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;   // vector-kernel partials
+    auto sum_vp = [&](int blocks, double *out) {
+      SumJob j{vp, blocks, 1, out};
+      launch_sum_jobs(&j, 1, s);
+    };
+    auto pass_n = [&](const T *xin, auto op, double *out, int ns) {   // DOT pass over A
+      StreamArgs<T> a = argsA();
+      a.xin = xin;
+      ctx_.stream_timer.begin(s);
+      launch_stream<T, true, false, false, kFull>(planA_, a, op, s);
+      ctx_.stream_timer.end(s);
+      if (ns > 0) sum_row_scalars(stream_grid<true, false>(planA_, m_), ns, out);
+      ctx_.stats.matvecs += 1;
+    };
+    auto pass_t = [&](const T *rin) {   // s = A^T r - shift x, |s|^2
+      gemv_t_partials(rin);
+      finish_cols(CgSColOp<T>{x, static_cast<T>(shift), cg_s_.p, n_}, ctx_.S.p + kCgS2, 0, 0);
+      ctx_.stats.matvecs += 1;
+    };
+    if (Ax_warm) {
+      hipLaunchKernelGGL(sub_norm_kernel<T>, dim3(vec_blocks(m_)), dim3(kVecTpb), 0, s, m_, y0, Ax_warm, cg_r_.p, vp);
+      hipLaunchKernelGGL(sub_norm_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, x, x0, x, vp);
+    } else {
+      hipLaunchKernelGGL(sub_norm_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, x, x0, x, vp);
+      sum_vp(bx, ctx_.S.p + kCgX2);
+      pass_n(x0, SubDotOp<T>{y0, cg_q_.p}, nullptr, 0);                 // b = y0 - A x0
+      const double *S0 = ctx_.fetch_scalars();
+      if (std::sqrt(S0[kCgX2]) > 0.0) pass_n(x, SubDotOp<T>{cg_q_.p, cg_r_.p}, nullptr, 0);   // r = b - A x
+      else POGS_HIP_CHECK(hipMemcpyAsync(cg_r_.p, cg_q_.p, m_ * sizeof(T), hipMemcpyDeviceToDevice, s));
+    }
+    pass_t(cg_r_.p);
+    hipLaunchKernelGGL(set_gamma_kernel, dim3(1), dim3(1), 0, s, ctx_.S.p, cg_.p);
+    hipLaunchKernelGGL(cg_update_p_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, cg_.p, cg_s_.p, cg_p_.p, vp, true);
+    sum_vp(bx, ctx_.S.p + kCgP2);
+    const double *S = ctx_.fetch_scalars();
+    const double norms0 = std::sqrt(S[kCgS2]);
+    const int maxit = (norms0 < kEps) ? 0 : 500;
+    for (int k = 0; k < maxit; ++k) {
+      pass_n(cg_p_.p, CgQRowOp<T>{cg_q_.p}, ctx_.S.p + kCgQ2, 1);     // q = A p
+      hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(1), 0, s, ctx_.S.p, cg_.p, shift, kEps);
+      const int bm = vec_blocks(m_);
+      hipLaunchKernelGGL(cg_update_xr_kernel<T>, dim3(bx + bm), dim3(kVecTpb), 0, s, n_, m_, cg_.p, cg_p_.p, x,
+                         cg_q_.p, cg_r_.p, vp, bx);
+      sum_vp(bx, ctx_.S.p + kCgX2);
+      pass_t(cg_r_.p);
+      hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(1), 0, s, ctx_.S.p, cg_.p);
+      hipLaunchKernelGGL(cg_update_p_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, cg_.p, cg_s_.p, cg_p_.p, vp, false);
+      sum_vp(bx, ctx_.S.p + kCgP2);
+      S = ctx_.fetch_scalars();
+      const double norms = std::sqrt(S[kCgS2]), normx = std::sqrt(S[kCgX2]);
+      ++ctx_.stats.cg_iters;
+      if ((norms <= norms0 * static_cast<double>(tol)) || (normx * static_cast<double>(tol) >= 1.0)) break;
+    }
+    launch_axpby<T>(n_, static_cast<T>(1), x0, static_cast<T>(1), x, s);   // x += x0
+  }
+
   // ---- per-solve -----------------------------------------------------------
   void load_problem(const FnHost &f, const FnHost &g, const SolveParams &p) {
     hipStream_t s = ctx_.stream;
@@ -608,7 +689,23 @@ class DenseSolver final : public SolverBase {
                      {ctx_.spart.p + static_cast<size_t>(pa.blocks_x) * 3, vec_blocks(m_), 3, ctx_.S.p + kGapY}};
       launch_sum_jobs(j, 2, s);
     }
-    if (tall_) {
+    if (use_cgls_) {
+      // (2c) CGLS projector (projector_cgls.cpp:52-88), warm-started with the previous x (pogs.cpp:281)
+      POGS_HIP_CHECK(hipMemcpyAsync(x_[nw].p, x_[cur_].p, n_ * sizeof(T), hipMemcpyDeviceToDevice, s));
+      cgls_project(xtemp_.p, ytemp_.p, x_[nw].p, ctl_.proj_tol(), y_[cur_].p);
+      StreamArgs<T> a = argsA();
+      a.xin = x_[nw].p;
+      ctx_.stream_timer.begin(s);
+      launch_stream<T, true, false, false, kFull>(planA_, a,
+                                                  ProjTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p}, s);
+      ctx_.stream_timer.end(s);
+      sum_row_scalars(stream_grid<true, false>(planA_, m_), 2, ctx_.S.p + kDYprev2);
+      double *sp2 = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
+      launch_admm_tail<T>(n_, x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, sp2, s);
+      SumJob jt{sp2, vec_blocks(n_), 2, ctx_.S.p + kDXprev2};
+      launch_sum_jobs(&jt, 1, s);
+      ctx_.stats.matvecs += 1;
+    } else if (tall_) {
       // (2) projection: x = (G + I)^{-1} (xtemp + A^T ytemp), y = A x   (projector_direct_dense.cpp:122-127)
       gemv_t_partials(ytemp_.p);
       finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, kGapY, 3);   // with shards: gap/norm sums ride along
@@ -633,7 +730,7 @@ class DenseSolver final : public SolverBase {
       gemv_t_partials(tmpn_.p);
       finish_cols(ProjTailColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_}, ctx_.S.p + kDXprev2, 0, 0);
     }
-    ctx_.stats.matvecs += 2;
+    if (!use_cgls_) ctx_.stats.matvecs += 2;
     const double *S = ctx_.fetch_scalars();
     ctl_.set_pre(S);
     bool exact = false;
@@ -813,7 +910,9 @@ class DenseSolver final : public SolverBase {
 
   Ctx ctx_;
   int m_ = 0, n_ = 0, n_pad_ = 0, k_ = 0, k_pad_ = 0;
-  bool tall_ = true, multi_ = false;
+  bool tall_ = true, multi_ = false, use_cgls_ = false;
+  DevBuf<T> cg_p_, cg_s_, cg_q_, cg_r_;
+  DevBuf<double> cg_;
   size_t lda_ = 0;
   StreamPlan planA_, planW_;
   DevBuf<T> A_, W_, U_, d_, e_, colpart_, colpart2_, pair_, y12s_, ytemps_;

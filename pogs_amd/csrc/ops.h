@@ -175,6 +175,35 @@ struct SymRowOp {
   __device__ __forceinline__ T u(int) const { return 0; }
 };
 
+// CGLS on a dense operator: q_i = (A p)_i, accumulates |q|^2 (cgls.h:257-263).
+template <typename T>
+struct CgQRowOp {
+  static constexpr int NS = 1;
+  T *q;
+  template <int N>
+  __device__ __forceinline__ T row(int i, T dot, double (&s)[N]) const {
+    q[i] = dot;
+    s[0] += static_cast<double>(dot) * dot;
+    return dot;
+  }
+  __device__ __forceinline__ T u(int) const { return 0; }
+};
+
+// out_i = yin_i - dot   (b = y0 - A x0, r = b - A x; projector_cgls.cpp:68, cgls.h:229-233)
+template <typename T>
+struct SubDotOp {
+  static constexpr int NS = 0;
+  const T *yin;
+  T *out;
+  template <int N>
+  __device__ __forceinline__ T row(int i, T dot, double (&)[N]) const {
+    const T v = yin[i] - dot;
+    out[i] = v;
+    return v;
+  }
+  __device__ __forceinline__ T u(int) const { return 0; }
+};
+
 // ---- functors of the one-pass iteration (stream_rows2_kernel) ---------------
 
 // Column-sum-only pass before the projection when the previous pass could not
@@ -351,6 +380,26 @@ struct SymColOp {
       s[1] += static_cast<double>(x[j] * sc) * v;
     } else {
       xnext[j] = 0;
+    }
+  }
+};
+
+// CGLS: s_j = (A^T r)_j - shift * x_j, accumulates |s|^2 (cgls.h:281-285).
+template <typename T>
+struct CgSColOp {
+  static constexpr int NS = 1;
+  const T *x;
+  T shift;
+  T *sout;
+  int n;
+  template <int N>
+  __device__ __forceinline__ void col(int j, T total, double (&s)[N]) const {
+    if (j < n) {
+      const T v = total - shift * x[j];
+      sout[j] = v;
+      s[0] += static_cast<double>(v) * v;
+    } else {
+      sout[j] = 0;
     }
   }
 };

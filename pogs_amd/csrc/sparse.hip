@@ -20,6 +20,7 @@
 #include <limits>
 #include <vector>
 
+#include "cg_kernels.h"
 #include "engine.h"
 #include "reduce.h"
 #include "vec_kernels.h"
@@ -325,83 +326,6 @@ __global__ void __launch_bounds__(256) scale_csr_kernel(T *val, const int *ind, 
   if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
 
-// ---------------------------------------------------------------------------
-// CGLS vector kernels (cgls.h:255-306); scalars live in a small device block
-// ---------------------------------------------------------------------------
-enum CgSlot : int { kCgGamma = 0, kCgAlpha, kCgBeta, kCgDelta, kCgIndef, kCgNumSlots = 8 };
-
-// alpha = gamma / (|q|^2 + shift |p|^2)   (cgls.h:262-271)
-__global__ void cg_alpha_kernel(double *S, double *cg, double shift, double eps) {
-  const double normq2 = S[kCgQ2], normp2 = S[kCgP2];
-  double delta = normq2 + shift * normp2;
-  if (delta <= 0.0) cg[kCgIndef] = 1.0;
-  if (delta == 0.0) delta = eps;
-  cg[kCgDelta] = delta;
-  cg[kCgAlpha] = cg[kCgGamma] / delta;
-}
-// beta = |s|^2 / gamma_prev; gamma = |s|^2   (cgls.h:288-292)
-__global__ void cg_beta_kernel(double *S, double *cg) {
-  const double g1 = cg[kCgGamma];
-  const double g = S[kCgS2];
-  cg[kCgGamma] = g;
-  cg[kCgBeta] = g / g1;
-}
-
-// x += alpha p (n);  r -= alpha q (m);  partial |x|^2      (cgls.h:274-277, 298)
-template <typename T>
-__global__ void __launch_bounds__(kVecTpb) cg_update_xr_kernel(int n, int m, const double *cg, const T *p, T *x,
-                                                               const T *q, T *r, double *partials, int blocks_x) {
-  __shared__ double s_red[kVecTpb / 64];
-  const T alpha = static_cast<T>(cg[kCgAlpha]);
-  const T neg_alpha = static_cast<T>(-cg[kCgAlpha]);
-  double acc[1] = {0.0};
-  if (static_cast<int>(blockIdx.x) < blocks_x) {
-    const int i = blockIdx.x * kVecTpb + threadIdx.x;
-    if (i < n) {
-      const T v = x[i] + alpha * p[i];
-      x[i] = v;
-      acc[0] = static_cast<double>(v) * v;
-    }
-  } else {
-    const int i = (blockIdx.x - blocks_x) * kVecTpb + threadIdx.x;
-    if (i < m) r[i] += neg_alpha * q[i];
-  }
-  dev::block_sum<1, kVecTpb>(acc, s_red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
-}
-
-// p = s + beta p; partial |p|^2      (cgls.h:295-296)
-template <typename T>
-__global__ void __launch_bounds__(kVecTpb) cg_update_p_kernel(int n, const double *cg, const T *s, T *p,
-                                                              double *partials, bool first) {
-  __shared__ double s_red[kVecTpb / 64];
-  const T beta = first ? static_cast<T>(0) : static_cast<T>(cg[kCgBeta]);
-  const int i = blockIdx.x * kVecTpb + threadIdx.x;
-  double acc[1] = {0.0};
-  if (i < n) {
-    const T v = first ? s[i] : s[i] + beta * p[i];
-    p[i] = v;
-    acc[0] = static_cast<double>(v) * v;
-  }
-  dev::block_sum<1, kVecTpb>(acc, s_red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
-}
-
-// out = a - b, partial |out|^2
-template <typename T>
-__global__ void __launch_bounds__(kVecTpb) sub_norm_kernel(int n, const T *a, const T *b, T *out, double *partials) {
-  __shared__ double s_red[kVecTpb / 64];
-  const int i = blockIdx.x * kVecTpb + threadIdx.x;
-  double acc[1] = {0.0};
-  if (i < n) {
-    const T v = a[i] - b[i];
-    out[i] = v;
-    acc[0] = static_cast<double>(v) * v;
-  }
-  dev::block_sum<1, kVecTpb>(acc, s_red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
-}
-
 // u = y12 + c yt - yprev   (pogs.cpp:366-368, y half)
 template <typename T>
 __global__ void exact_u_kernel(int m, const T *y12, const T *yt, const T *yprev, T c, T *u) {
@@ -409,10 +333,6 @@ __global__ void exact_u_kernel(int m, const T *y12, const T *yt, const T *yprev,
   if (i < m) u[i] = y12[i] + c * yt[i] - yprev[i];
 }
 
-__global__ void set_gamma_kernel(const double *S, double *cg) {
-  cg[kCgGamma] = S[kCgS2];
-  cg[kCgIndef] = 0.0;
-}
 
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -751,25 +671,38 @@ class SparseSolver final : public SolverBase {
   // ProjectorCgls::Project up to (not including) the final y = A x
   // (projector_cgls.cpp:59-75): x holds the warm start on entry, the projected x
   // on exit.
-  void cgls_project(const T *x0, const T *y0, T *x, T tol) {
+  // `Ax_warm` (optional): A times the warm-start x, if the caller already has it.  The
+  // reference forms b = y0 - A x0 and r = b - A (x - x0) with two SpMVs (:65-68,
+  // cgls.h:226-233); their sum is r = y0 - A x_warm, and inside the ADMM loop A x_warm is the
+  // previous iteration's y (the projection always ends with y = A x), so both SpMVs vanish.
+  void cgls_project(const T *x0, const T *y0, T *x, T tol, const T *Ax_warm = nullptr) {
     hipStream_t s = ctx_.stream;
     const int bx = vec_blocks(n_);
     const double shift = 1.0;
     const double kEps = std::numeric_limits<T>::epsilon();
-    // x <- x - x0, |x|^2                                                      (:62)
-    hipLaunchKernelGGL(sub_norm_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, x, x0, x, ctx_.spart.p);
-    sum_vec_partials(bx, ctx_.S.p + kCgX2);
-    // b = y0 - A x0                                                           (:65-68)
-    spmv<false>(A_, x0, nullptr, SpAxpbyOp<T>{static_cast<T>(-1), static_cast<T>(1), y0, cg_b_.p}, nullptr, 0, true);
-    const double *S = ctx_.fetch_scalars();
-    double normx = std::sqrt(S[kCgX2]);
-    // r = b - A x (only if x != 0)                                            (cgls.h:226-233)
-    if (normx > 0.0) {
-      spmv<false>(A_, x, nullptr, SpAxpbyOp<T>{static_cast<T>(-1), static_cast<T>(1), cg_b_.p, cg_r_.p}, nullptr, 0,
-                  true);
+    if (Ax_warm) {
+      // r = y0 - A x_warm ; x <- x - x0                                       (:62)
+      hipLaunchKernelGGL(sub_norm_kernel<T>, dim3(vec_blocks(m_)), dim3(kVecTpb), 0, s, m_, y0, Ax_warm, cg_r_.p,
+                         ctx_.spart.p);
+      hipLaunchKernelGGL(sub_norm_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, x, x0, x, ctx_.spart.p);
     } else {
-      POGS_HIP_CHECK(hipMemcpyAsync(cg_r_.p, cg_b_.p, m_ * sizeof(T), hipMemcpyDeviceToDevice, s));
+      // x <- x - x0, |x|^2                                                    (:62)
+      hipLaunchKernelGGL(sub_norm_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, x, x0, x, ctx_.spart.p);
+      sum_vec_partials(bx, ctx_.S.p + kCgX2);
+      // b = y0 - A x0                                                         (:65-68)
+      spmv<false>(A_, x0, nullptr, SpAxpbyOp<T>{static_cast<T>(-1), static_cast<T>(1), y0, cg_b_.p}, nullptr, 0,
+                  true);
+      const double *S0 = ctx_.fetch_scalars();
+      // r = b - A x (only if x != 0)                                          (cgls.h:226-233)
+      if (std::sqrt(S0[kCgX2]) > 0.0) {
+        spmv<false>(A_, x, nullptr, SpAxpbyOp<T>{static_cast<T>(-1), static_cast<T>(1), cg_b_.p, cg_r_.p}, nullptr,
+                    0, true);
+      } else {
+        POGS_HIP_CHECK(hipMemcpyAsync(cg_r_.p, cg_b_.p, m_ * sizeof(T), hipMemcpyDeviceToDevice, s));
+      }
     }
+    const double *S;
+    double normx;
     // s = A^T r - shift x ; p = s ; gamma = |s|^2                             (cgls.h:236-245)
     spmv<false>(At_, cg_r_.p, nullptr, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, ctx_.S.p + kCgS2, 0,
                 true);
@@ -830,7 +763,7 @@ class SparseSolver final : public SolverBase {
     }
     // warm start with the previous x (pogs.cpp:281), then CGLS
     POGS_HIP_CHECK(hipMemcpyAsync(x_[nw].p, x_[cur_].p, n_ * sizeof(T), hipMemcpyDeviceToDevice, s));
-    cgls_project(xtemp_.p, ytemp_.p, x_[nw].p, ctl_.proj_tol());
+    cgls_project(xtemp_.p, ytemp_.p, x_[nw].p, ctl_.proj_tol(), y_[cur_].p);   // y_cur == A x_cur
     // y = A x fused with the y-half bookkeeping; x-half element-wise        (projector_cgls.cpp:78)
     spmv<false>(A_, x_[nw].p, nullptr, SpTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p}, ctx_.S.p + kDYprev2, 0,
                 true);
