@@ -10,12 +10,11 @@
 
 namespace pogs_amd {
 
-// Device scalar block layout (doubles).  The first kNumYSlots entries are sums
-// over rows (y-sized data): on a row-sharded solve they are all-reduced as one
-// contiguous message.  The rest are sums over columns (replicated).
+// Device scalar block layout (doubles).  The first group holds sums over rows
+// (y-sized data): on a row-sharded solve the ones in use are all-reduced (contiguous
+// ranges).  The second group holds sums over columns (replicated data).
 enum Slot : int {
-  kGapY = 0, kWY2, kHY2, kDYprev2, kDY12, kExactR2, kPowSx2, kFro2, kFvalF, kCgQ2, kCgR2,
-  kNumYSlots = 12,
+  kGapY = 0, kWY2, kHY2, kDYprev2, kDY12, kExactR2, kPowSx2, kFro2, kFvalF, kCgQ2,
   kGapX = 12, kWX2, kHX2, kDXprev2, kDX12, kExactS2, kPowX2, kPowXGx, kFvalG, kCgP2, kCgS2, kCgX2,
   kSpecGapY = 26, kSpecWY2, kSpecHY2,   // next iteration's y-half sums from the one-pass kernel
   kNumSlots = 32
@@ -98,11 +97,5 @@ template <typename T> void launch_sqrt_inplace(T *p, size_t n, hipStream_t s);
 template <typename T> void launch_scal(T *p, T alpha, size_t n, hipStream_t s);
 // y = a*x + b*y
 template <typename T> void launch_axpby(size_t n, T a, const T *x, T b, T *y, hipStream_t s);
-// partials[b] = sum (x_i)^2 over block b  (blocks = vec_blocks(n))
-template <typename T> void launch_sumsq(int n, const T *x, double *partials, hipStream_t s);
-// out = total + x12 + c*xt - xprev, partial sum of squares (exact dual residual, multi-GPU form)
-template <typename T>
-void launch_exact_s(int n, const T *total, const T *x12, const T *xt, const T *xprev, T zt_scale,
-                    double *partials, hipStream_t s);
 
 }  // namespace pogs_amd

@@ -151,29 +151,6 @@ __global__ void axpby_kernel(size_t n, T a, const T *x, T b, T *y) {
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) y[i] = (b == static_cast<T>(0)) ? a * x[i] : a * x[i] + b * y[i];
 }
-template <typename T>
-__global__ void __launch_bounds__(kVecTpb) sumsq_kernel(int n, const T *x, double *partials) {
-  __shared__ double s_red[kVecTpb / 64];
-  const int i = blockIdx.x * kVecTpb + threadIdx.x;
-  double acc[1] = {0.0};
-  if (i < n) acc[0] = static_cast<double>(x[i]) * x[i];
-  dev::block_sum<1, kVecTpb>(acc, s_red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
-}
-template <typename T>
-__global__ void __launch_bounds__(kVecTpb) exact_s_kernel(int n, const T *total, const T *x12, const T *xt,
-                                                          const T *xprev, T zt_scale, double *partials) {
-  __shared__ double s_red[kVecTpb / 64];
-  const int i = blockIdx.x * kVecTpb + threadIdx.x;
-  double acc[1] = {0.0};
-  if (i < n) {
-    const T v = total[i] + x12[i] + zt_scale * xt[i] - xprev[i];
-    acc[0] = static_cast<double>(v) * v;
-  }
-  dev::block_sum<1, kVecTpb>(acc, s_red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
-}
-
 inline dim3 grid1d(size_t n, int tpb = 256) { return dim3(static_cast<unsigned>((n + tpb - 1) / tpb)); }
 
 }  // namespace
@@ -239,17 +216,6 @@ template <typename T>
 void launch_axpby(size_t n, T a, const T *x, T b, T *y, hipStream_t s) {
   if (n) hipLaunchKernelGGL(axpby_kernel<T>, grid1d(n), dim3(256), 0, s, n, a, x, b, y);
 }
-template <typename T>
-void launch_sumsq(int n, const T *x, double *partials, hipStream_t s) {
-  hipLaunchKernelGGL(sumsq_kernel<T>, dim3(vec_blocks(n)), dim3(kVecTpb), 0, s, n, x, partials);
-}
-template <typename T>
-void launch_exact_s(int n, const T *total, const T *x12, const T *xt, const T *xprev, T zt_scale,
-                    double *partials, hipStream_t s) {
-  hipLaunchKernelGGL(exact_s_kernel<T>, dim3(vec_blocks(n)), dim3(kVecTpb), 0, s, n, total, x12, xt, xprev,
-                     zt_scale, partials);
-}
-
 #define POGS_INST(T)                                                                                     \
   template void launch_scale_objective<T>(FnView<T>, T *, T *, T *, T *, const T *, int, bool, hipStream_t); \
   template void launch_admm_pre<T>(const AdmmPreArgs<T> &, hipStream_t);                                 \
@@ -260,9 +226,7 @@ void launch_exact_s(int n, const T *total, const T *x12, const T *xt, const T *x
   template void launch_fill<T>(T *, T, size_t, hipStream_t);                                             \
   template void launch_sqrt_inplace<T>(T *, size_t, hipStream_t);                                        \
   template void launch_scal<T>(T *, T, size_t, hipStream_t);                                             \
-  template void launch_axpby<T>(size_t, T, const T *, T, T *, hipStream_t);                              \
-  template void launch_sumsq<T>(int, const T *, double *, hipStream_t);                                  \
-  template void launch_exact_s<T>(int, const T *, const T *, const T *, const T *, T, double *, hipStream_t);
+  template void launch_axpby<T>(size_t, T, const T *, T, T *, hipStream_t);
 POGS_INST(float)
 POGS_INST(double)
 #undef POGS_INST

@@ -402,3 +402,43 @@ def test_dense_cgls_projector_option(dtype, shape):
     assert relerr(got["x"], want["x"]) < _tol(dtype, 1e-5, 3e-4)
     assert got["optval"] == pytest.approx(want["optval"], rel=_tol(dtype, 1e-6, 2e-4))
     assert st["cg_iters"] > 0
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (5, 1), (3, 2), (2, 3), (65, 64), (64, 65), (257, 256), (1000, 999),
+                                   (40, 7), (4100, 2050)])
+def test_edge_shapes_fp64(shape):
+    """Tiny, nearly square, odd widths (padding to the 16-byte vector), both projector branches."""
+    pogs = _pogs()
+    m, n = shape
+    rng = np.random.default_rng(m * 1000 + n)
+    A = rng.standard_normal((m, n))
+    b = rng.standard_normal(m)
+    f, g = pogs.graph.lasso_functions(b, 0.05, n)
+    got = pogs._solve_graph_form(A, f, g)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float64)
+    assert got["status"] == want["status"]
+    assert abs(got["iterations"] - want["iterations"]) <= 2
+    assert np.linalg.norm(got["x"] - want["x"]) <= 1e-6 * max(np.linalg.norm(want["x"]), 1.0)
+    assert got["optval"] == pytest.approx(want["optval"], rel=1e-7, abs=1e-9)
+
+
+def test_wide_register_plan_fp32():
+    """n = 16500 > 16384: the 1024-thread plan (no one-pass kernel), m > n."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.dense_lasso(17000, 16500, seed=31, dtype=np.float32)
+    rng = np.random.default_rng(2)
+    x0, y0 = rng.standard_normal(16500), rng.standard_normal(17000)
+    with pogs.Solver(A, dtype=np.float32) as s:
+        x, y = s.project(x0, y0)
+        xx = rng.standard_normal(16500)
+        yy = s.mul("n", 1.0, xx, 0.0, np.zeros(17000))
+        xt = s.mul("t", 1.0, y0, 0.0, np.zeros(16500))
+        A_eq, _, _, _ = s.equilibrated()
+    A64 = A_eq.astype(np.float64)
+    assert relerr(yy, A64 @ xx) < 2e-5
+    assert relerr(xt, A64.T @ y0) < 2e-5
+    assert np.linalg.norm(A64 @ x.astype(np.float64) - y) / np.sqrt(17000) < 3e-4
+    kkt = A64.T @ (A64 @ x.astype(np.float64) - y0) + (x - x0)
+    assert np.linalg.norm(kkt) / np.sqrt(16500) < 3e-4
