@@ -636,8 +636,13 @@ class DenseSolver final : public SolverBase {
     up(f_, f, m_);
     up(g_, g, n_);
     // the one-pass kernel evaluates prox_f inline: only for the cheap base functions
-    fused_now_ = fused_ok_;
-    for (int i = 0; i < m_ && fused_now_; ++i) fused_now_ = is_cheap_prox(f.h[i]);
+    bool all_cheap = true, all_logistic = true;
+    for (int i = 0; i < m_; ++i) {
+      all_cheap = all_cheap && is_cheap_prox(f.h[i]);
+      all_logistic = all_logistic && f.h[i] == kLogistic;
+    }
+    fused_now_ = fused_ok_ && (all_cheap || all_logistic);
+    fused_logistic_ = fused_now_ && all_logistic && !all_cheap;
     // scaled copies: h and b shared with the originals (pogs.cpp:608-617)
     launch_scale_objective<T>(f_.view(), fs_.a.p, fs_.c.p, fs_.d.p, fs_.e.p, d_.p, m_, true, s);
     launch_scale_objective<T>(g_.view(), gs_.a.p, gs_.c.p, gs_.d.p, gs_.e.p, e_.p, n_, false, s);
@@ -832,10 +837,16 @@ class DenseSolver final : public SolverBase {
       // speculate on the rho the adaptive rule is expected to choose (the previous
       // iteration's residuals stand in for this one's)
       ctl_.predict(&rho_pred_, &zs_pred_);
-      FusedIterOp<T> op{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, fview(), rho_pred_, ctl_.alpha(), zs_pred_,
-                        y12s_.p, ytemps_.p};
       ctx_.stream_timer.begin(s);
-      launch_stream2<T, 2, 2>(planA_, a2, op, s);
+      if (fused_logistic_) {
+        FusedIterOp<T, true> op{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, fview(), rho_pred_, ctl_.alpha(), zs_pred_,
+                                y12s_.p, ytemps_.p};
+        launch_stream2<T, 2, 2>(planA_, a2, op, s);
+      } else {
+        FusedIterOp<T, false> op{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, fview(), rho_pred_, ctl_.alpha(), zs_pred_,
+                                 y12s_.p, ytemps_.p};
+        launch_stream2<T, 2, 2>(planA_, a2, op, s);
+      }
       ctx_.stream_timer.end(s);
       const int grid = stream2_grid<2>(planA_, m_);
       SumJob j[2] = {{ctx_.spart.p, grid, 3, ctx_.S.p + kDYprev2, 6, 0},
@@ -916,7 +927,7 @@ class DenseSolver final : public SolverBase {
   size_t lda_ = 0;
   StreamPlan planA_, planW_;
   DevBuf<T> A_, W_, U_, d_, e_, colpart_, colpart2_, pair_, y12s_, ytemps_;
-  bool fused_ok_ = false, fused_now_ = false, spec_valid_ = false;
+  bool fused_ok_ = false, fused_now_ = false, fused_logistic_ = false, spec_valid_ = false;
   T rho_pred_ = 1, zs_pred_ = 1;
   DevBuf<T> x_[2], y_[2], xt_, yt_, xtemp_, ytemp_, x12_, y12_, rhs_, tvec_, tmpn_;
   DevBuf<T> xout_, yout_, lout_, muout_;

@@ -231,7 +231,9 @@ struct PreAccOp {
 //   then, assuming rho stays, the y half of iteration k+1's prox / gap sums /
 //   over-relaxation (pogs.cpp:257-278) and the two column-sum inputs of k+1.
 // Scalars: [ |yprev-y|^2, |y12-y|^2, |A x12 - y12|^2, sum w h, |w|^2, |h|^2 ].
-template <typename T>
+// LOGISTIC = true: every f_i is kLogistic (solve_logistic); the guarded-Newton prox
+// (prox_lib.h:131-170) is inlined on its own so the register footprint stays small.
+template <typename T, bool LOGISTIC = false>
 struct FusedIterOp {
   static constexpr int NS = 6;
   struct Pre {
@@ -265,7 +267,15 @@ struct FusedIterOp {
     ytemp[i] = ztn;
     const T zts = zs * ztn;
     const T v = yn - zts;
-    const T h = dev::ProxEvalCheap(p.h, p.a, p.b, p.c, p.d, p.e, v, rho);
+    T h;
+    if (LOGISTIC) {
+      // ProxEval wrapper (prox_lib.h:207-230) around ProxLogistic
+      const T vv = p.a * (v * rho - p.d) / (p.e + rho) - p.b;
+      const T rr = (p.e + rho) / (p.c * p.a * p.a);
+      h = (dev::ProxLogistic(vv, rr) + p.b) / p.a;
+    } else {
+      h = dev::ProxEvalCheap(p.h, p.a, p.b, p.c, p.d, p.e, v, rho);
+    }
     const T w = v - h;
     y12s[i] = h;
     const T yh = zts + alpha * h + (static_cast<T>(1) - alpha) * yn;

@@ -416,8 +416,14 @@ inline bool stream2_supported(const StreamPlan &p) {
   if (p.tpb == 1024) return false;  // 128-VGPR budget: would spill
   return p.nv <= 10;
 }
+// Rows per workgroup step of the two-accumulator kernel: as many as the register file
+// allows (4*NV*(R + 1 + 2) + ~70 VGPRs <= 256), so the per-row functor latency (one lane per
+// row) is amortised over R rows.
+constexpr int stream2_rows_c(int nd, int nv) {
+  return nd > 0 ? (nv <= 2 ? 8 : nv <= 4 ? 4 : nv <= 6 ? 3 : nv <= 8 ? 2 : 1) : (nv <= 4 ? 8 : nv <= 8 ? 4 : 2);
+}
 template <int ND>
-inline int stream2_rows(const StreamPlan &p) { return (ND > 0 || p.tpb == 1024) ? 1 : 2; }
+inline int stream2_rows(const StreamPlan &p) { return stream2_rows_c(ND, p.nv); }
 template <int ND>
 inline int stream2_grid(const StreamPlan &p, int m) {
   const int R = stream2_rows<ND>(p);
@@ -431,7 +437,7 @@ void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, 
   const int grid = stream2_grid<ND>(p, a.m);
 #define POGS_STREAM2_CASE(TPB_, NV_)                                                            \
   if (p.tpb == TPB_ && p.nv == NV_) {                                                           \
-    constexpr int R_ = (ND > 0 || TPB_ == 1024) ? 1 : 2;                                        \
+    constexpr int R_ = stream2_rows_c(ND, NV_);                                                 \
     const size_t lds = (ND > 1) ? static_cast<size_t>(a.n_pad) * sizeof(T) : 0;                 \
     static size_t attr_bytes = 48 * 1024;                                                       \
     if (lds > attr_bytes) {                                                                     \
