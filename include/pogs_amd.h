@@ -194,6 +194,11 @@ int PogsAmdBeginRun(PogsAmdSolver *s,
 int PogsAmdIterate(PogsAmdSolver *s, unsigned int iters, double *seconds,
                    unsigned int *solves_completed);
 
+/* Warm start for the NEXT PogsAmdSolve / PogsAmdBeginRun call only (reference: C++-only
+ * SetInitX / SetInitLambda, src/include/pogs.h:112-119, consumed at src/cpu/pogs.cpp:144-180;
+ * as there, x0 and l0 must be given together).  HOST pointers: x0 (n), l0 (m_local). */
+int PogsAmdSetWarmStart(PogsAmdSolver *s, const void *x0, const void *l0);
+
 int PogsAmdGetStats(const PogsAmdSolver *s, PogsAmdStats *out);
 int PogsAmdResetStats(PogsAmdSolver *s);
 void PogsAmdDestroy(PogsAmdSolver *s);

@@ -868,6 +868,20 @@ int AdmmSolve(Operator<T> *A, Projector<T> *P, std::vector<FunctionObj<T>> f,
   T prev_nrm_r = std::numeric_limits<T>::max();                                 // :251
   unsigned n_exact = 0;
 
+  // Warm start from (x0, lambda0) (pogs.cpp:144-156); the reference only supports both
+  // together (:159-179 assert otherwise).
+  if (info && info->warm_x && info->warm_l) {
+    const T *x0 = static_cast<const T *>(info->warm_x), *l0 = static_cast<const T *>(info->warm_l);
+    for (size_t j = 0; j < n; ++j) xtemp[j] = x0[j] / e[j];                      // :145-146
+    A->Mul('n', kOne, xtemp, kZero, ytemp);                                      // :147
+    z = ztemp;                                                                   // :148
+    for (size_t i = 0; i < m; ++i) ytemp[i] = l0[i] / d[i];                      // :151-152
+    A->Mul('t', -kOne, ytemp, kZero, xtemp);                                     // :153
+    comm.sum_vec(xtemp, n);                                                      // rows are sharded
+    for (size_t i = 0; i < m + n; ++i) ztemp[i] *= -kOne / rho;                  // :154
+    zt = ztemp;                                                                  // :155
+  }
+
   // Norm helpers: x-part replicated, y-part sharded.
   auto nrm_xy = [&](const T *vx, const T *vy) {   // ||[vx|vy]||
     return static_cast<T>(std::sqrt(sumsq(vx, n) + comm.sum1(sumsq(vy, m))));

@@ -19,6 +19,8 @@ typedef struct OracleInfo {
   int use_cgls;            /* dense entry only: use the CGLS projector       */
   double *d_out;           /* optional, length m: equilibration row scaling   */
   double *e_out;           /* optional, length n: equilibration col scaling   */
+  const void *warm_x;      /* optional, length n, element type T: x0           */
+  const void *warm_l;      /* optional, length m, element type T: lambda0      */
   /* out */
   double nrmA;             /* Norm2Est of the equilibrated matrix             */
   unsigned norm_est_iters; /* power iterations executed                       */

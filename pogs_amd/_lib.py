@@ -23,7 +23,7 @@ if "torch" not in sys.modules and os.environ.get("POGS_AMD_NO_TORCH_PRELOAD", "0
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         "pogs_amd: %s not found. Build it with:\n"
-        "  python -m pogs_amd.build        (needs hipcc; cross-compiles for gfx950 without a GPU)\n" % LIB_PATH
+        "  python pogs_amd/build.py        (needs hipcc; cross-compiles for gfx950 without a GPU)\n" % LIB_PATH
     )
 
 lib = ctypes.CDLL(LIB_PATH)
@@ -91,6 +91,7 @@ lib.PogsAmdSolve.argtypes = [c_void_p] + [c_void_p] * 12 + [c_double, c_double, 
                                                             ctypes.POINTER(c_double), ctypes.POINTER(c_uint)]
 lib.PogsAmdBeginRun.argtypes = [c_void_p] + [c_void_p] * 12 + [c_double, c_double, c_double, c_uint, c_int, c_int]
 lib.PogsAmdIterate.argtypes = [c_void_p, c_uint, ctypes.POINTER(c_double), ctypes.POINTER(c_uint)]
+lib.PogsAmdSetWarmStart.argtypes = [c_void_p, c_void_p, c_void_p]
 lib.PogsAmdGetStats.argtypes = [c_void_p, ctypes.POINTER(PogsAmdStats)]
 lib.PogsAmdResetStats.argtypes = [c_void_p]
 lib.PogsAmdDestroy.argtypes = [c_void_p]
@@ -107,7 +108,7 @@ lib.PogsAmdRandUniform.argtypes = [c_int, c_size_t, c_void_p]
 ABI_SYMBOLS = [
     "PogsD", "PogsS", "PogsSparseD", "PogsSparseS",
     "PogsAmdDistUniqueId", "PogsAmdCreateDense", "PogsAmdCreateSparse", "PogsAmdSolve", "PogsAmdBeginRun",
-    "PogsAmdIterate", "PogsAmdGetStats", "PogsAmdResetStats", "PogsAmdDestroy", "PogsAmdLastError",
+    "PogsAmdIterate", "PogsAmdSetWarmStart", "PogsAmdGetStats", "PogsAmdResetStats", "PogsAmdDestroy", "PogsAmdLastError",
     "PogsAmdProxEval", "PogsAmdFuncEval", "PogsAmdGetEquil", "PogsAmdProject", "PogsAmdMul", "PogsAmdRandUniform",
 ]
 

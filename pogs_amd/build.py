@@ -2,7 +2,7 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the
 resulting .so travels to the GPU box with the repo snapshot (it is git-ignored,
-not gpurun-ignored).  Usage: python -m pogs_amd.build [--force]
+not gpurun-ignored).  Usage: python pogs_amd/build.py [--force]
 """
 import concurrent.futures
 import os

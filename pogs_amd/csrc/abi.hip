@@ -269,6 +269,14 @@ int PogsAmdIterate(PogsAmdSolver *s, unsigned int iters, double *seconds, unsign
   });
 }
 
+int PogsAmdSetWarmStart(PogsAmdSolver *s, const void *x0, const void *l0) {
+  return guarded([&]() {
+    POGS_CHECK(s && s->impl && x0 && l0, "warm start needs both x0 and l0 (pogs.cpp:159-179)");
+    s->impl->set_warm_start(x0, l0);
+    return 0;
+  });
+}
+
 int PogsAmdGetStats(const PogsAmdSolver *s, PogsAmdStats *out) {
   return guarded([&]() {
     POGS_CHECK(s && s->impl && out, "null argument");

@@ -126,6 +126,7 @@ class DenseSolver final : public SolverBase {
     const double t0 = wall_s();
     load_problem(f, g, p);
     cold_start();
+    apply_warm_start();
     ctx_.sync();
     const double t1 = wall_s();
     if (p.verbose > 1 && ctx_.dist.rank() == 0)
@@ -152,7 +153,14 @@ class DenseSolver final : public SolverBase {
   void begin_run(const FnHost &f, const FnHost &g, const SolveParams &p) override {
     load_problem(f, g, p);
     cold_start();
+    apply_warm_start();
     ctx_.sync();
+  }
+
+  void set_warm_start(const void *x0, const void *l0) override {
+    warm_x_.assign(static_cast<const T *>(x0), static_cast<const T *>(x0) + n_);
+    warm_l_.assign(static_cast<const T *>(l0), static_cast<const T *>(l0) + m_);
+    warm_pending_ = true;
   }
 
   void iterate(unsigned iters, double *seconds, unsigned *solves) override {
@@ -670,6 +678,28 @@ class DenseSolver final : public SolverBase {
     ctl_.reset();
   }
 
+  // (x0, lambda0) -> (z, z~): z = [x0 / e | A (x0 / e)], z~ = -(1/rho) [-A^T (l0 / d) | l0 / d]
+  // (pogs.cpp:144-156).  Consumed once.
+  void apply_warm_start() {
+    if (!warm_pending_) return;
+    warm_pending_ = false;
+    hipStream_t s = ctx_.stream;
+    const T rho = ctl_.rho;
+    POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, warm_x_.data(), n_ * sizeof(T), hipMemcpyHostToDevice, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, warm_l_.data(), m_ * sizeof(T), hipMemcpyHostToDevice, s));
+    launch_scale_by<T>(n_, static_cast<T>(1), xtemp_.p, e_.p, true, x_[cur_].p, s);            // x = x0 / e
+    StreamArgs<T> a = argsA();
+    a.xin = x_[cur_].p;
+    launch_stream<T, true, false, false, kFull>(planA_, a, GemvNOp<T>{1, 0, y_[cur_].p}, s);     // y = A x
+    launch_scale_by<T>(m_, static_cast<T>(1), ytemp_.p, d_.p, true, yt_.p, s);                  // l0 / d
+    gemv_t_partials(yt_.p);
+    finish_cols(StoreColOp<T>{static_cast<T>(1) / rho, 0, xt_.p, n_}, nullptr, 0, 0);           // xt = A^T (l0/d) / rho
+    launch_scal<T>(yt_.p, static_cast<T>(-1) / rho, m_, s);                                     // yt = -(l0/d) / rho
+    ctx_.sync();
+    xtemp_.zero(s);
+    ytemp_.zero(s);
+  }
+
   // One ADMM iteration (pogs.cpp:253-470).  Returns true when the solve stops.
   bool iteration(unsigned verbose) {
     if (fused_now_) return iteration_fused(verbose);
@@ -928,6 +958,8 @@ class DenseSolver final : public SolverBase {
   StreamPlan planA_, planW_;
   DevBuf<T> A_, W_, U_, d_, e_, colpart_, colpart2_, pair_, y12s_, ytemps_;
   bool fused_ok_ = false, fused_now_ = false, fused_logistic_ = false, spec_valid_ = false;
+  bool warm_pending_ = false;
+  std::vector<T> warm_x_, warm_l_;
   T rho_pred_ = 1, zs_pred_ = 1;
   DevBuf<T> x_[2], y_[2], xt_, yt_, xtemp_, ytemp_, x12_, y12_, rhs_, tvec_, tmpn_;
   DevBuf<T> xout_, yout_, lout_, muout_;

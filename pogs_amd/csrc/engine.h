@@ -286,6 +286,7 @@ struct SolverBase {
                     void *mu, double *optval, unsigned *final_iter) = 0;
   virtual void begin_run(const FnHost &f, const FnHost &g, const SolveParams &p) = 0;
   virtual void iterate(unsigned iters, double *seconds, unsigned *solves) = 0;
+  virtual void set_warm_start(const void *x0, const void *l0) = 0;
   virtual void get_equil(void *A_eq, void *d, void *e, double *nrmA) = 0;
   virtual void project(const void *x0, const void *y0, double tol, void *x, void *y) = 0;
   virtual void mul(char trans, double alpha, const void *x, double beta, void *y) = 0;

@@ -393,6 +393,7 @@ class SparseSolver final : public SolverBase {
     const double t0 = wall_s();
     load_problem(f, g, p);
     cold_start();
+    apply_warm_start();
     ctx_.sync();
     const double t1 = wall_s();
     while (!iteration(p.verbose)) {}
@@ -417,7 +418,14 @@ class SparseSolver final : public SolverBase {
   void begin_run(const FnHost &f, const FnHost &g, const SolveParams &p) override {
     load_problem(f, g, p);
     cold_start();
+    apply_warm_start();
     ctx_.sync();
+  }
+
+  void set_warm_start(const void *x0, const void *l0) override {
+    warm_x_.assign(static_cast<const T *>(x0), static_cast<const T *>(x0) + n_);
+    warm_l_.assign(static_cast<const T *>(l0), static_cast<const T *>(l0) + m_);
+    warm_pending_ = true;
   }
 
   void iterate(unsigned iters, double *seconds, unsigned *solves) override {
@@ -741,6 +749,24 @@ class SparseSolver final : public SolverBase {
     launch_axpby<T>(n_, static_cast<T>(1), x0, static_cast<T>(1), x, s);
   }
 
+  // (x0, lambda0) -> (z, z~)   (pogs.cpp:144-156), see dense.hip
+  void apply_warm_start() {
+    if (!warm_pending_) return;
+    warm_pending_ = false;
+    hipStream_t s = ctx_.stream;
+    const T rho = ctl_.rho;
+    POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, warm_x_.data(), n_ * sizeof(T), hipMemcpyHostToDevice, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, warm_l_.data(), m_ * sizeof(T), hipMemcpyHostToDevice, s));
+    launch_scale_by<T>(n_, static_cast<T>(1), xtemp_.p, e_.p, true, x_[cur_].p, s);
+    spmv<false>(A_, x_[cur_].p, nullptr, SpAxpbyOp<T>{1, 0, nullptr, y_[cur_].p}, nullptr, 0);
+    launch_scale_by<T>(m_, static_cast<T>(1), ytemp_.p, d_.p, true, yt_.p, s);
+    spmv<false>(At_, yt_.p, nullptr, SpAxpbyOp<T>{static_cast<T>(1) / rho, 0, nullptr, xt_.p}, nullptr, 0);
+    launch_scal<T>(yt_.p, static_cast<T>(-1) / rho, m_, s);
+    ctx_.sync();
+    xtemp_.zero(s);
+    ytemp_.zero(s);
+  }
+
   bool iteration(unsigned verbose) {
     hipStream_t s = ctx_.stream;
     const int nw = cur_ ^ 1;
@@ -841,6 +867,8 @@ class SparseSolver final : public SolverBase {
   bool first_is_A_ = true;
   int spmv_grid_ = 2048;
   unsigned long long timed_spmvs_ = 0;
+  bool warm_pending_ = false;
+  std::vector<T> warm_x_, warm_l_;
   DevCsr<T> A_, At_;
   DevBuf<T> d_, e_;
   DevBuf<T> x_[2], y_[2], xt_, yt_, xtemp_, ytemp_, x12_, y12_;

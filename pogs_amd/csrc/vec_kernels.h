@@ -95,6 +95,8 @@ void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s);
 template <typename T> void launch_fill(T *p, T v, size_t n, hipStream_t s);
 template <typename T> void launch_sqrt_inplace(T *p, size_t n, hipStream_t s);
 template <typename T> void launch_scal(T *p, T alpha, size_t n, hipStream_t s);
+// out[i] = alpha * in[i] * (divide ? 1 / sc[i] : sc[i])   (warm start: x0 / e, lambda0 / d)
+template <typename T> void launch_scale_by(size_t n, T alpha, const T *in, const T *sc, bool divide, T *out, hipStream_t s);
 // y = a*x + b*y
 template <typename T> void launch_axpby(size_t n, T a, const T *x, T b, T *y, hipStream_t s);
 

@@ -151,6 +151,12 @@ __global__ void axpby_kernel(size_t n, T a, const T *x, T b, T *y) {
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) y[i] = (b == static_cast<T>(0)) ? a * x[i] : a * x[i] + b * y[i];
 }
+template <typename T>
+__global__ void scale_by_kernel(size_t n, T alpha, const T *in, const T *sc, bool divide, T *out) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = divide ? alpha * in[i] / sc[i] : alpha * in[i] * sc[i];
+}
+
 inline dim3 grid1d(size_t n, int tpb = 256) { return dim3(static_cast<unsigned>((n + tpb - 1) / tpb)); }
 
 }  // namespace
@@ -213,6 +219,10 @@ void launch_scal(T *p, T alpha, size_t n, hipStream_t s) {
   if (n) hipLaunchKernelGGL(scal_kernel<T>, grid1d(n), dim3(256), 0, s, p, alpha, n);
 }
 template <typename T>
+void launch_scale_by(size_t n, T alpha, const T *in, const T *sc, bool divide, T *out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(scale_by_kernel<T>, grid1d(n), dim3(256), 0, s, n, alpha, in, sc, divide, out);
+}
+template <typename T>
 void launch_axpby(size_t n, T a, const T *x, T b, T *y, hipStream_t s) {
   if (n) hipLaunchKernelGGL(axpby_kernel<T>, grid1d(n), dim3(256), 0, s, n, a, x, b, y);
 }
@@ -226,6 +236,7 @@ void launch_axpby(size_t n, T a, const T *x, T b, T *y, hipStream_t s) {
   template void launch_fill<T>(T *, T, size_t, hipStream_t);                                             \
   template void launch_sqrt_inplace<T>(T *, size_t, hipStream_t);                                        \
   template void launch_scal<T>(T *, T, size_t, hipStream_t);                                             \
+  template void launch_scale_by<T>(size_t, T, const T *, const T *, bool, T *, hipStream_t);             \
   template void launch_axpby<T>(size_t, T, const T *, T, T *, hipStream_t);
 POGS_INST(float)
 POGS_INST(double)

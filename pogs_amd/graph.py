@@ -341,8 +341,19 @@ class Solver:
         args = [_ptr(fa[k]) for k in "abcdeh"] + [_ptr(ga[k]) for k in "abcdeh"]
         return args, (fa, ga)
 
+    def warm_start(self, x0, l0):
+        """Start the next solve from (x0, lambda0) instead of zero (reference: SetInitX /
+        SetInitLambda, src/include/pogs.h:112-119; both are required, pogs.cpp:159-179)."""
+        x0 = np.ascontiguousarray(x0, self.dtype)
+        l0 = np.ascontiguousarray(l0, self.dtype)
+        assert x0.shape == (self.n,) and l0.shape == (self.m,)
+        if lib.PogsAmdSetWarmStart(self._h, _ptr(x0), _ptr(l0)) != 0:
+            raise RuntimeError("pogs_amd: " + _lib.last_error())
+
     def solve(self, f, g, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0, rho=1.0, adaptive_rho=True,
-              gap_stop=True):
+              gap_stop=True, x0=None, l0=None):
+        if x0 is not None or l0 is not None:
+            self.warm_start(x0, l0)
         args, keep = self._coef(f, g)
         x = np.zeros(self.n, self.dtype)
         y = np.zeros(self.m, self.dtype)

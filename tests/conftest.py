@@ -22,9 +22,13 @@ def pytest_configure(config):
 
     oracle_binding.build_oracle()
     oracle_binding.build_ref()
-    from pogs_amd import build as _build
-
     if os.path.exists("/opt/rocm/bin/hipcc"):
+        import importlib.util
+
+        # by path: importing the package itself requires the built library
+        spec = importlib.util.spec_from_file_location("_pogs_amd_build", os.path.join(ROOT, "pogs_amd", "build.py"))
+        _build = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_build)
         _build.build()
 
 

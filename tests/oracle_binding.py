@@ -21,6 +21,8 @@ class OracleInfo(ctypes.Structure):
         ("use_cgls", ctypes.c_int),
         ("d_out", ctypes.POINTER(ctypes.c_double)),
         ("e_out", ctypes.POINTER(ctypes.c_double)),
+        ("warm_x", ctypes.c_void_p),
+        ("warm_l", ctypes.c_void_p),
         ("nrmA", ctypes.c_double),
         ("norm_est_iters", ctypes.c_uint),
         ("rho_final", ctypes.c_double),
@@ -142,11 +144,15 @@ def _solve_sparse(fn, A_csr, f, g, dtype, rho, abs_tol, rel_tol, max_iter, verbo
 
 
 def oracle_solve(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0,
-                 adaptive_rho=True, gap_stop=True, order=1, use_cgls=False, want_de=False):
-    """Run the oracle through its PogsD/S-shaped entry.  A dense ndarray or scipy CSR."""
+                 adaptive_rho=True, gap_stop=True, order=1, use_cgls=False, want_de=False, x0=None, l0=None):
+    """Run the oracle through its PogsD/S-shaped entry.  A dense ndarray or scipy CSR.
+    (x0, l0): warm start, the reference's SetInitX/SetInitLambda (pogs.cpp:144-156)."""
     lib = oracle_lib()
     info = OracleInfo()
     info.use_cgls = int(use_cgls)
+    if x0 is not None:
+        warm = (np.ascontiguousarray(x0, dtype=dtype), np.ascontiguousarray(l0, dtype=dtype))
+        info.warm_x, info.warm_l = warm[0].ctypes.data, warm[1].ctypes.data
     sparse = hasattr(A, "indptr")
     m, n = A.shape
     keep = None

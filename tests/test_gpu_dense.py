@@ -442,3 +442,54 @@ def test_wide_register_plan_fp32():
     assert np.linalg.norm(A64 @ x.astype(np.float64) - y) / np.sqrt(17000) < 3e-4
     kkt = A64.T @ (A64 @ x.astype(np.float64) - y0) + (x - x0)
     assert np.linalg.norm(kkt) / np.sqrt(16500) < 3e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(800, 120), (120, 300)])
+def test_warm_start_lambda_path_matches_oracle(dtype, shape):
+    """SetInitX/SetInitLambda equivalent (pogs.cpp:144-156): the second solve of a lambda path
+    started from the first solve's (x, lambda) follows the oracle's warm-started trajectory."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    m, n = shape
+    A, b, _ = synth.dense_lasso(m, n, seed=21, dtype=dtype)
+    f1, g1 = pogs.graph.lasso_functions(b, 0.5, n)
+    f2, g2 = pogs.graph.lasso_functions(b, 0.4, n)
+    want1 = ob.oracle_solve(A, soa(f1), soa(g1), dtype=dtype)
+    cold = ob.oracle_solve(A, soa(f2), soa(g2), dtype=dtype)
+    want2 = ob.oracle_solve(A, soa(f2), soa(g2), dtype=dtype, x0=want1["x"], l0=want1["l"])
+    assert want2["iterations"] < cold["iterations"]
+    with pogs.Solver(A, dtype=dtype) as s:
+        r1 = s.solve(f1, g1)
+        r2 = s.solve(f2, g2, x0=want1["x"], l0=want1["l"])
+        r3 = s.solve(f2, g2)  # the warm start is consumed once: this one is cold again
+    tol = 1e-9 if dtype == np.float64 else 2e-3
+    assert r1["status"] == 0 and r2["status"] == 0
+    if dtype == np.float64:
+        assert r2["iterations"] == want2["iterations"]
+        assert r3["iterations"] == cold["iterations"]
+    else:
+        assert abs(int(r2["iterations"]) - int(want2["iterations"])) <= max(3, want2["iterations"] // 10)
+    assert relerr(r2["x"], want2["x"]) < tol
+    assert relerr(r2["l"], want2["l"]) < tol * 10
+    assert relerr(r3["x"], cold["x"]) < tol
+
+
+@pytest.mark.gpu
+def test_warm_start_from_solution_stops_immediately():
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.dense_lasso(2000, 300, seed=5, dtype=np.float32)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 300)
+    with pogs.Solver(A, dtype=np.float32) as s:
+        r = s.solve(f, g)
+        r2 = s.solve(f, g, x0=r["x"], l0=r["l"])
+        want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float32, x0=r["x"], l0=r["l"])
+        assert r2["status"] == 0 and r2["iterations"] * 4 < r["iterations"]
+        assert abs(int(r2["iterations"]) - int(want["iterations"])) <= 3
+        assert relerr(r2["x"], r["x"]) < 1e-3
+        with pytest.raises(Exception):
+            s.warm_start(r["x"], None)

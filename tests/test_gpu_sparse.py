@@ -171,3 +171,22 @@ def test_csc_input_through_raw_abi():
     assert st == 0 == want["status"]
     assert abs(fi.value - want["iterations"]) <= 1
     assert relerr(x, want["x"]) < 1e-6
+
+
+def test_sparse_warm_start_matches_oracle():
+    """Warm start (pogs.cpp:144-156) on the CSR + CGLS path."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.csr_lasso(3000, 800, 20, seed=8, dtype=np.float64)
+    f1, g1 = pogs.graph.lasso_functions(b, 0.3, 800)
+    f2, g2 = pogs.graph.lasso_functions(b, 0.2, 800)
+    w1 = ob.oracle_solve(A, soa(f1), soa(g1), dtype=np.float64)
+    cold = ob.oracle_solve(A, soa(f2), soa(g2), dtype=np.float64)
+    w2 = ob.oracle_solve(A, soa(f2), soa(g2), dtype=np.float64, x0=w1["x"], l0=w1["l"])
+    assert w2["iterations"] < cold["iterations"]
+    with pogs.Solver(A, dtype=np.float64) as s:
+        r2 = s.solve(f2, g2, x0=w1["x"], l0=w1["l"])
+        r3 = s.solve(f2, g2)
+    _check(r2, w2, 1e-6, 2)
+    _check(r3, cold, 1e-6, 2)
