@@ -108,10 +108,15 @@ class DenseSolver final : public SolverBase {
     lda_ = n_pad_;
     planA_ = make_stream_plan<T>(n_pad_, ctx_.num_cu);
     POGS_CHECK(planA_.ok, "n too large for the register-tiled streaming kernel");
+    ctx_.tmark_last = t0;
+    ctx_.tmark("ctx init");
     upload(ord, A, mem);
     ctx_.stats.t_h2d_s = wall_s() - t0;
+    ctx_.tmark("upload");
     alloc_state();
+    ctx_.tmark("alloc_state");
     equilibrate();
+    ctx_.tmark("equilibrate");
     if (!tall_ || use_cgls_) norm_est();   // direct, m > n: estimated from the Gram matrix inside factor()
     if (!use_cgls_) factor();
     ctx_.sync();
@@ -365,8 +370,11 @@ class DenseSolver final : public SolverBase {
     const int gridACC = stream_grid<false, true>(planA_, m_);
     const int gridBOTH = stream_grid<true, true>(planA_, m_);
     StreamArgs<T> a = argsA();
+    ctx_.tmark("  eq: start");
     launch_stream<T, false, true, true, kFull>(planA_, a, OnesOp<T>{}, s);
+    ctx_.tmark("  eq: first pass");
     finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_}, nullptr, 0, 0, gridACC);
+    ctx_.tmark("  eq: first cols");
     for (int k = 0; k < 50; ++k) {
       a.xin = e_.p;
       if (k < 49) {
@@ -377,6 +385,7 @@ class DenseSolver final : public SolverBase {
       }
     }
     ctx_.stats.matvecs_init += 51;
+    ctx_.tmark("  eq: sk loop");
     launch_sqrt_inplace<T>(d_.p, m_, s);                                  // matrix_dense.cpp:176-177
     launch_sqrt_inplace<T>(e_.p, n_, s);
     const int sgrid = std::min(m_, ctx_.num_cu * 8);
@@ -444,10 +453,13 @@ class DenseSolver final : public SolverBase {
     hipStream_t s = ctx_.stream;
     PhaseTimer pt(s);
     launch_zero_upper<T>(G, ld, n_, s);
+    ctx_.tmark("  ne: zero_upper");
     std::vector<T> x0(n_pad_, 0);
     rand_uniform_host(x0.data(), n_);
+    ctx_.tmark("  ne: rand host");
     POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, x0.data(), n_pad_ * sizeof(T), hipMemcpyHostToDevice, s));
     ctx_.sync();
+    ctx_.tmark("  ne: h2d");
     T *xa = xtemp_.p, *xb = rhs_.p;
     const T kTol = static_cast<T>(1e-4);
     T norm_est = 0, last;
@@ -489,61 +501,67 @@ class DenseSolver final : public SolverBase {
     const size_t ld = k_pad_;
     planW_ = make_stream_plan<T>(k_pad_, ctx_.num_cu);
     POGS_CHECK(planW_.ok, "min(m, n) too large for the register-tiled streaming kernel");
-    DevBuf<T> G(static_cast<size_t>(k_) * ld);
-    G.zero(s);
+    // One allocation, four k x k slabs: [G -> L | scratch | W = L^-1 | U = W^T].
+    const size_t slab = static_cast<size_t>(k_) * ld;
+    fac_.alloc(slab * 4);
+    fac_.zero(s);
+    T *G = fac_.p, *tmp = fac_.p + slab;
+    Wp_ = fac_.p + 2 * slab;
+    Up_ = fac_.p + 3 * slab;
     {
       PhaseTimer pt(s);
-      // split-K so the tile count is >> the number of workgroup slots (tail effect) and the
-      // K-sum is accumulated in chunks; slabs are added in fixed order (deterministic).
+      // split-K: short K ranges keep the workgroups of an XCD in step on the same rows of A
+      // (L2 hits; one long K range per tile measured 121 ms against 100 ms at C2), give every
+      // CU work to the end of the launch, and form the fp32 K-sum as an ordered sum of short
+      // sums: a sequential fp32 sum over 1e5 rows costs ~30 % more ADMM iterations at C2.
+      // Slabs are added in index order (deterministic); at most 8 GB of them, transient.
       const int kdim = tall_ ? m_ : n_;
       const long long tiles = static_cast<long long>((k_ + 127) / 128) * ((k_ + 127) / 128 + 1) / 2;
-      // chunks of <= ~6k rows keep the fp32 K-accumulation error near 5e-6 relative (a
-      // sequential fp32 sum over 1e5 rows costs ~30 % more ADMM iterations at C2); at
-      // most 8 GB of slabs.
-      const size_t slab = static_cast<size_t>(k_) * ld;
       int ksplit = 1;
       while (ksplit < 32 && kdim / (ksplit * 2) >= 2048 && (kdim / ksplit > 6400 || tiles * ksplit < 16LL * ctx_.num_cu * 3) &&
              slab * sizeof(T) * (ksplit * 2) <= (8ull << 30))
         ksplit *= 2;
+      if (const char *ev = std::getenv("POGS_AMD_KSPLIT")) ksplit = std::max(1, std::atoi(ev));   // tuning aid
       DevBuf<T> slabs;
-      T *dst = G.p;
+      T *dst = G;
       if (ksplit > 1) {
-        slabs.alloc(slab * ksplit);
-        slabs.zero(s);
+        slabs.alloc(slab * ksplit);   // lower tiles are fully overwritten (beta = 0): no memset
         dst = slabs.p;
       }
       GemmArgs<T> g{k_, k_, kdim, A_.p, lda_, A_.p, lda_, dst, ld, static_cast<T>(1), static_cast<T>(0)};
       g.ksplit = ksplit;
-      g.kchunk = static_cast<int>(round_up((kdim + ksplit - 1) / ksplit, 16));
+      g.kchunk = static_cast<int>(round_up((kdim + ksplit - 1) / ksplit, 32));
       g.csplit_stride = slab;
+      // where the memory cap leaves K ranges longer than ~6.4k rows the unit itself sums in chunks
+      const int nacc = (g.kchunk + 6399) / 6400;
+      g.kacc = nacc > 1 ? static_cast<int>(round_up((g.kchunk + nacc - 1) / nacc, 32)) : 0;
       launch_gemm<T>(tall_, tall_, true, g, s);
       if (ksplit > 1) {
-        launch_sum_slabs<T>(slabs.p, slab, ksplit, G.p, slab, s);
+        launch_sum_slabs<T>(slabs.p, slab, ksplit, G, ld, k_, s);
         ctx_.sync();   // slabs are freed at scope exit
       }
-      if (multi_) ctx_.dist.allreduce(G.p, static_cast<size_t>(k_) * ld, s);
+      if (multi_) ctx_.dist.allreduce(G, slab, s);
       ctx_.stats.gram_ms = pt.stop_ms();
-      ctx_.stats.gram_flops = static_cast<double>(tall_ ? m_ : n_) * k_ * k_;
+      ctx_.stats.gram_flops = static_cast<double>(kdim) * k_ * k_;
     }
-    if (tall_) norm_est_gram(G.p, ld);
-    launch_add_diag<T>(G.p, ld, k_, static_cast<T>(1), s);               // projector_direct_dense.cpp:118-119
-    W_.alloc(static_cast<size_t>(k_) * ld);
-    W_.zero(s);
+    ctx_.tmark("gram");
+    if (tall_) norm_est_gram(G, ld);
+    ctx_.tmark("norm_est_gram");
+    launch_add_diag<T>(G, ld, k_, static_cast<T>(1), s);                 // projector_direct_dense.cpp:118-119
     {
       PhaseTimer pt(s);
-      cholesky_lower<T>(G.p, ld, k_, W_.p, ld, s);
+      cholesky_lower<T>(G, ld, k_, Wp_, ld, s);
       ctx_.stats.chol_ms = pt.stop_ms();
     }
+    ctx_.tmark("cholesky");
     {
       PhaseTimer pt(s);
-      DevBuf<T> tmp(static_cast<size_t>(k_) * ld);
-      trtri_lower<T>(G.p, ld, k_, W_.p, ld, tmp.p, s);
-      U_.alloc(static_cast<size_t>(k_) * ld);
-      U_.zero(s);
-      launch_transpose<T>(W_.p, ld, k_, k_, U_.p, ld, s);
+      trtri_lower<T>(G, ld, k_, Wp_, ld, tmp, s);
+      launch_transpose<T>(Wp_, ld, k_, k_, Up_, ld, s);
       ctx_.stats.trtri_ms = pt.stop_ms();
     }
     ctx_.sync();
+    ctx_.tmark("trtri");
   }
 
   // x_out-functor( U (W (rhs + add)) ): the two triangular products that replace
@@ -552,11 +570,11 @@ class DenseSolver final : public SolverBase {
   void solve_gram(const T *rhs, const T *add, const TailOp &tail, double *tail_scalars) {
     hipStream_t s = ctx_.stream;
     StreamArgs<T> a;
-    a.A = W_.p; a.lda = k_pad_; a.m = k_; a.n_pad = k_pad_;
+    a.A = Wp_; a.lda = k_pad_; a.m = k_; a.n_pad = k_pad_;
     a.xin = rhs; a.xin_add = add; a.xin_nrm2 = nullptr;
     a.col_partials = nullptr; a.scalar_partials = ctx_.spart.p;
     launch_stream<T, true, false, false, kLower>(planW_, a, GemvNOp<T>{1, 0, tvec_.p}, s);
-    a.A = U_.p;
+    a.A = Up_;
     a.xin = tvec_.p; a.xin_add = nullptr;
     launch_stream<T, true, false, false, kUpper>(planW_, a, tail, s);
     if (TailOp::NS > 0 && tail_scalars) {
@@ -956,7 +974,8 @@ class DenseSolver final : public SolverBase {
   DevBuf<double> cg_;
   size_t lda_ = 0;
   StreamPlan planA_, planW_;
-  DevBuf<T> A_, W_, U_, d_, e_, colpart_, colpart2_, pair_, y12s_, ytemps_;
+  T *Wp_ = nullptr, *Up_ = nullptr;   // views into fac_
+  DevBuf<T> A_, fac_, d_, e_, colpart_, colpart2_, pair_, y12s_, ytemps_;
   bool fused_ok_ = false, fused_now_ = false, fused_logistic_ = false, spec_valid_ = false;
   bool warm_pending_ = false;
   std::vector<T> warm_x_, warm_l_;

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <memory>
 #include <vector>
@@ -123,6 +125,19 @@ struct Ctx {
     return S_host.p;
   }
   void sync() { POGS_HIP_CHECK(hipStreamSynchronize(stream)); }
+  // POGS_AMD_TRACE=1: host-side setup timeline on stderr (time to reach the mark on the host,
+  // then the extra wait for the stream to drain) -- finds host stalls the kernel trace hides.
+  void tmark(const char *label) {
+    static const bool on = std::getenv("POGS_AMD_TRACE") != nullptr;
+    if (!on) return;
+    const double t1 = wall_s();
+    POGS_HIP_CHECK(hipStreamSynchronize(stream));
+    const double t2 = wall_s();
+    std::fprintf(stderr, "[pogs_amd trace] %-28s host +%8.3f ms, drain +%8.3f ms\n", label,
+                 (t1 - tmark_last) * 1e3, (t2 - t1) * 1e3);
+    tmark_last = wall_s();
+  }
+  double tmark_last = 0;
   ~Ctx() {
     if (stream) (void)hipStreamDestroy(stream);
   }

@@ -27,6 +27,10 @@ struct GemmArgs {
   int ksplit = 1;
   int kchunk = 0;
   size_t csplit_stride = 0;
+  // kacc > 0 (multiple of 32; lower_only Gram launches): every kacc rows of the K range the
+  // register accumulators are added into a second set and cleared, so a long fp32 K-sum is
+  // formed as an ordered sum of short ones (same error behaviour as split-K, no slabs).
+  int kacc = 0;
 };
 
 // A_KMAJ: op(A)(i,k) = A[k*lda + i], else A[i*lda + k].
@@ -56,9 +60,11 @@ void trtri_lower(const T *L, size_t ldg, int n, T *W, size_t ldw, T *tmp, hipStr
 template <typename T>
 void launch_transpose(const T *in, size_t ld_in, int rows, int cols, T *out, size_t ld_out, hipStream_t s);
 
-// out[i] = sum_s in[s * stride + i], s in fixed order (combines split-K slabs)
+// out = sum_s in[s * stride + .] over the lower 128-tiles of an n x n matrix (leading dim ld,
+// ld a multiple of the 16-byte vector), s in fixed order: combines split-K slabs, which a
+// lower_only launch leaves unwritten above the diagonal tiles.
 template <typename T>
-void launch_sum_slabs(const T *in, size_t stride, int nslabs, T *out, size_t count, hipStream_t s);
+void launch_sum_slabs(const T *in, size_t stride, int nslabs, T *out, size_t ld, int n, hipStream_t s);
 
 // zero the strictly upper triangle of an n x n matrix
 template <typename T>

@@ -99,7 +99,7 @@ __device__ __forceinline__ void store_tile(T *sm, const typename Vec16<T>::type 
   }
 }
 
-template <typename T, bool A_KMAJ, bool B_KMAJ, bool LOWER>
+template <typename T, bool A_KMAJ, bool B_KMAJ, bool LOWER, bool TWOLEVEL = false>
 __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
   using V = typename Vec16<T>::type;
   using Acc = typename Mma<T>::Acc;
@@ -169,6 +169,17 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
   load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg + BK, g.M, kend, ra0);
   load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg + BK, g.N, kend, rb0);
   __syncthreads();
+  Acc tot[TWOLEVEL ? 4 : 1][TWOLEVEL ? 4 : 1];
+  if (TWOLEVEL) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tot[a][b][r] = 0;
+  }
+  const int acc_tiles = TWOLEVEL ? g.kacc / BK : 0;   // even
+  int until_flush = acc_tiles;
   for (int kt = 0; kt < nk; kt += 2) {
     // even phase: LDS[0] = tile kt, stage 0 = tile kt+1 (in flight), request tile kt+2
     load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg + (kt + 2) * BK, g.M, kend, ra1);
@@ -184,8 +195,28 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
     store_tile<T, A_KMAJ>(sA[0], ra1);
     store_tile<T, B_KMAJ>(sB[0], rb1);
     __syncthreads();
+    if (TWOLEVEL) {
+      until_flush -= 2;
+      if (until_flush == 0) {
+        until_flush = acc_tiles;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            tot[a][b] += acc[a][b];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0;
+          }
+      }
+    }
   }
 #undef POGS_GEMM_COMPUTE
+  if (TWOLEVEL) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] += tot[a][b];
+  }
 
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -204,61 +235,99 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
       }
 }
 
-// Cholesky of one NB x NB diagonal block held in LDS (right-looking, 2 barriers per
-// column, 16 x 16 thread layout for the rank-1 updates: no integer divisions), then the
-// inverse of the triangular factor by forward substitution, one column per thread
-// with four independent accumulators to pipeline the LDS reads.  One workgroup.
+// The 16 steps j = 16 JB .. 16 JB + 15 of potrf_inv_kernel.  JB is a template parameter so
+// that which register groups take part is known at compile time (rows a >= JB; L columns
+// b >= JB; X columns b <= JB) and the register arrays are only indexed statically.
+template <typename T, int NB, int JB>
+__device__ __forceinline__ void potrf_steps(T (&Lr)[NB / 16][NB / 16], T (&Xr)[NB / 16][NB / 16], T (&colj)[2][NB],
+                                            T (&rowj)[2][NB], int nb, int tx, int ty) {
+  constexpr int NBK = NB / 16;
+  for (int jl = 0; jl < 16; ++jl) {
+    const int j = 16 * JB + jl, par = jl & 1;
+    if (j >= nb) break;
+    if (tx == jl) {
+#pragma unroll
+      for (int a = JB; a < NBK; ++a) colj[par][ty + 16 * a] = Lr[a][JB];
+    }
+    if (ty == jl) {
+#pragma unroll
+      for (int b = 0; b <= JB; ++b) rowj[par][tx + 16 * b] = Xr[JB][b];
+    }
+    __syncthreads();
+    // unconditional LDS reads (a read under a lane condition becomes a branch with its own wait)
+    T lij[NBK], fl[NBK], fx[NBK];
+    const T djj = colj[par][j];
+#pragma unroll
+    for (int a = JB; a < NBK; ++a) lij[a] = colj[par][ty + 16 * a];
+#pragma unroll
+    for (int b = JB; b < NBK; ++b) fl[b] = colj[par][tx + 16 * b];
+#pragma unroll
+    for (int b = 0; b <= JB; ++b) fx[b] = rowj[par][tx + 16 * b];
+    const T ljj = sqrt(djj);
+    const T inv = static_cast<T>(1) / ljj;
+#pragma unroll
+    for (int a = JB; a < NBK; ++a) lij[a] = (ty + 16 * a > j) ? lij[a] * inv : static_cast<T>(0);
+#pragma unroll
+    for (int b = JB; b < NBK; ++b) fl[b] = (tx + 16 * b > j) ? fl[b] * inv : static_cast<T>(0);
+#pragma unroll
+    for (int b = 0; b <= JB; ++b) fx[b] = (tx + 16 * b <= j) ? fx[b] * inv : static_cast<T>(0);
+    // the owners finish column j of L and row j of X
+    if (tx == jl) {
+#pragma unroll
+      for (int a = JB; a < NBK; ++a) {
+        const int i = ty + 16 * a;
+        Lr[a][JB] = (i == j) ? ljj : ((i > j) ? lij[a] : Lr[a][JB]);
+      }
+    }
+    if (ty == jl) {
+#pragma unroll
+      for (int b = 0; b <= JB; ++b) Xr[JB][b] = (tx + 16 * b <= j) ? fx[b] : Xr[JB][b];
+    }
+#pragma unroll
+    for (int a = JB; a < NBK; ++a) {
+#pragma unroll
+      for (int b = JB; b < NBK; ++b) Lr[a][b] -= lij[a] * fl[b];
+#pragma unroll
+      for (int b = 0; b <= JB; ++b) Xr[a][b] -= lij[a] * fx[b];
+    }
+  }
+  if constexpr (JB + 1 < NBK) potrf_steps<T, NB, JB + 1>(Lr, Xr, colj, rowj, nb, tx, ty);
+}
+
+// Cholesky of one NB x NB diagonal block together with the inverse of its factor, one
+// workgroup, right-looking, the whole block in registers: thread (ty, tx) of a 16 x 16 layout
+// owns the elements (ty + 16 a, tx + 16 b) of L and of X = L^-1.  Step j: the owners publish
+// column j of L and row j of X (unscaled) through LDS, one barrier, then every thread applies
+//   L[i][c] -= L[i][j] L[c][j]  (j < c, j < i)      X[i][c] -= L[i][j] X[j][c]  (c <= j < i)
+// to its own registers; 16-row / 16-column groups that lie entirely outside the active region
+// are skipped with uniform branches.  (A version that kept the block in LDS spent 340 us per
+// 128-block on address arithmetic and LDS round trips; the Cholesky was 75 % potrf time.)
 template <typename T, int NB>
 __global__ void __launch_bounds__(256) potrf_inv_kernel(T *G, size_t ldg, int nb, T *Winv, size_t ldw) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int LD = NB + 1;
-  T *sL = reinterpret_cast<T *>(smem_raw);
-  T *sX = sL + NB * LD;
-  __shared__ T s_diag[NB];
+  constexpr int NBK = NB / 16;
+  __shared__ T colj[2][NB], rowj[2][NB];
   const int t = threadIdx.x;
   const int tx = t & 15, ty = t >> 4;
-  for (int r = ty; r < nb; r += 16)
-    for (int c = tx; c < nb; c += 16) {
-      sL[r * LD + c] = (c <= r) ? G[static_cast<size_t>(r) * ldg + c] : static_cast<T>(0);
-      sX[r * LD + c] = 0;
+  T Lr[NBK][NBK], Xr[NBK][NBK];
+#pragma unroll
+  for (int a = 0; a < NBK; ++a)
+#pragma unroll
+    for (int b = 0; b < NBK; ++b) {
+      const int i = ty + 16 * a, c = tx + 16 * b;
+      const T unit = (i == c) ? static_cast<T>(1) : static_cast<T>(0);
+      Lr[a][b] = (i < nb && c <= i) ? G[static_cast<size_t>(i) * ldg + c] : unit;
+      Xr[a][b] = unit;
     }
-  for (int j = 0; j < nb; ++j) {
-    __syncthreads();
-    const T ljj = sqrt(sL[j * LD + j]);
-    const T inv = static_cast<T>(1) / ljj;
-    for (int i = j + 1 + t; i < nb; i += 256) sL[i * LD + j] *= inv;
-    if (t == 0) s_diag[j] = ljj;
-    __syncthreads();
-    for (int i = j + 1 + ty; i < nb; i += 16) {
-      const T lij = sL[i * LD + j];
-      for (int c = j + 1 + tx; c <= i; c += 16) sL[i * LD + c] -= lij * sL[c * LD + j];
-    }
-  }
-  __syncthreads();
-  if (t < nb) sL[t * LD + t] = s_diag[t];
-  __syncthreads();
-  if (t < nb) {
-    const int c = t;
-    sX[c * LD + c] = static_cast<T>(1) / sL[c * LD + c];
-    for (int i = c + 1; i < nb; ++i) {
-      const T *li = sL + i * LD;
-      T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-      int p = c;
-      for (; p + 3 < i; p += 4) {
-        a0 += li[p] * sX[p * LD + c];
-        a1 += li[p + 1] * sX[(p + 1) * LD + c];
-        a2 += li[p + 2] * sX[(p + 2) * LD + c];
-        a3 += li[p + 3] * sX[(p + 3) * LD + c];
+  potrf_steps<T, NB, 0>(Lr, Xr, colj, rowj, nb, tx, ty);
+#pragma unroll
+  for (int a = 0; a < NBK; ++a)
+#pragma unroll
+    for (int b = 0; b < NBK; ++b) {
+      const int i = ty + 16 * a, c = tx + 16 * b;
+      if (i < nb && c <= i) {
+        G[static_cast<size_t>(i) * ldg + c] = Lr[a][b];
+        Winv[static_cast<size_t>(i) * ldw + c] = Xr[a][b];
       }
-      for (; p < i; ++p) a0 += li[p] * sX[p * LD + c];
-      sX[i * LD + c] = -((a0 + a1) + (a2 + a3)) / li[i];
-    }
-  }
-  __syncthreads();
-  for (int r = ty; r < nb; r += 16)
-    for (int c = tx; c <= r; c += 16) {
-      G[static_cast<size_t>(r) * ldg + c] = sL[r * LD + c];
-      Winv[static_cast<size_t>(r) * ldw + c] = sX[r * LD + c];
     }
 }
 
@@ -281,22 +350,31 @@ __global__ void __launch_bounds__(256) transpose_kernel(const T *in, size_t ld_i
   }
 }
 
+// out[r][c] = sum_s in[s][r][c] over the lower 128 x 128 tiles (c < 128 * (r / 128 + 1)),
+// slabs added in index order.  One workgroup per row.
 template <typename T>
 __global__ void __launch_bounds__(256) sum_slabs_kernel(const T *in, size_t stride, int nslabs, T *out,
-                                                        size_t count_vec) {
+                                                        size_t ld, int n) {
   using V = typename Vec16<T>::type;
   constexpr int VEC = Vec16<T>::N;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count_vec;
-       i += static_cast<size_t>(gridDim.x) * 256) {
-    V acc = *reinterpret_cast<const V *>(in + i * VEC);
+  const int r = blockIdx.x;
+  const int cend = min(n, (r / BM + 1) * BM);
+  const size_t base = static_cast<size_t>(r) * ld;
+  for (int c = threadIdx.x * VEC; c < cend; c += 256 * VEC) {
+    V acc = *reinterpret_cast<const V *>(in + base + c);
     T *ap = reinterpret_cast<T *>(&acc);
     for (int sl = 1; sl < nslabs; ++sl) {
-      const V v = *reinterpret_cast<const V *>(in + static_cast<size_t>(sl) * stride + i * VEC);
+      const V v = *reinterpret_cast<const V *>(in + static_cast<size_t>(sl) * stride + base + c);
       const T *vp = reinterpret_cast<const T *>(&v);
 #pragma unroll
-      for (int c = 0; c < VEC; ++c) ap[c] += vp[c];
+      for (int k = 0; k < VEC; ++k) ap[k] += vp[k];
     }
-    *reinterpret_cast<V *>(out + i * VEC) = acc;
+    if (c + VEC > n) {   // padding columns of the last vector stay zero
+#pragma unroll
+      for (int k = 0; k < VEC; ++k)
+        if (c + k >= n) ap[k] = 0;
+    }
+    *reinterpret_cast<V *>(out + base + c) = acc;
   }
 }
 
@@ -321,7 +399,9 @@ void launch_gemm_ab(bool lower, const GemmArgs<T> &g, hipStream_t s) {
   if (gg.ksplit < 1) gg.ksplit = 1;
   const int nt = (lower ? tm * (tm + 1) / 2 : tm * tn) * gg.ksplit;
   const int grid = (nt + kNumXcd - 1) / kNumXcd * kNumXcd;
-  if (lower) {
+  if (lower && gg.kacc > 0 && A_KMAJ == B_KMAJ) {
+    hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, true, true>), dim3(grid), dim3(GT), 0, s, gg);
+  } else if (lower) {
     hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, true>), dim3(grid), dim3(GT), 0, s, gg);
   } else {
     hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, false>), dim3(grid), dim3(GT), 0, s, gg);
@@ -341,14 +421,11 @@ void launch_gemm(bool a_kmaj, bool b_kmaj, bool lower_only, const GemmArgs<T> &g
 template <typename T>
 void cholesky_lower(T *G, size_t ldg, int n, T *W, size_t ldw, hipStream_t s) {
   constexpr int NB = CholBlock<T>::NB;
-  const size_t smem = 2 * static_cast<size_t>(NB) * (NB + 1) * sizeof(T);
-  POGS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_inv_kernel<T, NB>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
   for (int o = 0; o < n; o += NB) {
     const int nb = (n - o < NB) ? n - o : NB;
     T *Gd = G + static_cast<size_t>(o) * ldg + o;
     T *Wd = W + static_cast<size_t>(o) * ldw + o;
-    hipLaunchKernelGGL((potrf_inv_kernel<T, NB>), dim3(1), dim3(256), smem, s, Gd, ldg, nb, Wd, ldw);
+    hipLaunchKernelGGL((potrf_inv_kernel<T, NB>), dim3(1), dim3(256), 0, s, Gd, ldg, nb, Wd, ldw);
     const int rem = n - o - nb;
     if (rem > 0) {
       T *L21 = G + static_cast<size_t>(o + nb) * ldg + o;
@@ -391,9 +468,8 @@ void launch_transpose(const T *in, size_t ld_in, int rows, int cols, T *out, siz
 }
 
 template <typename T>
-void launch_sum_slabs(const T *in, size_t stride, int nslabs, T *out, size_t count, hipStream_t s) {
-  const size_t nvec = count / Vec16<T>::N;
-  hipLaunchKernelGGL(sum_slabs_kernel<T>, dim3(2048), dim3(256), 0, s, in, stride, nslabs, out, nvec);
+void launch_sum_slabs(const T *in, size_t stride, int nslabs, T *out, size_t ld, int n, hipStream_t s) {
+  hipLaunchKernelGGL(sum_slabs_kernel<T>, dim3(n), dim3(256), 0, s, in, stride, nslabs, out, ld, n);
 }
 
 template <typename T>
@@ -411,7 +487,7 @@ void launch_add_diag(T *G, size_t ldg, int n, T v, hipStream_t s) {
   template void cholesky_lower<T>(T *, size_t, int, T *, size_t, hipStream_t);                 \
   template void trtri_lower<T>(const T *, size_t, int, T *, size_t, T *, hipStream_t);         \
   template void launch_transpose<T>(const T *, size_t, int, int, T *, size_t, hipStream_t);    \
-  template void launch_sum_slabs<T>(const T *, size_t, int, T *, size_t, hipStream_t);       \
+  template void launch_sum_slabs<T>(const T *, size_t, int, T *, size_t, int, hipStream_t);       \
   template void launch_zero_upper<T>(T *, size_t, int, hipStream_t);                           \
   template void launch_add_diag<T>(T *, size_t, int, T, hipStream_t);
 POGS_INST(float)
