@@ -31,6 +31,10 @@ struct GemmArgs {
   // register accumulators are added into a second set and cleared, so a long fp32 K-sum is
   // formed as an ordered sum of short ones (same error behaviour as split-K, no slabs).
   int kacc = 0;
+  // batch > 1: `batch` independent products of the same shape; product q uses A + q*strideA,
+  // B + q*strideB, C + q*strideC (one launch for a whole TRTRI level).
+  int batch = 1;
+  size_t strideA = 0, strideB = 0, strideC = 0;
 };
 
 // A_KMAJ: op(A)(i,k) = A[k*lda + i], else A[i*lda + k].

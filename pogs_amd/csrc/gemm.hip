@@ -113,10 +113,16 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
   // range) meet in one L2.  Units beyond the real count exit.
   const int tm_ = (g.M + BM - 1) / BM, tn_ = (g.N + BN - 1) / BN;
   const int ntiles = LOWER ? tm_ * (tm_ + 1) / 2 : tm_ * tn_;
-  const int nunits = ntiles * g.ksplit;
+  const int per_batch = ntiles * g.ksplit;
+  const int nunits = per_batch * g.batch;
   const int per_xcd = (nunits + kNumXcd - 1) / kNumXcd;
-  const int unit = static_cast<int>(blockIdx.x % kNumXcd) * per_xcd + static_cast<int>(blockIdx.x / kNumXcd);
+  int unit = static_cast<int>(blockIdx.x % kNumXcd) * per_xcd + static_cast<int>(blockIdx.x / kNumXcd);
   if (unit >= nunits || static_cast<int>(blockIdx.x / kNumXcd) >= per_xcd) return;
+  const int q = unit / per_batch;
+  unit -= q * per_batch;
+  g.A += q * g.strideA;
+  g.B += q * g.strideB;
+  g.C += q * g.strideC;
   const int ks = unit / ntiles;
   const int tile = unit % ntiles;
   const int kbeg = (g.ksplit > 1) ? ks * g.kchunk : 0;
@@ -397,7 +403,8 @@ void launch_gemm_ab(bool lower, const GemmArgs<T> &g, hipStream_t s) {
   if (tm <= 0 || tn <= 0 || g.K <= 0) return;
   GemmArgs<T> gg = g;
   if (gg.ksplit < 1) gg.ksplit = 1;
-  const int nt = (lower ? tm * (tm + 1) / 2 : tm * tn) * gg.ksplit;
+  if (gg.batch < 1) gg.batch = 1;
+  const int nt = (lower ? tm * (tm + 1) / 2 : tm * tn) * gg.ksplit * gg.batch;
   const int grid = (nt + kNumXcd - 1) / kNumXcd * kNumXcd;
   if (lower && gg.kacc > 0 && A_KMAJ == B_KMAJ) {
     hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, true, true>), dim3(grid), dim3(GT), 0, s, gg);
@@ -445,19 +452,32 @@ template <typename T>
 void trtri_lower(const T *L, size_t ldg, int n, T *W, size_t ldw, T *tmp, hipStream_t s) {
   constexpr int NB = CholBlock<T>::NB;
   for (long long sz = NB; sz < n; sz *= 2) {
-    for (long long o = 0; o + sz < n; o += 2 * sz) {
-      const int na = static_cast<int>(sz);
-      const int nb = static_cast<int>((n - o - sz < sz) ? n - o - sz : sz);
-      const T *Lba = L + static_cast<size_t>(o + sz) * ldg + o;
-      const T *Waa = W + static_cast<size_t>(o) * ldw + o;
-      const T *Wbb = W + static_cast<size_t>(o + sz) * ldw + (o + sz);
-      T *Wba = W + static_cast<size_t>(o + sz) * ldw + o;
+    // pairs (a = [o, o+sz), b = [o+sz, o+2sz)) at o = 0, 2sz, 4sz, ...: all full pairs of a
+    // level go out as one batched launch per product, a ragged last pair on its own
+    const int na = static_cast<int>(sz);
+    int full = 0;
+    long long o = 0;
+    for (; o + 2 * sz <= n; o += 2 * sz) ++full;
+    auto level = [&](long long o0, int nb, int batch) {
+      const T *Lba = L + static_cast<size_t>(o0 + sz) * ldg + o0;
+      const T *Waa = W + static_cast<size_t>(o0) * ldw + o0;
+      const T *Wbb = W + static_cast<size_t>(o0 + sz) * ldw + (o0 + sz);
+      T *Wba = W + static_cast<size_t>(o0 + sz) * ldw + o0;
+      T *Tba = tmp + static_cast<size_t>(o0 + sz) * ldw + o0;
       // T = L_ba W_aa ; W_ba = -W_bb T
-      GemmArgs<T> g1{nb, na, na, Lba, ldg, Waa, ldw, tmp, ldw, static_cast<T>(1), static_cast<T>(0)};
+      GemmArgs<T> g1{nb, na, na, Lba, ldg, Waa, ldw, Tba, ldw, static_cast<T>(1), static_cast<T>(0)};
+      g1.batch = batch;
+      g1.strideA = static_cast<size_t>(2 * sz) * (ldg + 1);
+      g1.strideB = static_cast<size_t>(2 * sz) * (ldw + 1);
+      g1.strideC = g1.strideB;
       launch_gemm<T>(false, true, false, g1, s);
-      GemmArgs<T> g2{nb, na, nb, Wbb, ldw, tmp, ldw, Wba, ldw, static_cast<T>(-1), static_cast<T>(0)};
+      GemmArgs<T> g2{nb, na, nb, Wbb, ldw, Tba, ldw, Wba, ldw, static_cast<T>(-1), static_cast<T>(0)};
+      g2.batch = batch;
+      g2.strideA = g2.strideB = g2.strideC = g1.strideB;
       launch_gemm<T>(false, true, false, g2, s);
-    }
+    };
+    if (full > 0) level(0, na, full);
+    if (o + sz < n) level(o, static_cast<int>(n - o - sz), 1);
   }
 }
 

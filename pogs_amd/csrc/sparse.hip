@@ -14,6 +14,15 @@
 // streams a row block's values / indices with fully coalesced loads, stages the
 // products val * x[ind] in LDS, then reduces each row from LDS (CSR-stream);
 // rows longer than a tile are reduced by the whole workgroup.
+//
+// Column-blocked copy (the one the solver normally runs on): a random gather x[ind] is one
+// 64-byte L2 request per non-zero and that request rate, not HBM, bounds the plain kernel
+// (~1 TB/s at C4).  So each CSR is also stored split into column blocks of 28672 (fp32) or
+// 10240 (fp64) columns: non-zeros ordered by (column block, row), local column as uint16 (6 instead of 8
+// bytes per fp32 non-zero).  A workgroup keeps its block's slice of x in LDS (112 KB) and
+// gathers from there; per-(block, row) partial sums go to a buffer that a second kernel adds
+// in block order (deterministic) and hands to the row functor.  One block (n <= 28672 fp32
+// columns): no partials, the functor runs in the first kernel.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -35,6 +44,11 @@ namespace {
 constexpr int kSpTpb = 256;
 constexpr int kSpCap = 4096;       // non-zeros staged in LDS per row block
 constexpr int kSpMaxRows = 2048;   // rows per block cap (balance when rows are empty)
+constexpr int kBlkTpb = 1024;      // column-blocked kernel: one workgroup per CU
+// LDS bytes for the x slice of one column block (+ 2 x kSpCap staged products <= 160 KB)
+template <typename T> struct BlkCfg { static constexpr int BYTES = sizeof(T) == 4 ? 112 * 1024 : 80 * 1024;
+                                      static constexpr int BW = BYTES / sizeof(T); };
+constexpr int kBlkU = kSpCap / kBlkTpb; // non-zeros per thread per row block
 
 // ---------------------------------------------------------------------------
 // Row functors (one thread per finished row; scalars accumulate in doubles)
@@ -213,6 +227,206 @@ __global__ void __launch_bounds__(kSpTpb) spmv_kernel(Csr<T> A, const T *__restr
 }
 
 // ---------------------------------------------------------------------------
+// Column-blocked SpMV
+// ---------------------------------------------------------------------------
+// Pseudo-row q = cb * nrows + r holds the non-zeros of row r whose column lies in block cb;
+// (val, loc, bptr) is an ordinary CSR over the ncb * nrows pseudo-rows with block-local
+// uint16 columns, `blocks` its row blocks (none spans two column blocks).
+
+template <typename T>
+struct BlkRegs {
+  T v[kBlkU];
+  unsigned short l[kBlkU];
+  int bp[2];   // row offsets t and t + kBlkTpb of the row block
+};
+constexpr int kBlkMaxRows = 2 * kBlkTpb - 1;   // rows per row block: their offsets fit BlkRegs::bp
+
+// DIRECT (ncb == 1): the row functor runs here; otherwise part[q] receives the partial sums.
+// The structure arrays are separate __restrict__ arguments (not struct members) so that the
+// compiler may read the row-block descriptors through the scalar cache: as vector loads their
+// waits (vmcnt is in order) would drain the prefetched non-zeros of the next row blocks.
+struct BcsrDims {
+  int nrows, ncols, ncb, bw, nblocks;
+};
+
+template <typename T, bool SQ, bool DIRECT, typename Op>
+__global__ void __launch_bounds__(kBlkTpb) spmv_blocked_kernel(const T *__restrict__ a_val,
+                                                                const unsigned short *__restrict__ a_loc,
+                                                                const int *__restrict__ a_bptr,
+                                                                const int2 *__restrict__ a_desc, BcsrDims A,
+                                                                const T *__restrict__ x, const double *x_nrm2, Op op,
+                                                                T *__restrict__ part, double *scalar_partials) {
+  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char blk_smem[];
+  T *s_x = reinterpret_cast<T *>(blk_smem);                    // [bw]
+  T *s_prod = s_x + BlkCfg<T>::BW;                             // [2][kSpCap]
+  unsigned short *s_ptr = reinterpret_cast<unsigned short *>(s_prod + 2 * kSpCap);   // [2][2 kBlkTpb]
+  __shared__ T s_long[kBlkTpb / 64];
+  __shared__ double s_red[NS * (kBlkTpb / 64)];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  double sacc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
+  T xs = 1;
+  if (x_nrm2) xs = static_cast<T>(1.0 / sqrt(*x_nrm2));
+
+  // contiguous share of the row blocks: the column block changes at most a few times
+  const int d0 = static_cast<int>(static_cast<long long>(A.nblocks) * blockIdx.x / gridDim.x);
+  const int d1 = static_cast<int>(static_cast<long long>(A.nblocks) * (blockIdx.x + 1) / gridDim.x);
+  int cur_cb = -1, buf = 0;
+
+  // a_desc[d] = {first pseudo-row, first non-zero} of row block d (entry nblocks closes the
+  // last one).  The descriptors of the next four row blocks ride in scalar registers, loaded
+  // one row block ahead of their first use, so no load sits on the critical path.
+  auto desc_at = [&](int d) { return a_desc[min(d, A.nblocks)]; };
+  int2 Da = desc_at(d0), Db = desc_at(d0 + 1), Dc = desc_at(d0 + 2), Dd = desc_at(d0 + 3);
+
+  // values / local columns of row block d = [lo, hi) into registers (nothing for a long row)
+  auto fetch = [&](int d, int2 lo, int2 hi, BlkRegs<T> &R) {
+    if (d >= d1) return;
+    const int q0 = lo.x, nq = hi.x - lo.x;
+    const int p0 = lo.y, cnt = hi.y - lo.y;
+    if (cnt > kSpCap) return;
+    R.bp[0] = (t <= nq) ? a_bptr[q0 + t] : 0;
+    R.bp[1] = (t + kBlkTpb <= nq) ? a_bptr[q0 + kBlkTpb + t] : 0;
+#pragma unroll
+    for (int u = 0; u < kBlkU; ++u) {
+      const int k = u * kBlkTpb + t;
+      const bool ok = k < cnt;
+      R.v[u] = ok ? a_val[p0 + k] : static_cast<T>(0);
+      R.l[u] = ok ? a_loc[p0 + k] : static_cast<unsigned short>(0);
+    }
+  };
+  // consumes (Da, Db) = row block d, refills R with row block d + 2 = (Dc, Dd), then shifts
+  auto process = [&](int d, BlkRegs<T> &R) {
+    const int2 De = desc_at(d + 4);
+    const int q0 = Da.x, q1 = Db.x;
+    const int cb = q0 / A.nrows;
+    if (cb != cur_cb) {   // uniform
+      __syncthreads();
+      const int c0 = cb * A.bw, w = min(A.bw, A.ncols - c0);
+      for (int c = t; c < w; c += kBlkTpb) s_x[c] = x[c0 + c] * xs;
+      cur_cb = cb;
+      __syncthreads();
+    }
+    const int p0 = Da.y, cnt = Db.y - p0;
+    const int rbase = cb * A.nrows;
+    if (cnt > kSpCap) {
+      // one long pseudo-row: the whole workgroup strides over it
+      T sl = 0;
+      for (int k = t; k < cnt; k += kBlkTpb) {
+        T v = a_val[p0 + k];
+        if (SQ) v *= v;
+        sl += v * s_x[a_loc[p0 + k]];
+      }
+      sl = dev::wave_sum(sl);
+      if (lane == 0) s_long[wave] = sl;
+      __syncthreads();
+      if (t == 0) {
+        T tot = 0;
+#pragma unroll
+        for (int w = 0; w < kBlkTpb / 64; ++w) tot += s_long[w];
+        if (DIRECT) op.row(q0 - rbase, tot, sacc);
+        else part[q0] = tot;
+      }
+      __syncthreads();
+      fetch(d + 2, Dc, Dd, R);
+      Da = Db; Db = Dc; Dc = Dd; Dd = De;
+      return;
+    }
+    T *sp = s_prod + buf * kSpCap;
+    unsigned short *spt = s_ptr + buf * (2 * kBlkTpb);
+#pragma unroll
+    for (int u = 0; u < kBlkU; ++u) {
+      const int k = u * kBlkTpb + t;
+      if (k < cnt) sp[k] = (SQ ? R.v[u] * R.v[u] : R.v[u]) * s_x[R.l[u]];
+    }
+    spt[t] = static_cast<unsigned short>(R.bp[0] - p0);   // entries past nq are never read
+    spt[kBlkTpb + t] = static_cast<unsigned short>(R.bp[1] - p0);
+    fetch(d + 2, Dc, Dd, R);   // in flight during this and the next row block's reduction
+    __syncthreads();
+    const int nq = q1 - q0;
+    int tpr = 1;  // threads per row: a power of two <= 64, about a quarter of the mean row length
+    while (tpr < 64 && tpr * 4 < cnt / (nq > 0 ? nq : 1)) tpr <<= 1;
+    const int rpp = kBlkTpb / tpr, lir = t % tpr, slot = t / tpr;
+    for (int base = 0; base < nq; base += rpp) {
+      const int q = q0 + base + slot;
+      T sr = 0;
+      if (q < q1) {
+        const int a = spt[q - q0], e = spt[q - q0 + 1];
+        for (int k = a + lir; k < e; k += tpr) sr += sp[k];
+      }
+      for (int off = tpr >> 1; off > 0; off >>= 1) sr += __shfl_xor(sr, off, 64);
+      if (lir == 0 && q < q1) {
+        if (DIRECT) op.row(q - rbase, sr, sacc);
+        else part[q] = sr;
+      }
+    }
+    buf ^= 1;   // the next row block stages into the other half: one barrier per row block
+    Da = Db; Db = Dc; Dc = Dd; Dd = De;
+  };
+
+  BlkRegs<T> R0, R1;
+  fetch(d0, Da, Db, R0);
+  fetch(d0 + 1, Db, Dc, R1);
+  for (int d = d0; d < d1; d += 2) {
+    process(d, R0);
+    if (d + 1 < d1) process(d + 1, R1);
+  }
+  if (DIRECT && Op::NS > 0) {
+    __syncthreads();
+    dev::block_sum<NS, kBlkTpb>(sacc, s_red);
+    if (t == 0) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) scalar_partials[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
+    }
+  }
+}
+
+// row r: sum of its ncb partial sums in block order, then the row functor
+template <typename T, typename Op>
+__global__ void __launch_bounds__(256) reduce_parts_kernel(const T *__restrict__ part, int nrows, int ncb, Op op,
+                                                           double *scalar_partials) {
+  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+  __shared__ double s_red[NS * 4];
+  double sacc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < nrows; r += gridDim.x * 256) {
+    T sum = part[r];
+    for (int cb = 1; cb < ncb; ++cb) sum += part[static_cast<size_t>(cb) * nrows + r];
+    op.row(r, sum, sacc);
+  }
+  if (Op::NS > 0) {
+    dev::block_sum<NS, 256>(sacc, s_red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) scalar_partials[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
+    }
+  }
+}
+
+// cnt[cb * nrows + r] = non-zeros of row r in column block cb (one thread per row)
+__global__ void bcsr_count_kernel(const int *ind, const int *ptr, int nrows, int bw, int *cnt) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x)
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) cnt[static_cast<size_t>(ind[k] / bw) * nrows + r] += 1;
+}
+
+// copies row r's non-zeros to their pseudo-rows, keeping their order (one thread per row);
+// cursor starts as a copy of bptr
+template <typename T>
+__global__ void bcsr_fill_kernel(const T *val, const int *ind, const int *ptr, int nrows, int bw, int *cursor,
+                                 T *bval, unsigned short *loc) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x)
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
+      const int c = ind[k], cb = c / bw;
+      const int pos = cursor[static_cast<size_t>(cb) * nrows + r]++;
+      bval[pos] = val[k];
+      if (loc) loc[pos] = static_cast<unsigned short>(c - cb * bw);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // One-time structure kernels
 // ---------------------------------------------------------------------------
 __global__ void count_cols_kernel(const int *ind, size_t nnz, int *cnt) {
@@ -244,6 +458,87 @@ __global__ void __launch_bounds__(1024) scan_kernel(const int *cnt, int n, int *
     run += cnt[i];
   }
   if (t == 1023) ptr[n] = s_tot[1023];
+}
+
+// Three-kernel exclusive scan for long arrays: per-tile (8192 items) local scan + tile totals,
+// scan_kernel over the totals, then the tile offsets are added.
+constexpr int kScanTile = 8192;
+
+__global__ void __launch_bounds__(1024) scan_tiles_kernel(const int *cnt, int n, int *out, int *tile_tot) {
+  __shared__ int s_w[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int base = blockIdx.x * kScanTile + t * 8;
+  int v[8], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] = (base + k < n) ? cnt[base + k] : 0;
+    sum += v[k];
+  }
+  // inclusive scan of the thread sums: within the wave by shuffles, then across the 16 waves
+  int inc = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += s_w[w];
+  int run = woff + inc - sum;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (t == 1023) tile_tot[blockIdx.x] = woff + inc;
+}
+
+__global__ void __launch_bounds__(1024) scan_add_kernel(int *out, int n, const int *tile_off, int ntiles) {
+  const int base = blockIdx.x * kScanTile + threadIdx.x * 8;
+  const int off = tile_off[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (base + k < n) out[base + k] += off;
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_off[ntiles];
+}
+
+// Row blocks of the column-blocked copy, found in parallel.  Window w holds the pseudo-rows
+// whose first non-zero lies in [w, w + 1) * kBlkSlot; win_start[w] is its first pseudo-row.
+// Pseudo-row q starts a row block when it is the first of its column block or of its window,
+// every kBlkMaxRows rows after the window start, and when it or its predecessor is longer than
+// kSpCap - kBlkSlot.  A row block therefore holds < kSpCap non-zeros unless it is one long row.
+constexpr int kBlkSlot = kSpCap - 512;
+
+__global__ void bcsr_windows_kernel(const int *bptr, int nq, int nwin, int *win_start) {
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nwin; w += gridDim.x * blockDim.x) {
+    const long long target = static_cast<long long>(w) * kBlkSlot;
+    int lo = 0, hi = nq;   // first q with bptr[q] >= target
+    while (lo < hi) {
+      const int mid = lo + (hi - lo) / 2;
+      if (bptr[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    win_start[w] = lo;
+  }
+}
+
+__global__ void bcsr_flag_kernel(const int *bptr, const int *win_start, int nq, int nrows, int *flag) {
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+    bool f = (q % nrows == 0);
+    if (!f) {
+      const int a = bptr[q - 1], b = bptr[q], c = bptr[q + 1];
+      const int w = b / kBlkSlot;
+      f = (w != a / kBlkSlot) || ((q - win_start[w]) % kBlkMaxRows == 0) || (c - b > kSpCap - kBlkSlot) ||
+          (b - a > kSpCap - kBlkSlot);
+    }
+    flag[q] = f ? 1 : 0;
+  }
+}
+
+__global__ void bcsr_compact_kernel(const int *flag, const int *pos, const int *bptr, int nq, int2 *desc) {
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x)
+    if (flag[q]) desc[pos[q]] = make_int2(q, bptr[q]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) desc[pos[nq]] = make_int2(nq, bptr[nq]);
 }
 
 // scatter (row, val) of every non-zero into its column segment (order within a
@@ -339,9 +634,16 @@ template <typename T>
 struct DevCsr {
   DevBuf<T> val;
   DevBuf<int> ind, ptr, blocks;
-  int nrows = 0, nblocks = 0;
+  int nrows = 0, ncols = 0, nblocks = 0;
   size_t nnz = 0;
   Csr<T> view() const { return Csr<T>{val.p, ind.p, ptr.p, blocks.p, nrows, nblocks}; }
+  // column-blocked copy (see the file header); ncb == 0: not built, the plain kernel runs
+  DevBuf<T> bval, part;
+  DevBuf<unsigned short> loc;
+  DevBuf<int> bptr;
+  DevBuf<int2> bdesc;
+  int ncb = 0, nbblocks = 0;
+  BcsrDims bdims() const { return BcsrDims{nrows, ncols, ncb, BlkCfg<T>::BW, nbblocks}; }
 };
 
 std::vector<int> make_row_blocks(const std::vector<int> &ptr, int nrows) {
@@ -510,7 +812,7 @@ class SparseSolver final : public SolverBase {
     DevBuf<int> cnt(c1 + 1), cursor(c1 + 1);
     cnt.zero(s);
     if (nnz_) hipLaunchKernelGGL(count_cols_kernel, dim3(2048), dim3(256), 0, s, first.ind.p, nnz_, cnt.p);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, cnt.p, c1, second.ptr.p);
+    exclusive_scan(cnt.p, c1, second.ptr.p);
     POGS_HIP_CHECK(hipMemcpyAsync(cursor.p, second.ptr.p, (c1 + 1) * sizeof(int), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(fill_transpose_kernel<T>, dim3(2048), dim3(256), 0, s, first.val.p, first.ind.p, first.ptr.p,
                        r1, cursor.p, second.val.p, second.ind.p);
@@ -527,9 +829,83 @@ class SparseSolver final : public SolverBase {
     };
     set_blocks(first, hptr);
     set_blocks(second, hptr2);
+    first.ncols = c1;
+    second.ncols = r1;
+    const char *ev = std::getenv("POGS_AMD_SPMV");
+    if (!(ev && ev[0] == 'p')) {   // POGS_AMD_SPMV=plain keeps the plain CSR kernel (testing aid)
+      build_blocked(first);
+      build_blocked(second);
+    }
     if (ord == ROW_MAJ) { A_ = std::move(first); At_ = std::move(second); }
     else { At_ = std::move(first); A_ = std::move(second); }
     first_is_A_ = (ord == ROW_MAJ);
+  }
+
+  // ptr[0..n] = exclusive scan of cnt[0..n)
+  void exclusive_scan(const int *cnt, int n, int *ptr) {
+    hipStream_t s = ctx_.stream;
+    if (n <= 4 * kScanTile) {
+      hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, cnt, n, ptr);
+      return;
+    }
+    const int ntiles = (n + kScanTile - 1) / kScanTile;
+    DevBuf<int> tot(ntiles), off(ntiles + 1);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(ntiles), dim3(1024), 0, s, cnt, n, ptr, tot.p);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, tot.p, ntiles, off.p);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(ntiles), dim3(1024), 0, s, ptr, n, off.p, ntiles);
+    ctx_.sync();   // temporaries are freed at scope exit
+  }
+
+  // Column-blocked copy of M (structure now, values again after every rescaling).  Skipped
+  // when the per-(block, row) bookkeeping would outweigh the non-zeros themselves.
+  void build_blocked(DevCsr<T> &M) {
+    hipStream_t s = ctx_.stream;
+    constexpr int BW = BlkCfg<T>::BW;
+    const int ncb = (M.ncols + BW - 1) / BW;
+    const long long nq = static_cast<long long>(ncb) * M.nrows;
+    if (M.nnz == 0 || nq >= (1LL << 30) || (ncb > 1 && nq > 2 * static_cast<long long>(M.nnz) + (1 << 20))) return;
+    DevBuf<int> cnt(nq + 1);
+    cnt.zero(s);
+    const int g = std::max(1, std::min((M.nrows + 255) / 256, ctx_.num_cu * 16));
+    hipLaunchKernelGGL(bcsr_count_kernel, dim3(g), dim3(256), 0, s, M.ind.p, M.ptr.p, M.nrows, BW, cnt.p);
+    M.bptr.alloc(nq + 1);
+    exclusive_scan(cnt.p, static_cast<int>(nq), M.bptr.p);
+    M.bval.alloc(M.nnz);
+    M.loc.alloc(M.nnz);
+    M.ncb = ncb;
+    fill_blocked(M, true);
+    {
+      const int nwin = static_cast<int>(M.nnz / kBlkSlot) + 1;
+      DevBuf<int> flag(nq + 1), pos(nq + 1), win(nwin);
+      const int gq = static_cast<int>(std::min<long long>((nq + 255) / 256, ctx_.num_cu * 32));
+      hipLaunchKernelGGL(bcsr_windows_kernel, dim3((nwin + 255) / 256), dim3(256), 0, s, M.bptr.p,
+                         static_cast<int>(nq), nwin, win.p);
+      hipLaunchKernelGGL(bcsr_flag_kernel, dim3(gq), dim3(256), 0, s, M.bptr.p, win.p, static_cast<int>(nq), M.nrows,
+                         flag.p);
+      exclusive_scan(flag.p, static_cast<int>(nq), pos.p);
+      int nb = 0;
+      POGS_HIP_CHECK(hipMemcpyAsync(&nb, pos.p + nq, sizeof(int), hipMemcpyDeviceToHost, s));
+      ctx_.sync();
+      M.nbblocks = nb;
+      M.bdesc.alloc(nb + 1);
+      hipLaunchKernelGGL(bcsr_compact_kernel, dim3(gq), dim3(256), 0, s, flag.p, pos.p, M.bptr.p, static_cast<int>(nq),
+                         M.bdesc.p);
+      ctx_.sync();
+    }
+    if (ncb > 1) M.part.alloc(nq);
+  }
+
+  // (re)writes the blocked values from M.val; with_loc also the local columns
+  void fill_blocked(DevCsr<T> &M, bool with_loc) {
+    if (M.ncb == 0) return;
+    hipStream_t s = ctx_.stream;
+    const size_t nq = static_cast<size_t>(M.ncb) * M.nrows;
+    DevBuf<int> cursor(nq + 1);
+    POGS_HIP_CHECK(hipMemcpyAsync(cursor.p, M.bptr.p, (nq + 1) * sizeof(int), hipMemcpyDeviceToDevice, s));
+    const int g = std::max(1, std::min((M.nrows + 255) / 256, ctx_.num_cu * 16));
+    hipLaunchKernelGGL(bcsr_fill_kernel<T>, dim3(g), dim3(256), 0, s, M.val.p, M.ind.p, M.ptr.p, M.nrows,
+                       BlkCfg<T>::BW, cursor.p, M.bval.p, with_loc ? M.loc.p : nullptr);
+    ctx_.sync();   // cursor is freed at scope exit
   }
 
   void alloc_state() {
@@ -553,10 +929,32 @@ class SparseSolver final : public SolverBase {
   void spmv(const DevCsr<T> &M, const T *x, const double *x_nrm2, const Op &op, double *scalar_out, int,
             bool timed = false) {
     hipStream_t s = ctx_.stream;
-    const int grid = std::max(1, std::min(M.nblocks, spmv_grid_));
+    int grid;
     if (timed) ctx_.stream_timer.begin(s);
-    hipLaunchKernelGGL((spmv_kernel<T, SQ, Op>), dim3(grid), dim3(kSpTpb), 0, s, M.view(), x, x_nrm2, op,
-                       ctx_.spart.p);
+    if (M.ncb > 0) {
+      constexpr size_t smem = BlkCfg<T>::BYTES + 2 * kSpCap * sizeof(T) + 4 * kBlkTpb * sizeof(unsigned short);
+      const int g1 = std::max(1, std::min(M.nbblocks, ctx_.num_cu));
+      if (M.ncb == 1) {
+        static const bool once = allow_smem(reinterpret_cast<const void *>(&spmv_blocked_kernel<T, SQ, true, Op>), smem);
+        (void)once;
+        hipLaunchKernelGGL((spmv_blocked_kernel<T, SQ, true, Op>), dim3(g1), dim3(kBlkTpb), smem, s, M.bval.p,
+                           M.loc.p, M.bptr.p, M.bdesc.p, M.bdims(), x, x_nrm2, op, static_cast<T *>(nullptr),
+                           ctx_.spart.p);
+        grid = g1;
+      } else {
+        static const bool once = allow_smem(reinterpret_cast<const void *>(&spmv_blocked_kernel<T, SQ, false, Op>), smem);
+        (void)once;
+        hipLaunchKernelGGL((spmv_blocked_kernel<T, SQ, false, Op>), dim3(g1), dim3(kBlkTpb), smem, s, M.bval.p,
+                           M.loc.p, M.bptr.p, M.bdesc.p, M.bdims(), x, x_nrm2, op, M.part.p, ctx_.spart.p);
+        grid = std::max(1, std::min((M.nrows + 255) / 256, spmv_grid_));
+        hipLaunchKernelGGL((reduce_parts_kernel<T, Op>), dim3(grid), dim3(256), 0, s, M.part.p, M.nrows, M.ncb, op,
+                           ctx_.spart.p);
+      }
+    } else {
+      grid = std::max(1, std::min(M.nblocks, spmv_grid_));
+      hipLaunchKernelGGL((spmv_kernel<T, SQ, Op>), dim3(grid), dim3(kSpTpb), 0, s, M.view(), x, x_nrm2, op,
+                         ctx_.spart.p);
+    }
     if (timed) {
       ctx_.stream_timer.end(s);
       ++timed_spmvs_;
@@ -565,6 +963,10 @@ class SparseSolver final : public SolverBase {
       SumJob j{ctx_.spart.p, grid, Op::NS, scalar_out};
       launch_sum_jobs(&j, 1, s);
     }
+  }
+  static bool allow_smem(const void *fn, size_t bytes) {
+    POGS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+    return true;
   }
 
   // MatrixSparse::Equil (matrix_sparse.cpp:158-242): Sinkhorn-Knopp on the squared
@@ -596,6 +998,8 @@ class SparseSolver final : public SolverBase {
                     static_cast<T>(std::sqrt(static_cast<double>(std::min(m_, n_))));
     launch_scal<T>(A_.val.p, static_cast<T>(1) / normA, nnz_, s);
     launch_scal<T>(At_.val.p, static_cast<T>(1) / normA, nnz_, s);
+    fill_blocked(A_, false);
+    fill_blocked(At_, false);
     const T invs = static_cast<T>(1) / std::sqrt(normA);
     launch_scal<T>(d_.p, invs, m_, s);
     launch_scal<T>(e_.p, invs, n_, s);

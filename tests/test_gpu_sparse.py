@@ -190,3 +190,54 @@ def test_sparse_warm_start_matches_oracle():
         r3 = s.solve(f2, g2)
     _check(r2, w2, 1e-6, 2)
     _check(r3, cold, 1e-6, 2)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_column_blocked_spmv_several_blocks(dtype):
+    """Shapes past one LDS column block (28672 fp32 / 10240 fp64 columns) in both directions:
+    partial sums per (block, row) + ordered reduction; an empty row, a long row, duplicates."""
+    pogs = _pogs()
+    rng = np.random.default_rng(5)
+    m, n = 70000, 61000
+    k = 6
+    rows = np.repeat(np.arange(m), k)
+    cols = rng.integers(0, n, m * k)
+    vals = rng.standard_normal(m * k)
+    # one long row (> 4096 non-zeros in a single column block) and one empty row
+    long_cols = rng.choice(20000, 9000, replace=False)
+    rows = np.concatenate([rows[rows != 17], np.full(9000, 12345)])
+    cols = np.concatenate([cols[: len(rows) - 9000], long_cols])
+    vals = np.concatenate([vals[: len(rows) - 9000], rng.standard_normal(9000)])
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(m, n)).astype(dtype)
+    A.sum_duplicates()
+    assert A.indptr[18] == A.indptr[17]
+    x = rng.standard_normal(n).astype(dtype)
+    y = rng.standard_normal(m).astype(dtype)
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    A.sort_indices()
+    with pogs.Solver(A, dtype=dtype) as s:
+        from pogs_amd import _lib
+
+        buf = np.zeros(A.nnz, dtype)
+        nrm = ctypes.c_double()
+        assert _lib.lib.PogsAmdGetEquil(s._h, buf.ctypes.data_as(ctypes.c_void_p), None, None, ctypes.byref(nrm)) == 0
+        As = sp.csr_matrix((buf.astype(np.float64), A.indices, A.indptr), shape=(m, n))
+        got = s.mul("n", 1.0, x, 0.0, np.zeros(m, dtype))
+        assert relerr(got, As @ x.astype(np.float64)) < tol
+        got_t = s.mul("t", 2.0, y, 0.5, x.copy())
+        assert relerr(got_t, 2.0 * (As.T @ y.astype(np.float64)) + 0.5 * x) < tol
+
+
+def test_plain_csr_kernel_still_matches(monkeypatch):
+    """POGS_AMD_SPMV=plain keeps the un-blocked CSR-stream kernel (the fallback for shapes whose
+    per-(block, row) bookkeeping would outweigh the non-zeros): same solve, same iterations."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.csr_lasso(3000, 800, 20, seed=4, dtype=np.float64)
+    blocked = pogs.solve_lasso(A, b, 0.1)
+    monkeypatch.setenv("POGS_AMD_SPMV", "plain")
+    plain = pogs.solve_lasso(A, b, 0.1)
+    assert plain["status"] == blocked["status"] == 0
+    assert abs(int(plain["iterations"]) - int(blocked["iterations"])) <= 1
+    assert relerr(plain["x"], blocked["x"]) < 1e-8
