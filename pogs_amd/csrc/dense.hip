@@ -535,6 +535,14 @@ class DenseSolver final : public SolverBase {
       // where the memory cap leaves K ranges longer than ~6.4k rows the unit itself sums in chunks
       const int nacc = (g.kchunk + 6399) / 6400;
       g.kacc = nacc > 1 ? static_cast<int>(round_up((g.kchunk + nacc - 1) / nacc, 32)) : 0;
+      DevBuf<int> tmap;
+      if (k_ > 16 * 128 && k_ < 65536 * 128) {
+        const std::vector<int> order = gram_tile_order(k_);
+        tmap.alloc(order.size());
+        POGS_HIP_CHECK(hipMemcpyAsync(tmap.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        ctx_.sync();   // order is a host temporary
+        g.tile_map = tmap.p;
+      }
       launch_gemm<T>(tall_, tall_, true, g, s);
       if (ksplit > 1) {
         launch_sum_slabs<T>(slabs.p, slab, ksplit, G, ld, k_, s);

@@ -10,6 +10,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace pogs_amd {
@@ -35,7 +37,14 @@ struct GemmArgs {
   // B + q*strideB, C + q*strideC (one launch for a whole TRTRI level).
   int batch = 1;
   size_t strideA = 0, strideB = 0, strideC = 0;
+  // optional tile order (device pointer, one entry (tile_i << 16 | tile_j) per computed tile):
+  // workgroups that run together then share operand panels in L2 (see gram_tile_order)
+  const int *tile_map = nullptr;
 };
+
+// Lower-triangular tile order in 8 x 8 super-tiles for an n x n Gram product: the ~64
+// workgroups an XCD runs at a time then touch 16 operand panels instead of 65.
+std::vector<int> gram_tile_order(int n);
 
 // A_KMAJ: op(A)(i,k) = A[k*lda + i], else A[i*lda + k].
 // B_KMAJ: op(B)(k,j) = B[k*ldb + j], else B[j*ldb + k].

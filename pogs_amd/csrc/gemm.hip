@@ -129,7 +129,11 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
   const int kend = (g.ksplit > 1) ? ((kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K) : g.K;
   T *Cout = g.C + static_cast<size_t>(ks) * g.csplit_stride;
   int ti, tj;
-  if (LOWER) {
+  if (g.tile_map) {
+    const int e = g.tile_map[tile];
+    ti = e >> 16;
+    tj = e & 0xffff;
+  } else if (LOWER) {
     const int p = tile;
     ti = static_cast<int>((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
     while (ti * (ti + 1) / 2 > p) --ti;
@@ -416,6 +420,22 @@ void launch_gemm_ab(bool lower, const GemmArgs<T> &g, hipStream_t s) {
 }
 
 }  // namespace
+
+std::vector<int> gram_tile_order(int n) {
+  constexpr int G = 8;
+  const int tm = (n + BM - 1) / BM;
+  std::vector<int> order;
+  order.reserve(static_cast<size_t>(tm) * (tm + 1) / 2);
+  const int sm = (tm + G - 1) / G;
+  for (int I = 0; I < sm; ++I)
+    for (int J = 0; J <= I; ++J)
+      for (int a = 0; a < G; ++a)
+        for (int b = 0; b < G; ++b) {
+          const int ti = I * G + a, tj = J * G + b;
+          if (ti < tm && tj <= ti) order.push_back((ti << 16) | tj);
+        }
+  return order;
+}
 
 template <typename T>
 void launch_gemm(bool a_kmaj, bool b_kmaj, bool lower_only, const GemmArgs<T> &g, hipStream_t s) {

@@ -120,14 +120,28 @@ struct SumJobs {
 };
 
 __global__ void __launch_bounds__(256) sum_jobs_kernel(SumJobs jobs) {
+  // the whole workgroup strides over the partials of one scalar at a time (independent loads,
+  // four in flight per thread), then a fixed-order wave / workgroup reduction
+  __shared__ double s_w[4];
   const SumJob job = jobs.j[blockIdx.x];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int stride = job.stride > 0 ? job.stride : job.ns;
-  for (int k = wave; k < job.ns; k += 4) {
-    double s = 0;
-    for (int b = lane; b < job.nparts; b += 64) s += job.partials[static_cast<size_t>(b) * stride + job.offset + k];
-    s = dev::wave_sum(s);
-    if (lane == 0) job.out[k] = s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const size_t stride = job.stride > 0 ? job.stride : job.ns;
+  for (int k = 0; k < job.ns; ++k) {
+    const double *p = job.partials + job.offset + k;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int b = t;
+    for (; b + 768 < job.nparts; b += 1024) {
+      s0 += p[static_cast<size_t>(b) * stride];
+      s1 += p[static_cast<size_t>(b + 256) * stride];
+      s2 += p[static_cast<size_t>(b + 512) * stride];
+      s3 += p[static_cast<size_t>(b + 768) * stride];
+    }
+    for (; b < job.nparts; b += 256) s0 += p[static_cast<size_t>(b) * stride];
+    double s = dev::wave_sum((s0 + s1) + (s2 + s3));
+    if (lane == 0) s_w[wave] = s;
+    __syncthreads();
+    if (t == 0) job.out[k] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    __syncthreads();
   }
 }
 

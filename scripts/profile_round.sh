@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round profile of the bench command on the GPU box.  Writes into gpurun_out/prof_<tag>/:
+#   bench.json                plain run (no profiler)
+#   kernel_stats.csv          rocprofv3 --kernel-trace --stats summary of the same command
+#   pmc_traffic.json          FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes, corrected)
+# usage: profile_round.sh <tag>       (then copy the three files into profiles/)
+tag=${1:-r01}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof_$tag
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/kt.log 2>&1
+db=$(find $O/kt -name "*.db" | head -1)
+python $R/scripts/rocpd_summary.py $db $O/kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o g -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/pmc_$c.log 2>&1
+done
+python $R/scripts/pmc_summary.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json
+rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+cat $O/bench.json
