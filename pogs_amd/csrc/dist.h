@@ -8,6 +8,13 @@
 // RCCL is bound at run time with dlopen: if the process already has a librccl
 // (PyTorch ships its own copy) that instance is reused, so the library never
 // ends up with two RCCL / HIP runtimes in one address space.
+//
+// Test transport: a unique id that starts with "POGSLOCAL:" selects an in-process
+// communicator instead of RCCL -- the ranks are threads of one process (each with its
+// own solver, possibly on the same GPU), buffers are staged through the host and summed
+// in rank order.  It exists so that the row-sharded decomposition of the engine itself
+// can be verified on a single GPU (RCCL refuses two ranks on one device); it is not a
+// performance path.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,7 +33,7 @@ class DistComm {
 
   // Collective: every rank calls with the same unique id.
   void init(int rank, int world, const char *unique_id);
-  bool active() const { return comm_ != nullptr; }
+  bool active() const { return comm_ != nullptr || local_ != nullptr; }
   int rank() const { return rank_; }
   int world() const { return world_; }
 
@@ -43,6 +50,7 @@ class DistComm {
   void reduce_raw(void *buf, size_t count, int dtype, hipStream_t stream) const;
   int rank_ = 0, world_ = 1;
   void *comm_ = nullptr;
+  void *local_ = nullptr;   // std::shared_ptr<LocalGroup>* (test transport)
 };
 
 }  // namespace pogs_amd

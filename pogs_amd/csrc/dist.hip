@@ -3,8 +3,14 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <mutex>
+#include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -61,12 +67,72 @@ void check(int r, const char *what) {
   }
 }
 
+// ---- in-process test transport (see dist.h) --------------------------------------------
+constexpr char kLocalTag[] = "POGSLOCAL:";
+
+struct LocalGroup {
+  int world = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  unsigned long long gen = 0;
+  std::vector<std::vector<unsigned char>> slots;
+
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const unsigned long long g = gen;
+    if (++arrived == world) {
+      arrived = 0;
+      ++gen;
+      cv.notify_all();
+      return;
+    }
+    if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g; }))
+      throw Error("local communicator: a rank did not reach the collective within 120 s");
+  }
+};
+
+std::shared_ptr<LocalGroup> local_group(const std::string &key, int world) {
+  static std::mutex mu;
+  static std::map<std::string, std::weak_ptr<LocalGroup>> groups;
+  std::lock_guard<std::mutex> lk(mu);
+  std::shared_ptr<LocalGroup> g = groups[key].lock();
+  if (!g) {
+    g = std::make_shared<LocalGroup>();
+    g->world = world;
+    g->slots.resize(world);
+    groups[key] = g;
+  }
+  POGS_CHECK(g->world == world, "local communicator: ranks disagree on the world size");
+  return g;
+}
+
+template <typename T>
+void local_allreduce(LocalGroup &g, int rank, T *buf, size_t count, hipStream_t stream) {
+  const size_t bytes = count * sizeof(T);
+  std::vector<unsigned char> &mine = g.slots[rank];
+  mine.resize(bytes);
+  POGS_HIP_CHECK(hipMemcpyAsync(mine.data(), buf, bytes, hipMemcpyDeviceToHost, stream));
+  POGS_HIP_CHECK(hipStreamSynchronize(stream));
+  g.barrier();
+  std::vector<T> sum(count, static_cast<T>(0));
+  for (int r = 0; r < g.world; ++r) {   // rank order: every rank forms the identical sum
+    POGS_CHECK(g.slots[r].size() == bytes, "local communicator: ranks disagree on the element count");
+    const T *p = reinterpret_cast<const T *>(g.slots[r].data());
+    for (size_t i = 0; i < count; ++i) sum[i] += p[i];
+  }
+  g.barrier();   // nobody overwrites a slot that is still being read
+  POGS_HIP_CHECK(hipMemcpyAsync(buf, sum.data(), bytes, hipMemcpyHostToDevice, stream));
+  POGS_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
 }  // namespace
 
 DistComm::~DistComm() {
   if (comm_) {
     try { api().CommDestroy(comm_); } catch (...) {}
   }
+  delete static_cast<std::shared_ptr<LocalGroup> *>(local_);
 }
 
 void DistComm::unique_id(char *out) {
@@ -79,12 +145,23 @@ void DistComm::init(int rank, int world, const char *unique_id) {
   POGS_CHECK(world >= 1 && rank >= 0 && rank < world, "bad rank/world");
   rank_ = rank;
   world_ = world;
+  if (std::strncmp(unique_id, kLocalTag, sizeof(kLocalTag) - 1) == 0) {
+    const std::string key(unique_id, strnlen(unique_id, kUniqueIdBytes));
+    local_ = new std::shared_ptr<LocalGroup>(local_group(key, world));
+    return;
+  }
   UniqueId id;
   std::memcpy(id.internal, unique_id, kUniqueIdBytes);
   check(api().CommInitRank(&comm_, world, id, rank), "ncclCommInitRank");
 }
 
 void DistComm::reduce_raw(void *buf, size_t count, int dtype, hipStream_t stream) const {
+  if (local_ && count > 0) {
+    LocalGroup &g = **static_cast<std::shared_ptr<LocalGroup> *>(local_);
+    if (dtype == kNcclFloat) local_allreduce(g, rank_, static_cast<float *>(buf), count, stream);
+    else local_allreduce(g, rank_, static_cast<double *>(buf), count, stream);
+    return;
+  }
   if (!comm_ || count == 0) return;
   check(api().AllReduce(buf, buf, count, dtype, kNcclSum, comm_, stream), "ncclAllReduce");
 }
@@ -98,6 +175,11 @@ void DistComm::allreduce(double *buf, size_t count, hipStream_t stream) const {
 
 template <typename T>
 void DistComm::allreduce2(T *buf, size_t count, double *scalars, size_t nscalars, hipStream_t stream) const {
+  if (local_) {
+    allreduce(buf, count, stream);
+    allreduce(scalars, nscalars, stream);
+    return;
+  }
   if (!comm_) return;
   check(api().GroupStart(), "ncclGroupStart");
   allreduce(buf, count, stream);

@@ -63,3 +63,36 @@ def _fsum(fv, v):
             raise NotImplementedError(code)
         out[msk] = r
     return float(np.sum(c * out + d * v + 0.5 * e * v * v))
+
+
+def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, **solve_kw):
+    """Solves with `world` ranks inside this process: one thread + one Solver per rank, rows split
+    evenly, joined by the engine's in-process test communicator ("POGSLOCAL:" unique id, see
+    pogs_amd/csrc/dist.h).  Verifies the engine's own row-sharded decomposition on ONE GPU.
+    Returns the per-rank result dicts (x replicated, y / l row slices)."""
+    import os
+    import threading
+
+    import numpy as np
+
+    m = A.shape[0]
+    uid = (b"POGSLOCAL:" + os.urandom(8).hex().encode()).ljust(128, b"\0")
+    bounds = np.linspace(0, m, world + 1).astype(int)
+    results, errors = [None] * world, []
+
+    def work(r):
+        try:
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            with pogs.Solver(A[lo:hi], dtype=dtype, dist=(r, world, m, uid), **(solver_kw or {})) as s:
+                results[r] = s.solve(f.slice(lo, hi), g, **solve_kw)
+        except Exception as e:  # pragma: no cover - surfaced below
+            errors.append((r, e))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    assert all(r is not None for r in results)
+    return results, bounds

@@ -493,3 +493,37 @@ def test_warm_start_from_solution_stops_immediately():
         assert relerr(r2["x"], r["x"]) < 1e-3
         with pytest.raises(Exception):
             s.warm_start(r["x"], None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,world", [(np.float64, 2), (np.float32, 3)])
+def test_row_sharded_engine_matches_single_rank(dtype, world):
+    """The engine's row-sharded decomposition with 2 / 3 ranks on one GPU
+    (threads + the in-process test communicator): same trajectory and solution as the
+    unsharded solve and as the sharded oracle."""
+    pogs = _pogs()
+    from helpers import run_row_sharded
+    from pogs_amd import synth
+
+    m, n = 3001, 257
+    A, b, _ = synth.dense_lasso(m, n, seed=17, dtype=dtype)
+    f, g = pogs.graph.lasso_functions(b, 0.1, n)
+    with pogs.Solver(A, dtype=dtype) as s:
+        one = s.solve(f, g)
+    res, bounds = run_row_sharded(pogs, A, f, g, world, dtype)
+    tol = 1e-9 if dtype == np.float64 else 2e-4
+    for r, out in enumerate(res):
+        assert out["status"] == one["status"] == 0
+        if dtype == np.float64:
+            assert out["iterations"] == one["iterations"]
+        else:
+            assert abs(int(out["iterations"]) - int(one["iterations"])) <= max(3, one["iterations"] // 10)
+        assert relerr(out["x"], one["x"]) < tol
+        lo, hi = bounds[r], bounds[r + 1]
+        assert relerr(out["y"], one["y"][lo:hi]) < tol * 10
+        assert relerr(out["l"], one["l"][lo:hi]) < tol * 100
+        assert out["optval"] == pytest.approx(one["optval"], rel=max(tol, 1e-7))
+    # all ranks took the same decisions: identical x and iteration count
+    for out in res[1:]:
+        assert out["iterations"] == res[0]["iterations"]
+        assert np.array_equal(out["x"], res[0]["x"])
