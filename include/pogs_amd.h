@@ -161,10 +161,13 @@ int PogsAmdCreateDense(PogsAmdSolver **out, int dtype, enum ORD ord, size_t m,
                        const PogsAmdOptions *opt, const PogsAmdDist *dist);
 
 /* Create a solver for a sparse matrix (CSR if ord == ROW_MAJ, else CSC);
- * data/ptr/ind are host or device pointers (mem). */
+ * data/ptr/ind are host or device pointers (mem).  With dist (may be NULL) the
+ * matrix is this rank's block of m consecutive rows, given as CSR (SURVEY.md
+ * section 8 f.3): CGLS with the A^T products and row sums all-reduced. */
 int PogsAmdCreateSparse(PogsAmdSolver **out, int dtype, enum ORD ord, size_t m,
                         size_t n, size_t nnz, const void *data, const int *ptr,
-                        const int *ind, int mem, const PogsAmdOptions *opt);
+                        const int *ind, int mem, const PogsAmdOptions *opt,
+                        const PogsAmdDist *dist);
 
 /* Cold-start solve (reference: PogsImplementation::Solve, src/cpu/pogs.cpp:91-581).
  * Coefficient and output pointers are HOST pointers of the solver's dtype

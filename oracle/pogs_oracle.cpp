@@ -577,10 +577,10 @@ void EquilDense(DenseOp<T> *A, T *d, T *e, size_t m_glob, const Comm &comm) {
 
 // MatrixSparse::Equil (src/cpu/matrix/matrix_sparse.cpp:158-242, 249-302).
 template <typename T>
-void EquilSparse(SparseOp<T> *A, T *d, T *e) {
+void EquilSparse(SparseOp<T> *A, T *d, T *e, size_t m_glob = 0, const Comm &comm = Comm()) {
   const size_t m = A->m, n = A->n, nnz = A->nnz;
-  Comm none;
-  SinkhornKnopp<T>(A, d, e, m, none);
+  if (m_glob == 0) m_glob = m;
+  SinkhornKnopp<T>(A, d, e, m_glob, comm);
   for (size_t t = 0; t < 2 * nnz; ++t) A->val[t] = sign_sqrt_square(A->val[t]);
   for (size_t i = 0; i < m; ++i) d[i] = Sqrt(d[i]);
   for (size_t j = 0; j < n; ++j) e[j] = Sqrt(e[j]);
@@ -597,7 +597,8 @@ void EquilSparse(SparseOp<T> *A, T *d, T *e) {
     for (size_t t = 0; t < m; ++t) for (int i = p1[t]; i < p1[t + 1]; ++i) v1[i] *= d[t] * e[i1[i]];
   }
   // Frobenius norm over the first nnz only (:257), / sqrt(min(m,n)).
-  const T normA = nrm2(v0, nnz) / static_cast<T>(std::sqrt(static_cast<double>(std::min(m, n))));
+  const T normA = (comm.fn ? static_cast<T>(std::sqrt(comm.sum1(sumsq(v0, nnz)))) : nrm2(v0, nnz)) /
+                  static_cast<T>(std::sqrt(static_cast<double>(std::min(m_glob, n))));
   const T inv = 1 / normA;
   for (size_t t = 0; t < 2 * nnz; ++t) A->val[t] *= inv;
   const T invs = 1 / std::sqrt(normA);
@@ -748,7 +749,8 @@ struct ProjectorDirect : Projector<T> {
 // CGLS (src/cpu/include/cgls.h:200-323).
 template <typename T>
 int CglsSolve(Operator<T> *A, const T *b, T *x, double shift, double tol, int maxit,
-              long *iters) {
+              long *iters, const Comm &comm = Comm()) {
+  // rows sharded: x-sized vectors are replicated, A^T products and |q|^2 are summed over ranks
   const size_t m = A->m, n = A->n;
   std::vector<T> p(n), q(m), r(b, b + m), s(x, x + n);
   double gamma, normp, normq, norms, norms0, normx, xmax;
@@ -757,7 +759,14 @@ int CglsSolve(Operator<T> *A, const T *b, T *x, double shift, double tol, int ma
   const double kEps = std::numeric_limits<T>::epsilon();
   normx = nrm2(x, n);
   if (normx > 0.) A->Mul('n', static_cast<T>(-1), x, static_cast<T>(1), r.data());   // :229-233
-  A->Mul('t', static_cast<T>(1), r.data(), kNegShift, s.data());                     // :236
+  if (comm.fn) {
+    std::vector<T> t(n);
+    A->Mul('t', static_cast<T>(1), r.data(), static_cast<T>(0), t.data());
+    comm.sum_vec(t.data(), n);
+    for (size_t j = 0; j < n; ++j) s[j] = t[j] + kNegShift * s[j];
+  } else {
+    A->Mul('t', static_cast<T>(1), r.data(), kNegShift, s.data());                   // :236
+  }
   p = s;
   norms = nrm2(s.data(), n);
   norms0 = norms;
@@ -768,7 +777,7 @@ int CglsSolve(Operator<T> *A, const T *b, T *x, double shift, double tol, int ma
   for (k = 0; k < maxit && !flag; ++k) {
     A->Mul('n', static_cast<T>(1), p.data(), static_cast<T>(0), q.data());           // :257
     normp = nrm2(p.data(), n);
-    normq = nrm2(q.data(), m);
+    normq = comm.fn ? std::sqrt(comm.sum1(sumsq(q.data(), m))) : nrm2(q.data(), m);
     double delta = normq * normq + shift * normp * normp;                            // :266
     if (delta <= 0.) indefinite = 1;
     if (delta == 0.) delta = kEps;
@@ -777,7 +786,14 @@ int CglsSolve(Operator<T> *A, const T *b, T *x, double shift, double tol, int ma
     axpy(alpha, p.data(), x, n);
     axpy(neg_alpha, q.data(), r.data(), m);
     std::memcpy(s.data(), x, n * sizeof(T));                                         // :281
-    A->Mul('t', static_cast<T>(1), r.data(), kNegShift, s.data());                   // :282
+    if (comm.fn) {
+      std::vector<T> t(n);
+      A->Mul('t', static_cast<T>(1), r.data(), static_cast<T>(0), t.data());
+      comm.sum_vec(t.data(), n);
+      for (size_t j = 0; j < n; ++j) s[j] = t[j] + kNegShift * s[j];
+    } else {
+      A->Mul('t', static_cast<T>(1), r.data(), kNegShift, s.data());                 // :282
+    }
     norms = nrm2(s.data(), n);
     const double gamma1 = gamma;
     gamma = norms * norms;
@@ -801,7 +817,8 @@ int CglsSolve(Operator<T> *A, const T *b, T *x, double shift, double tol, int ma
 template <typename T>
 struct ProjectorCgls : Projector<T> {
   Operator<T> *A;
-  explicit ProjectorCgls(Operator<T> *A_) : A(A_) {}
+  Comm comm;
+  explicit ProjectorCgls(Operator<T> *A_, const Comm &c = Comm()) : A(A_), comm(c) {}
   void Init() override {}
   void Project(const T *x0, const T *y0, T s, T *x, T *y, T tol) override {
     this->n_proj++;
@@ -809,7 +826,7 @@ struct ProjectorCgls : Projector<T> {
     axpy(static_cast<T>(-1), x0, x, n);                                   // :62
     std::memcpy(y, y0, m * sizeof(T));                                    // :65
     A->Mul('n', static_cast<T>(-1), x0, static_cast<T>(1), y);            // :68
-    CglsSolve<T>(A, y, x, s, tol, 500, &this->cg_iters);                  // :71-72
+    CglsSolve<T>(A, y, x, s, tol, 500, &this->cg_iters, comm);            // :71-72
     axpy(static_cast<T>(1), x0, x, n);                                    // :75
     A->Mul('n', static_cast<T>(1), x, static_cast<T>(0), y);              // :78
   }
@@ -1096,19 +1113,20 @@ int PogsSparse(int ord, size_t m, size_t n, size_t nnz, const T *data, const int
                const T *f_e, const int *f_h, const T *g_a, const T *g_b, const T *g_c,
                const T *g_d, const T *g_e, const int *g_h, T rho, T abs_tol, T rel_tol,
                unsigned max_iter, unsigned verbose, int adaptive_rho, int gap_stop, T *x,
-               T *y, T *l, T *optval, unsigned *final_iter, OracleInfo *info) {
+               T *y, T *l, T *optval, unsigned *final_iter, OracleInfo *info, size_t m_glob = 0,
+               const Comm &none = Comm()) {
   const double t0 = now_s();
+  if (m_glob == 0) m_glob = m;
   SparseOp<T> A(ord == 1, m, n, nnz, data, ptr, ind);
   std::vector<T> de(m + n, 0);
-  EquilSparse<T>(&A, de.data(), de.data() + m);
-  Comm none;
+  EquilSparse<T>(&A, de.data(), de.data() + m, m_glob, none);
   unsigned kpow = 0;
   T nrmA = Norm2Est<T>(&A, none, &kpow);
-  ProjectorCgls<T> P(&A);
+  ProjectorCgls<T> P(&A, none);
   const double t1 = now_s();
   SolveArgs<T> arg{rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho != 0, gap_stop != 0};
   int st = AdmmSolve<T>(&A, &P, make_objs(m, f_a, f_b, f_c, f_d, f_e, f_h),
-                        make_objs(n, g_a, g_b, g_c, g_d, g_e, g_h), de.data(), nrmA, m, none,
+                        make_objs(n, g_a, g_b, g_c, g_d, g_e, g_h), de.data(), nrmA, m_glob, none,
                         arg, x, y, l, static_cast<T *>(nullptr), optval, final_iter, info);
   const double t2 = now_s();
   if (info) {
@@ -1176,6 +1194,26 @@ ORACLE_SHARD(OraclePogsShardS, float)
   }
 ORACLE_SPARSE(OraclePogsSparseD, double)
 ORACLE_SPARSE(OraclePogsSparseS, float)
+
+// Row-sharded CSR + CGLS: this rank holds m_local consecutive rows.
+#define ORACLE_SPARSE_SHARD(NAME, T)                                                       \
+  int NAME(size_t m_local, size_t m_global, size_t n, size_t nnz, const T *data,           \
+           const int *ptr, const int *ind, const T *f_a, const T *f_b, const T *f_c,       \
+           const T *f_d, const T *f_e, const int *f_h, const T *g_a, const T *g_b,         \
+           const T *g_c, const T *g_d, const T *g_e, const int *g_h, T rho, T abs_tol,     \
+           T rel_tol, unsigned max_iter, unsigned verbose, int adaptive_rho, int gap_stop, \
+           T *x, T *y, T *l, T *optval, unsigned *final_iter, OracleInfo *info,            \
+           oracle_allreduce_fn fn, void *ctx) {                                            \
+    Comm comm;                                                                             \
+    comm.fn = fn;                                                                          \
+    comm.ctx = ctx;                                                                        \
+    return PogsSparse<T>(1, m_local, n, nnz, data, ptr, ind, f_a, f_b, f_c, f_d, f_e, f_h, \
+                         g_a, g_b, g_c, g_d, g_e, g_h, rho, abs_tol, rel_tol, max_iter,    \
+                         verbose, adaptive_rho, gap_stop, x, y, l, optval, final_iter,     \
+                         info, m_global, comm);                                            \
+  }
+ORACLE_SPARSE_SHARD(OraclePogsSparseShardD, double)
+ORACLE_SPARSE_SHARD(OraclePogsSparseShardS, float)
 
 // Element-wise prox / function evaluation with SoA coefficients.
 #define ORACLE_PROX(NAME, FNAME, T)                                                        \

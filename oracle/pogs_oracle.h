@@ -59,6 +59,17 @@ ORACLE_DECL_SHARD(OraclePogsShardS, float)
            const T *g_d, const T *g_e, const int *g_h, T rho, T abs_tol, T rel_tol,  \
            unsigned max_iter, unsigned verbose, int adaptive_rho, int gap_stop,      \
            T *x, T *y, T *l, T *optval, unsigned *final_iter, OracleInfo *info);
+#define ORACLE_DECL_SPARSE_SHARD(NAME, T)                                            \
+  int NAME(size_t m_local, size_t m_global, size_t n, size_t nnz, const T *data,     \
+           const int *ptr, const int *ind, const T *f_a, const T *f_b, const T *f_c, \
+           const T *f_d, const T *f_e, const int *f_h, const T *g_a, const T *g_b,   \
+           const T *g_c, const T *g_d, const T *g_e, const int *g_h, T rho,          \
+           T abs_tol, T rel_tol, unsigned max_iter, unsigned verbose,                \
+           int adaptive_rho, int gap_stop, T *x, T *y, T *l, T *optval,              \
+           unsigned *final_iter, OracleInfo *info, oracle_allreduce_fn fn, void *ctx);
+ORACLE_DECL_SPARSE_SHARD(OraclePogsSparseShardD, double)
+ORACLE_DECL_SPARSE_SHARD(OraclePogsSparseShardS, float)
+
 ORACLE_DECL_SPARSE(OraclePogsSparseD, double)
 ORACLE_DECL_SPARSE(OraclePogsSparseS, float)
 

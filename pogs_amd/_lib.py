@@ -85,7 +85,8 @@ lib.PogsAmdDistUniqueId.argtypes = [c_void_p]
 lib.PogsAmdCreateDense.argtypes = [ctypes.POINTER(c_void_p), c_int, c_int, c_size_t, c_size_t, c_void_p, c_int,
                                    ctypes.POINTER(PogsAmdOptions), ctypes.POINTER(PogsAmdDist)]
 lib.PogsAmdCreateSparse.argtypes = [ctypes.POINTER(c_void_p), c_int, c_int, c_size_t, c_size_t, c_size_t, c_void_p,
-                                    c_void_p, c_void_p, c_int, ctypes.POINTER(PogsAmdOptions)]
+                                    c_void_p, c_void_p, c_int, ctypes.POINTER(PogsAmdOptions),
+                                    ctypes.POINTER(PogsAmdDist)]
 lib.PogsAmdSolve.argtypes = [c_void_p] + [c_void_p] * 12 + [c_double, c_double, c_double, c_uint, c_uint, c_int, c_int,
                                                             c_void_p, c_void_p, c_void_p, c_void_p,
                                                             ctypes.POINTER(c_double), ctypes.POINTER(c_uint)]

@@ -13,7 +13,8 @@ namespace pogs_amd {
 SolverBase *make_dense_solver(int dtype, int ord, size_t m, size_t n, const void *A, int mem,
                               const PogsAmdOptions *opt, const PogsAmdDist *dist);
 SolverBase *make_sparse_solver(int dtype, int ord, size_t m, size_t n, size_t nnz, const void *data,
-                               const int *ptr, const int *ind, int mem, const PogsAmdOptions *opt);
+                               const int *ptr, const int *ind, int mem, const PogsAmdOptions *opt,
+                               const PogsAmdDist *dist);
 
 // gsl::rand (src/cpu/include/gsl/gsl_rand.h:8-16): a fresh
 // std::default_random_engine (libstdc++: minstd_rand0, x <- 16807 x mod 2^31-1,
@@ -110,7 +111,7 @@ int pogs_sparse(enum ORD ord, size_t m, size_t n, size_t nnz, const T *data, con
                 T *x, T *y, T *l, T *optval, unsigned *final_iter) {
   return guarded([&]() {
     std::unique_ptr<SolverBase> s(make_sparse_solver(sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64, ord, m, n, nnz,
-                                                     data, ptr, ind, POGS_AMD_HOST, nullptr));
+                                                     data, ptr, ind, POGS_AMD_HOST, nullptr, nullptr));
     FnHost f{f_a, f_b, f_c, f_d, f_e, reinterpret_cast<const int *>(f_h)};
     FnHost g{g_a, g_b, g_c, g_d, g_e, reinterpret_cast<const int *>(g_h)};
     double ov = 0;
@@ -224,11 +225,12 @@ int PogsAmdCreateDense(PogsAmdSolver **out, int dtype, enum ORD ord, size_t m, s
 }
 
 int PogsAmdCreateSparse(PogsAmdSolver **out, int dtype, enum ORD ord, size_t m, size_t n, size_t nnz,
-                        const void *data, const int *ptr, const int *ind, int mem, const PogsAmdOptions *opt) {
+                        const void *data, const int *ptr, const int *ind, int mem, const PogsAmdOptions *opt,
+                        const PogsAmdDist *dist) {
   return guarded([&]() {
     *out = nullptr;
     std::unique_ptr<PogsAmdSolver> h(new PogsAmdSolver);
-    h->impl.reset(make_sparse_solver(dtype, ord, m, n, nnz, data, ptr, ind, mem, opt));
+    h->impl.reset(make_sparse_solver(dtype, ord, m, n, nnz, data, ptr, ind, mem, opt, dist));
     *out = h.release();
     return 0;
   });

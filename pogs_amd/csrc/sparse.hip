@@ -406,6 +406,26 @@ __global__ void __launch_bounds__(256) reduce_parts_kernel(const T *__restrict__
   }
 }
 
+// the row functor applied to a finished vector of dot products (row-sharded solves: the
+// A^T products are summed over the ranks before the functor sees them)
+template <typename T, typename Op>
+__global__ void __launch_bounds__(256) apply_rows_kernel(const T *__restrict__ dots, int nrows, Op op,
+                                                         double *scalar_partials) {
+  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+  __shared__ double s_red[NS * 4];
+  double sacc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < nrows; r += gridDim.x * 256) op.row(r, dots[r], sacc);
+  if (Op::NS > 0) {
+    dev::block_sum<NS, 256>(sacc, s_red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) scalar_partials[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
+    }
+  }
+}
+
 // cnt[cb * nrows + r] = non-zeros of row r in column block cb (one thread per row)
 __global__ void bcsr_count_kernel(const int *ind, const int *ptr, int nrows, int bw, int *cnt) {
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x)
@@ -670,14 +690,23 @@ template <typename T>
 class SparseSolver final : public SolverBase {
  public:
   SparseSolver(int ord, size_t m, size_t n, size_t nnz, const void *data, const int *ptr, const int *ind, int mem,
-               const PogsAmdOptions *opt) {
+               const PogsAmdOptions *opt, const PogsAmdDist *dist) {
     const double t0 = wall_s();
     ctx_.init(opt ? opt->device : -1, opt ? opt->profile != 0 : false);
     POGS_CHECK(m > 0 && n > 0 && m < (1u << 31) && n < (1u << 31) && nnz < (1ull << 31), "bad dimensions");
     m_ = static_cast<int>(m);
     n_ = static_cast<int>(n);
     nnz_ = nnz;
-    ctx_.m_global = m;
+    // row shards: this rank holds m consecutive rows as CSR; y-sized
+    // state is local, x-sized state replicated, A^T products and row sums are all-reduced
+    if (dist && dist->world >= 1) {
+      POGS_CHECK(ord == ROW_MAJ, "a row shard must be given as CSR (ROW_MAJ)");
+      ctx_.dist.init(dist->rank, dist->world, dist->unique_id);
+      ctx_.m_global = dist->m_global;
+    } else {
+      ctx_.m_global = m;
+    }
+    multi_ = ctx_.dist.active();
     build_structure(ord, data, ptr, ind, mem);
     ctx_.stats.t_h2d_s = wall_s() - t0;
     alloc_state();
@@ -778,8 +807,9 @@ class SparseSolver final : public SolverBase {
     DevBuf<T> vin(nin), vout(nout);
     POGS_HIP_CHECK(hipMemcpyAsync(vin.p, x, nin * sizeof(T), hipMemcpyHostToDevice, s));
     POGS_HIP_CHECK(hipMemcpyAsync(vout.p, y, nout * sizeof(T), hipMemcpyHostToDevice, s));
-    spmv<false>(tr ? At_ : A_, vin.p, nullptr,
-                SpAxpbyOp<T>{static_cast<T>(alpha), static_cast<T>(beta), vout.p, vout.p}, nullptr, 0);
+    const SpAxpbyOp<T> op{static_cast<T>(alpha), static_cast<T>(beta), vout.p, vout.p};
+    if (tr) spmv_t<false>(vin.p, op, nullptr);   // summed over the row shards
+    else spmv<false>(A_, vin.p, nullptr, op, nullptr, 0);
     POGS_HIP_CHECK(hipMemcpyAsync(y, vout.p, nout * sizeof(T), hipMemcpyDeviceToHost, s));
     ctx_.sync();
   }
@@ -919,6 +949,7 @@ class SparseSolver final : public SolverBase {
     f_.alloc(m_); g_.alloc(n_); fs_.alloc(m_); gs_.alloc(n_);
     cg_.alloc(kCgNumSlots);
     cg_.zero(s);
+    if (multi_) tsum_.alloc(n_);
     spmv_grid_ = ctx_.num_cu * 8;
     const size_t vb = vec_blocks(n_) + vec_blocks(m_);
     ctx_.ensure_spart(std::max<size_t>(static_cast<size_t>(spmv_grid_) * 4 + 64, vb * 3 + 64));
@@ -964,6 +995,27 @@ class SparseSolver final : public SolverBase {
       launch_sum_jobs(&j, 1, s);
     }
   }
+  // A^T product: with row shards the n partial sums are all-reduced before the row functor runs
+  template <bool SQ, typename Op>
+  void spmv_t(const T *xin, const Op &op, double *scalar_out, bool timed = false) {
+    if (!multi_) {
+      spmv<SQ>(At_, xin, nullptr, op, scalar_out, 0, timed);
+      return;
+    }
+    hipStream_t s = ctx_.stream;
+    spmv<SQ>(At_, xin, nullptr, SpAxpbyOp<T>{1, 0, nullptr, tsum_.p}, nullptr, 0, timed);
+    ctx_.dist.allreduce(tsum_.p, n_, s);
+    const int grid = std::max(1, std::min((n_ + 255) / 256, spmv_grid_));
+    hipLaunchKernelGGL((apply_rows_kernel<T, Op>), dim3(grid), dim3(256), 0, s, tsum_.p, n_, op, ctx_.spart.p);
+    if (Op::NS > 0 && scalar_out) {
+      SumJob j{ctx_.spart.p, grid, Op::NS, scalar_out};
+      launch_sum_jobs(&j, 1, s);
+    }
+  }
+  // sums of a y-sized quantity: add the other ranks' rows
+  void reduce_y_scalars(double *slot, int count) {
+    if (multi_) ctx_.dist.allreduce(slot, count, ctx_.stream);
+  }
   static bool allow_smem(const void *fn, size_t bytes) {
     POGS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
     return true;
@@ -974,13 +1026,13 @@ class SparseSolver final : public SolverBase {
   void equilibrate() {
     hipStream_t s = ctx_.stream;
     PhaseTimer pt(s);
-    const double mg = m_, nn = n_;
+    const double mg = static_cast<double>(ctx_.m_global), nn = n_;
     const T ce = static_cast<T>(1e-4) * static_cast<T>(mg + nn) / static_cast<T>(mg);
     const T cd = static_cast<T>(1e-4) * static_cast<T>(mg + nn) / static_cast<T>(nn);
     launch_fill<T>(d_.p, static_cast<T>(1), m_, s);
     launch_fill<T>(e_.p, static_cast<T>(1), n_, s);
     for (int k = 0; k < 50; ++k) {
-      spmv<true>(At_, d_.p, nullptr, SpSkOp<T>{static_cast<T>(mg), ce, e_.p}, nullptr, 0);
+      spmv_t<true>(d_.p, SpSkOp<T>{static_cast<T>(mg), ce, e_.p}, nullptr);
       spmv<true>(A_, e_.p, nullptr, SpSkOp<T>{static_cast<T>(nn), cd, d_.p}, nullptr, 0);
     }
     ctx_.stats.matvecs_init += 100;
@@ -993,9 +1045,10 @@ class SparseSolver final : public SolverBase {
                        pb);
     SumJob j{first_is_A_ ? pa : pb, g, 1, ctx_.S.p + kFro2};   // first nnz only (matrix_sparse.cpp:257)
     launch_sum_jobs(&j, 1, s);
+    reduce_y_scalars(ctx_.S.p + kFro2, 1);
     const double *S = ctx_.fetch_scalars();
     const T normA = static_cast<T>(std::sqrt(S[kFro2])) /
-                    static_cast<T>(std::sqrt(static_cast<double>(std::min(m_, n_))));
+                    static_cast<T>(std::sqrt(std::min(mg, nn)));
     launch_scal<T>(A_.val.p, static_cast<T>(1) / normA, nnz_, s);
     launch_scal<T>(At_.val.p, static_cast<T>(1) / normA, nnz_, s);
     fill_blocked(A_, false);
@@ -1022,7 +1075,8 @@ class SparseSolver final : public SolverBase {
       // Sx = A (x / |x|);  x' = A^T Sx
       spmv<false>(A_, xtemp_.p, (i == 0) ? nullptr : ctx_.S.p + kPowX2,
                   SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p}, ctx_.S.p + kPowSx2, 0);
-      spmv<false>(At_, cg_q_.p, nullptr, SpAxpbyNormOp<T>{1, 0, nullptr, xtemp_.p}, ctx_.S.p + kPowX2, 0);
+      reduce_y_scalars(ctx_.S.p + kPowSx2, 1);
+      spmv_t<false>(cg_q_.p, SpAxpbyNormOp<T>{1, 0, nullptr, xtemp_.p}, ctx_.S.p + kPowX2);
       const double *S = ctx_.fetch_scalars();
       const T normx = static_cast<T>(std::sqrt(S[kPowX2]));
       const T normSx = static_cast<T>(std::sqrt(S[kPowSx2]));
@@ -1059,7 +1113,7 @@ class SparseSolver final : public SolverBase {
     ctl_.adaptive_rho = p.adaptive_rho;
     ctl_.gap_stop = p.gap_stop;
     ctl_.rho0 = static_cast<T>(p.rho);
-    ctl_.m_glob = m_;
+    ctl_.m_glob = ctx_.m_global;
     ctl_.n = n_;
     ctx_.sync();
   }
@@ -1116,8 +1170,7 @@ class SparseSolver final : public SolverBase {
     const double *S;
     double normx;
     // s = A^T r - shift x ; p = s ; gamma = |s|^2                             (cgls.h:236-245)
-    spmv<false>(At_, cg_r_.p, nullptr, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, ctx_.S.p + kCgS2, 0,
-                true);
+    spmv_t<false>(cg_r_.p, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, ctx_.S.p + kCgS2, true);
     hipLaunchKernelGGL(set_gamma_kernel, dim3(1), dim3(1), 0, s, ctx_.S.p, cg_.p);
     hipLaunchKernelGGL(cg_update_p_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, cg_.p, cg_s_.p, cg_p_.p,
                        ctx_.spart.p, true);
@@ -1129,6 +1182,7 @@ class SparseSolver final : public SolverBase {
     for (int k = 0; k < maxit; ++k) {
       // q = A p, |q|^2 ; alpha                                               (cgls.h:257-271)
       spmv<false>(A_, cg_p_.p, nullptr, SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p}, ctx_.S.p + kCgQ2, 0, true);
+      reduce_y_scalars(ctx_.S.p + kCgQ2, 1);
       hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(1), 0, s, ctx_.S.p, cg_.p, shift, kEps);
       // x += alpha p ; r -= alpha q ; |x|^2                                  (:274-277)
       const int bm = vec_blocks(m_);
@@ -1136,8 +1190,7 @@ class SparseSolver final : public SolverBase {
                          cg_q_.p, cg_r_.p, ctx_.spart.p, bx);
       sum_vec_partials(bx, ctx_.S.p + kCgX2);
       // s = A^T r - shift x ; |s|^2 ; beta ; p = s + beta p ; |p|^2          (:281-296)
-      spmv<false>(At_, cg_r_.p, nullptr, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, ctx_.S.p + kCgS2,
-                  0, true);
+      spmv_t<false>(cg_r_.p, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, ctx_.S.p + kCgS2, true);
       hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(1), 0, s, ctx_.S.p, cg_.p);
       hipLaunchKernelGGL(cg_update_p_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, cg_.p, cg_s_.p, cg_p_.p,
                          ctx_.spart.p, false);
@@ -1164,7 +1217,7 @@ class SparseSolver final : public SolverBase {
     launch_scale_by<T>(n_, static_cast<T>(1), xtemp_.p, e_.p, true, x_[cur_].p, s);
     spmv<false>(A_, x_[cur_].p, nullptr, SpAxpbyOp<T>{1, 0, nullptr, y_[cur_].p}, nullptr, 0);
     launch_scale_by<T>(m_, static_cast<T>(1), ytemp_.p, d_.p, true, yt_.p, s);
-    spmv<false>(At_, yt_.p, nullptr, SpAxpbyOp<T>{static_cast<T>(1) / rho, 0, nullptr, xt_.p}, nullptr, 0);
+    spmv_t<false>(yt_.p, SpAxpbyOp<T>{static_cast<T>(1) / rho, 0, nullptr, xt_.p}, nullptr);
     launch_scal<T>(yt_.p, static_cast<T>(-1) / rho, m_, s);
     ctx_.sync();
     xtemp_.zero(s);
@@ -1190,6 +1243,7 @@ class SparseSolver final : public SolverBase {
       SumJob j[2] = {{ctx_.spart.p, pa.blocks_x, 3, ctx_.S.p + kGapX},
                      {ctx_.spart.p + static_cast<size_t>(pa.blocks_x) * 3, vec_blocks(m_), 3, ctx_.S.p + kGapY}};
       launch_sum_jobs(j, 2, s);
+      reduce_y_scalars(ctx_.S.p + kGapY, 3);
     }
     // warm start with the previous x (pogs.cpp:281), then CGLS
     POGS_HIP_CHECK(hipMemcpyAsync(x_[nw].p, x_[cur_].p, n_ * sizeof(T), hipMemcpyDeviceToDevice, s));
@@ -1197,6 +1251,7 @@ class SparseSolver final : public SolverBase {
     // y = A x fused with the y-half bookkeeping; x-half element-wise        (projector_cgls.cpp:78)
     spmv<false>(A_, x_[nw].p, nullptr, SpTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p}, ctx_.S.p + kDYprev2, 0,
                 true);
+    reduce_y_scalars(ctx_.S.p + kDYprev2, 2);
     launch_admm_tail<T>(n_, x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, ctx_.spart.p, s);
     {
       SumJob j{ctx_.spart.p, vec_blocks(n_), 2, ctx_.S.p + kDXprev2};
@@ -1207,10 +1262,10 @@ class SparseSolver final : public SolverBase {
     bool exact = false;
     if (ctl_.set_approx(S, nrmA_)) {
       spmv<false>(A_, x12_.p, nullptr, SpExactROp<T>{y12_.p}, ctx_.S.p + kExactR2, 0, true);
+      reduce_y_scalars(ctx_.S.p + kExactR2, 1);
       hipLaunchKernelGGL(exact_u_kernel<T>, dim3((m_ + 255) / 256), dim3(256), 0, s, m_, y12_.p, yt_.p, y_[cur_].p,
                          zt_scale_, u_.p);
-      spmv<false>(At_, u_.p, nullptr, SpExactSOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_}, ctx_.S.p + kExactS2, 0,
-                  true);
+      spmv_t<false>(u_.p, SpExactSOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_}, ctx_.S.p + kExactS2, true);
       S = ctx_.fetch_scalars();
       ctl_.set_exact(S);
       exact = true;
@@ -1235,6 +1290,7 @@ class SparseSolver final : public SolverBase {
     launch_func_eval<T>(n_, gview(), x12_.p, ctx_.spart.p + by, s);
     SumJob j[2] = {{ctx_.spart.p, by, 1, ctx_.S.p + kFvalF}, {ctx_.spart.p + by, bx, 1, ctx_.S.p + kFvalG}};
     launch_sum_jobs(j, 2, s);
+    reduce_y_scalars(ctx_.S.p + kFvalF, 1);
     UnscaleArgs<T> u;
     u.n_x = n_; u.n_y = m_;
     u.x12 = x12_.p; u.y12 = y12_.p; u.xt = xt_.p; u.yt = yt_.p;
@@ -1269,6 +1325,8 @@ class SparseSolver final : public SolverBase {
   int m_ = 0, n_ = 0;
   size_t nnz_ = 0;
   bool first_is_A_ = true;
+  bool multi_ = false;
+  DevBuf<T> tsum_;   // row shards: this rank's A^T partial sums before the all-reduce
   int spmv_grid_ = 2048;
   unsigned long long timed_spmvs_ = 0;
   bool warm_pending_ = false;
@@ -1289,9 +1347,9 @@ class SparseSolver final : public SolverBase {
 }  // namespace
 
 SolverBase *make_sparse_solver(int dtype, int ord, size_t m, size_t n, size_t nnz, const void *data, const int *ptr,
-                               const int *ind, int mem, const PogsAmdOptions *opt) {
-  if (dtype == POGS_AMD_F32) return new SparseSolver<float>(ord, m, n, nnz, data, ptr, ind, mem, opt);
-  if (dtype == POGS_AMD_F64) return new SparseSolver<double>(ord, m, n, nnz, data, ptr, ind, mem, opt);
+                               const int *ind, int mem, const PogsAmdOptions *opt, const PogsAmdDist *dist) {
+  if (dtype == POGS_AMD_F32) return new SparseSolver<float>(ord, m, n, nnz, data, ptr, ind, mem, opt, dist);
+  if (dtype == POGS_AMD_F64) return new SparseSolver<double>(ord, m, n, nnz, data, ptr, ind, mem, opt, dist);
   throw Error("unknown dtype");
 }
 

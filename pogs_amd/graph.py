@@ -321,7 +321,8 @@ class Solver:
             ptr = np.ascontiguousarray(A_csr.indptr, dtype=np.int32)
             ind = np.ascontiguousarray(A_csr.indices, dtype=np.int32)
             st = lib.PogsAmdCreateSparse(ctypes.byref(self._h), code, int(Ordering.ROW_MAJ), self.m, self.n,
-                                         A_csr.nnz, _ptr(data), _ptr(ptr), _ptr(ind), _lib.HOST, ctypes.byref(opt))
+                                         A_csr.nnz, _ptr(data), _ptr(ptr), _ptr(ind), _lib.HOST, ctypes.byref(opt),
+                                         ctypes.byref(dist_s) if dist_s is not None else None)
         else:
             if device_ptr:
                 self.m, self.n = shape

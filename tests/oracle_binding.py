@@ -226,11 +226,12 @@ def ref_solve(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, ma
 
 def oracle_solve_shard(A_local, m_global, f_local, g, allreduce, dtype=np.float64, rho=1.0, abs_tol=1e-4,
                        rel_tol=1e-4, max_iter=2500, verbose=0, adaptive_rho=True, gap_stop=True):
-    """Row-sharded oracle: `allreduce(np.ndarray float64)` sums in place across ranks."""
+    """Row-sharded oracle: `allreduce(np.ndarray float64)` sums in place across ranks.
+    A_local: dense ndarray (direct projector) or scipy CSR (CGLS projector) holding this rank's rows."""
     lib = oracle_lib()
     c = _ct(dtype)
-    A = np.ascontiguousarray(A_local, dtype=dtype)
-    m, n = A.shape
+    sparse = hasattr(A_local, "indptr")
+    m, n = A_local.shape
     f = _coef_arrays(f_local, dtype)
     gg = _coef_arrays(g, dtype)
     x = np.zeros(n, dtype)
@@ -245,8 +246,18 @@ def oracle_solve_shard(A_local, m_global, f_local, g, allreduce, dtype=np.float6
         allreduce(arr)
 
     cb = ALLREDUCE_FN(_cb)
-    fn = lib.OraclePogsShardD if dtype == np.float64 else lib.OraclePogsShardS
-    status = fn(ctypes.c_size_t(m), ctypes.c_size_t(m_global), ctypes.c_size_t(n), _p(A),
+    if sparse:
+        data = np.ascontiguousarray(A_local.data, dtype=dtype)
+        ptr = np.ascontiguousarray(A_local.indptr, dtype=np.int32)
+        ind = np.ascontiguousarray(A_local.indices, dtype=np.int32)
+        head = [ctypes.c_size_t(m), ctypes.c_size_t(m_global), ctypes.c_size_t(n), ctypes.c_size_t(len(data)),
+                _p(data), _p(ptr), _p(ind)]
+        fn = lib.OraclePogsSparseShardD if dtype == np.float64 else lib.OraclePogsSparseShardS
+    else:
+        A = np.ascontiguousarray(A_local, dtype=dtype)
+        head = [ctypes.c_size_t(m), ctypes.c_size_t(m_global), ctypes.c_size_t(n), _p(A)]
+        fn = lib.OraclePogsShardD if dtype == np.float64 else lib.OraclePogsShardS
+    status = fn(*head,
                 _p(f["a"]), _p(f["b"]), _p(f["c"]), _p(f["d"]), _p(f["e"]), _p(f["h"]),
                 _p(gg["a"]), _p(gg["b"]), _p(gg["c"]), _p(gg["d"]), _p(gg["e"]), _p(gg["h"]),
                 c(rho), c(abs_tol), c(rel_tol), ctypes.c_uint(max_iter), ctypes.c_uint(verbose),

@@ -32,11 +32,17 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, m, n, dtype_name, out_dir):
+def _problem(m, n, dtype, sparse):
+    if sparse:
+        return synth.csr_lasso(m, n, 12, seed=31, dtype=dtype)
+    return synth.dense_lasso(m, n, seed=31, dtype=dtype)
+
+
+def _worker(rank, world, port, m, n, dtype_name, out_dir, sparse=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dtype = np.dtype(dtype_name).type
-    A, b, _ = synth.dense_lasso(m, n, seed=31, dtype=dtype)
+    A, b, _ = _problem(m, n, dtype, sparse)
     rows = m // world
     lo, hi = rank * rows, (rank + 1) * rows if rank < world - 1 else m
     f, g = G.lasso_functions(b, 0.1, n)
@@ -75,4 +81,24 @@ def test_row_sharded_solve_matches_single_process(tmp_path, dtype, tol):
     l = np.concatenate([p["l"] for p in parts])
     assert relerr(y, want["y"]) < tol and relerr(l, want["l"]) < 10 * tol
     # replicas took identical decisions
+    assert np.array_equal(parts[0]["x"], parts[1]["x"])
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-8), (np.float32, 5e-4)])
+def test_row_sharded_sparse_cgls_matches_single_process(tmp_path, dtype, tol):
+    """CSR row blocks + CGLS; A^T r partials and |q|^2 are all-reduced."""
+    m, n, world = 1200, 300, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, m, n, np.dtype(dtype).name, str(tmp_path), True), nprocs=world, join=True)
+    A, b, _ = _problem(m, n, dtype, True)
+    f, g = G.lasso_functions(b, 0.1, n)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for p in parts:
+        assert int(p["status"]) == want["status"] == 0
+        assert abs(int(p["iterations"]) - want["iterations"]) <= (1 if dtype == np.float64 else 5)
+        assert relerr(p["x"], want["x"]) < tol
+        assert float(p["optval"]) == pytest.approx(want["optval"], rel=max(tol, 1e-8))
+    y = np.concatenate([p["y"] for p in parts])
+    assert relerr(y, want["y"]) < tol
     assert np.array_equal(parts[0]["x"], parts[1]["x"])

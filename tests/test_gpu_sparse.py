@@ -241,3 +241,47 @@ def test_plain_csr_kernel_still_matches(monkeypatch):
     assert plain["status"] == blocked["status"] == 0
     assert abs(int(plain["iterations"]) - int(blocked["iterations"])) <= 1
     assert relerr(plain["x"], blocked["x"]) < 1e-8
+
+
+@pytest.mark.parametrize("dtype,world", [(np.float64, 2), (np.float32, 3)])
+def test_row_sharded_sparse_engine_matches_single_rank(dtype, world):
+    """CSR row blocks over several ranks (threads + the in-process test
+    communicator, one GPU): CGLS with all-reduced A^T products and row sums follows the unsharded
+    solve and the sharded oracle (tests/test_dist_gloo.py checks that decomposition on CPU)."""
+    pogs = _pogs()
+    from helpers import run_row_sharded
+    from pogs_amd import synth
+
+    m, n = 4001, 900
+    A, b, _ = synth.csr_lasso(m, n, 15, seed=12, dtype=dtype)
+    f, g = pogs.graph.lasso_functions(b, 0.1, n)
+    with pogs.Solver(A, dtype=dtype) as s:
+        one = s.solve(f, g)
+    res, bounds = run_row_sharded(pogs, A.tocsr(), f, g, world, dtype)
+    tol = 1e-7 if dtype == np.float64 else 5e-4
+    for r, out in enumerate(res):
+        assert out["status"] == one["status"] == 0
+        assert abs(int(out["iterations"]) - int(one["iterations"])) <= (1 if dtype == np.float64 else 5)
+        assert relerr(out["x"], one["x"]) < tol
+        lo, hi = bounds[r], bounds[r + 1]
+        assert relerr(out["y"], one["y"][lo:hi]) < tol * 10
+        assert out["optval"] == pytest.approx(one["optval"], rel=max(tol, 1e-7))
+    for out in res[1:]:
+        assert out["iterations"] == res[0]["iterations"]
+        assert np.array_equal(out["x"], res[0]["x"])
+
+
+def test_sparse_one_rank_rccl_path():
+    """The sharded sparse code path over RCCL itself (1-rank communicator)."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.csr_lasso(3000, 800, 20, seed=4, dtype=np.float32)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 800)
+    with pogs.Solver(A, dtype=np.float32) as s:
+        r0 = s.solve(f, g)
+    with pogs.Solver(A, dtype=np.float32, dist=(0, 1, 3000, pogs.dist_unique_id())) as s:
+        r1 = s.solve(f, g)
+    assert r0["status"] == r1["status"] == 0
+    assert abs(int(r0["iterations"]) - int(r1["iterations"])) <= 2
+    assert relerr(r1["x"], r0["x"]) < 1e-4
