@@ -874,12 +874,17 @@ class DenseSolver final : public SolverBase {
       finish_cols(ExactColOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_, n_}, ctx_.S.p + kExactS2, 0, 0, nparts,
                   colpart2_.p);
     } else {
-      // row shards: both n-vectors and the three gap/norm sums travel in ONE RCCL group
+      // row shards: both n-vectors and the three gap/norm sums travel in ONE RCCL group -- when
+      // the iteration was speculated they already crossed the links with the previous pass's
+      // residual sums (end of (D)), so a speculated iteration has a single collective
       double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
       T *both = pair_.p;
-      launch_reduce_cols<T, StoreColOp<T>>(colpart_.p, nparts, n_pad_, StoreColOp<T>{1, 0, both, n_}, sp, s);
-      launch_reduce_cols<T, StoreColOp<T>>(colpart2_.p, nparts, n_pad_, StoreColOp<T>{1, 0, both + n_pad_, n_}, sp, s);
-      ctx_.dist.allreduce2<T>(both, 2 * static_cast<size_t>(n_pad_), ctx_.S.p + kGapY, 3, s);
+      if (!spec_valid_) {
+        launch_reduce_cols<T, StoreColOp<T>>(colpart_.p, nparts, n_pad_, StoreColOp<T>{1, 0, both, n_}, sp, s);
+        launch_reduce_cols<T, StoreColOp<T>>(colpart2_.p, nparts, n_pad_, StoreColOp<T>{1, 0, both + n_pad_, n_}, sp,
+                                             s);
+        ctx_.dist.allreduce2<T>(both, 2 * static_cast<size_t>(n_pad_), ctx_.S.p + kGapY, 3, s);
+      }
       launch_reduce_cols<T, StoreColOp<T>>(both, 1, n_pad_, StoreColOp<T>{1, 0, rhs_.p, n_}, sp, s);
       launch_reduce_cols<T, ExactColOp<T>>(both + n_pad_, 1, n_pad_,
                                            ExactColOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_, n_}, sp, s);
@@ -908,7 +913,16 @@ class DenseSolver final : public SolverBase {
       SumJob j[2] = {{ctx_.spart.p, grid, 3, ctx_.S.p + kDYprev2, 6, 0},
                      {ctx_.spart.p, grid, 3, ctx_.S.p + kSpecGapY, 6, 3}};
       launch_sum_jobs(j, 2, s);
-      if (multi_) ctx_.dist.allreduce(ctx_.S.p + kDYprev2, 3, s);
+      if (multi_) {
+        // this iteration's y-residual sums, and the speculative column sums / y-half sums of the
+        // next one, in one group
+        double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
+        T *both = pair_.p;
+        launch_reduce_cols<T, StoreColOp<T>>(colpart_.p, grid, n_pad_, StoreColOp<T>{1, 0, both, n_}, sp, s);
+        launch_reduce_cols<T, StoreColOp<T>>(colpart2_.p, grid, n_pad_, StoreColOp<T>{1, 0, both + n_pad_, n_}, sp, s);
+        ctx_.dist.allreduce3<T>(both, 2 * static_cast<size_t>(n_pad_), ctx_.S.p + kDYprev2, 3,
+                                ctx_.S.p + kSpecGapY, 3, s);
+      }
       ctx_.stats.matvecs += 1;
     }
     // (E) host decisions (pogs.cpp:270-273, 342-394)

@@ -43,6 +43,9 @@ class DistComm {
   // Two buffers as one RCCL group (one launch).
   template <typename T>
   void allreduce2(T *buf, size_t count, double *scalars, size_t nscalars, hipStream_t stream) const;
+  // One buffer and two scalar ranges as one group.
+  template <typename T>
+  void allreduce3(T *buf, size_t count, double *s1, size_t n1, double *s2, size_t n2, hipStream_t stream) const;
 
   static void unique_id(char *out);  // fresh id (rank 0)
 

@@ -186,6 +186,24 @@ void DistComm::allreduce2(T *buf, size_t count, double *scalars, size_t nscalars
   allreduce(scalars, nscalars, stream);
   check(api().GroupEnd(), "ncclGroupEnd");
 }
+template <typename T>
+void DistComm::allreduce3(T *buf, size_t count, double *s1, size_t n1, double *s2, size_t n2,
+                          hipStream_t stream) const {
+  if (local_) {
+    allreduce(buf, count, stream);
+    allreduce(s1, n1, stream);
+    allreduce(s2, n2, stream);
+    return;
+  }
+  if (!comm_) return;
+  check(api().GroupStart(), "ncclGroupStart");
+  allreduce(buf, count, stream);
+  allreduce(s1, n1, stream);
+  allreduce(s2, n2, stream);
+  check(api().GroupEnd(), "ncclGroupEnd");
+}
+template void DistComm::allreduce3<float>(float *, size_t, double *, size_t, double *, size_t, hipStream_t) const;
+template void DistComm::allreduce3<double>(double *, size_t, double *, size_t, double *, size_t, hipStream_t) const;
 template void DistComm::allreduce2<float>(float *, size_t, double *, size_t, hipStream_t) const;
 template void DistComm::allreduce2<double>(double *, size_t, double *, size_t, hipStream_t) const;
 
