@@ -514,27 +514,23 @@ class DenseSolver final : public SolverBase {
       // (L2 hits; one long K range per tile measured 121 ms against 100 ms at C2), give every
       // CU work to the end of the launch, and form the fp32 K-sum as an ordered sum of short
       // sums: a sequential fp32 sum over 1e5 rows costs ~30 % more ADMM iterations at C2.
-      // Slabs are added in index order (deterministic); at most 8 GB of them, transient.
+      // The K ranges are processed in rounds that write their partial products into the four
+      // slabs of fac_ itself (4 ranges in the first round, 3 in the later ones: slab 0 carries
+      // the running sum), added in range order -- no transient multi-GB allocation, whose
+      // first-touch cost was seen to stall this phase by 100-180 ms now and then.
       const int kdim = tall_ ? m_ : n_;
       const long long tiles = static_cast<long long>((k_ + 127) / 128) * ((k_ + 127) / 128 + 1) / 2;
       int ksplit = 1;
-      while (ksplit < 32 && kdim / (ksplit * 2) >= 2048 && (kdim / ksplit > 6400 || tiles * ksplit < 16LL * ctx_.num_cu * 3) &&
-             slab * sizeof(T) * (ksplit * 2) <= (8ull << 30))
+      while (ksplit < 32 && kdim / (ksplit * 2) >= 2048 && (kdim / ksplit > 6400 || tiles * ksplit < 16LL * ctx_.num_cu * 3))
         ksplit *= 2;
       if (const char *ev = std::getenv("POGS_AMD_KSPLIT")) ksplit = std::max(1, std::atoi(ev));   // tuning aid
-      DevBuf<T> slabs;
-      T *dst = G;
-      if (ksplit > 1) {
-        slabs.alloc(slab * ksplit);   // lower tiles are fully overwritten (beta = 0): no memset
-        dst = slabs.p;
-      }
-      GemmArgs<T> g{k_, k_, kdim, A_.p, lda_, A_.p, lda_, dst, ld, static_cast<T>(1), static_cast<T>(0)};
-      g.ksplit = ksplit;
-      g.kchunk = static_cast<int>(round_up((kdim + ksplit - 1) / ksplit, 32));
+      GemmArgs<T> g{k_, k_, kdim, A_.p, lda_, A_.p, lda_, G, ld, static_cast<T>(1), static_cast<T>(0)};
+      g.kchunk = ksplit > 1 ? static_cast<int>(round_up((kdim + ksplit - 1) / ksplit, 32)) : 0;
       g.csplit_stride = slab;
-      // where the memory cap leaves K ranges longer than ~6.4k rows the unit itself sums in chunks
-      const int nacc = (g.kchunk + 6399) / 6400;
-      g.kacc = nacc > 1 ? static_cast<int>(round_up((g.kchunk + nacc - 1) / nacc, 32)) : 0;
+      // where K ranges stay longer than ~6.4k rows the unit itself sums in chunks
+      const int klen = ksplit > 1 ? g.kchunk : kdim;
+      const int nacc = (klen + 6399) / 6400;
+      g.kacc = nacc > 1 ? static_cast<int>(round_up((klen + nacc - 1) / nacc, 32)) : 0;
       DevBuf<int> tmap;
       if (k_ > 16 * 128 && k_ < 65536 * 128) {
         const std::vector<int> order = gram_tile_order(k_);
@@ -543,11 +539,18 @@ class DenseSolver final : public SolverBase {
         ctx_.sync();   // order is a host temporary
         g.tile_map = tmap.p;
       }
-      launch_gemm<T>(tall_, tall_, true, g, s);
-      if (ksplit > 1) {
-        launch_sum_slabs<T>(slabs.p, slab, ksplit, G, ld, k_, s);
-        ctx_.sync();   // slabs are freed at scope exit
+      for (int ks = 0; ks < ksplit;) {
+        const bool first = ks == 0;
+        const int nb = std::min(first ? 4 : 3, ksplit - ks);
+        g.ks0 = ks;
+        g.ksplit = nb;
+        g.C = first ? G : G + slab;
+        launch_gemm<T>(tall_, tall_, true, g, s);
+        if (ksplit > 1) launch_sum_slabs<T>(G, slab, first ? nb : nb + 1, G, ld, k_, s);   // in place: slab 0 is G
+        ks += nb;
       }
+      if (ksplit > 1) POGS_HIP_CHECK(hipMemsetAsync(G + slab, 0, 3 * slab * sizeof(T), s));
+      ctx_.sync();   // tmap is freed at scope exit
       if (multi_) ctx_.dist.allreduce(G, slab, s);
       ctx_.stats.gram_ms = pt.stop_ms();
       ctx_.stats.gram_flops = static_cast<double>(kdim) * k_ * k_;

@@ -29,6 +29,7 @@ struct GemmArgs {
   int ksplit = 1;
   int kchunk = 0;
   size_t csplit_stride = 0;
+  int ks0 = 0;   // K range of slab ks is [(ks0 + ks) * kchunk, (ks0 + ks + 1) * kchunk)
   // kacc > 0 (multiple of 32; lower_only Gram launches): every kacc rows of the K range the
   // register accumulators are added into a second set and cleared, so a long fp32 K-sum is
   // formed as an ordered sum of short ones (same error behaviour as split-K, no slabs).

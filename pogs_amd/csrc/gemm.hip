@@ -125,8 +125,9 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
   g.C += q * g.strideC;
   const int ks = unit / ntiles;
   const int tile = unit % ntiles;
-  const int kbeg = (g.ksplit > 1) ? ks * g.kchunk : 0;
-  const int kend = (g.ksplit > 1) ? ((kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K) : g.K;
+  const bool split = g.kchunk > 0;
+  const int kbeg = split ? (g.ks0 + ks) * g.kchunk : 0;
+  const int kend = split ? ((kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K) : g.K;
   T *Cout = g.C + static_cast<size_t>(ks) * g.csplit_stride;
   int ti, tj;
   if (g.tile_map) {

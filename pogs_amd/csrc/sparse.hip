@@ -287,14 +287,15 @@ __global__ void __launch_bounds__(kBlkTpb) spmv_blocked_kernel(const T *__restri
     const int q0 = lo.x, nq = hi.x - lo.x;
     const int p0 = lo.y, cnt = hi.y - lo.y;
     if (cnt > kSpCap) return;
-    R.bp[0] = (t <= nq) ? a_bptr[q0 + t] : 0;
-    R.bp[1] = (t + kBlkTpb <= nq) ? a_bptr[q0 + kBlkTpb + t] : 0;
+    // streamed once per SpMV: non-temporal
+    R.bp[0] = (t <= nq) ? __builtin_nontemporal_load(a_bptr + q0 + t) : 0;
+    R.bp[1] = (t + kBlkTpb <= nq) ? __builtin_nontemporal_load(a_bptr + q0 + kBlkTpb + t) : 0;
 #pragma unroll
     for (int u = 0; u < kBlkU; ++u) {
       const int k = u * kBlkTpb + t;
       const bool ok = k < cnt;
-      R.v[u] = ok ? a_val[p0 + k] : static_cast<T>(0);
-      R.l[u] = ok ? a_loc[p0 + k] : static_cast<unsigned short>(0);
+      R.v[u] = ok ? __builtin_nontemporal_load(a_val + p0 + k) : static_cast<T>(0);
+      R.l[u] = ok ? __builtin_nontemporal_load(a_loc + p0 + k) : static_cast<unsigned short>(0);
     }
   };
   // consumes (Da, Db) = row block d, refills R with row block d + 2 = (Dc, Dd), then shifts

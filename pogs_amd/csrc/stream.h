@@ -25,6 +25,25 @@
 
 namespace pogs_amd {
 
+// Load of the matrix stream: every element is used once per pass, so it is marked
+// non-temporal (POGS_AMD_NT_LOADS=0 at compile time falls back to plain loads).
+#ifndef POGS_AMD_NT_LOADS
+#define POGS_AMD_NT_LOADS 1
+#endif
+template <typename V, typename T>
+__device__ __forceinline__ V stream_load(const T *p) {
+#if POGS_AMD_NT_LOADS
+  typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(V) == 16, "16-byte vectors");
+  const raw16 raw = __builtin_nontemporal_load(reinterpret_cast<const raw16 *>(p));
+  V out;
+  __builtin_memcpy(&out, &raw, 16);
+  return out;
+#else
+  return *reinterpret_cast<const V *>(p);
+#endif
+}
+
 enum Tri : int { kFull = 0, kLower = 1, kUpper = 2 };
 
 template <typename T>
@@ -149,7 +168,7 @@ __global__ void __launch_bounds__(TPB) stream_rows_kernel(StreamArgs<T> a, Op op
         if (TRI == kLower) ok = ok && (col <= row);
         if (TRI == kUpper) ok = ok && (col + VEC - 1 >= row);
         V val = dev::vzero<V>();
-        if (ok) val = *reinterpret_cast<const V *>(rp + col);
+        if (ok) val = stream_load<V>(rp + col);
         av[r][v] = SQ ? dev::vsq(val) : val;
       }
     }
@@ -324,7 +343,7 @@ __global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op 
       for (int v = 0; v < NV; ++v) {
         const int col = (v * TPB + t) * VEC;
         V val = dev::vzero<V>();
-        if (col < a.n_pad && row < a.m) val = *reinterpret_cast<const V *>(rp + col);
+        if (col < a.n_pad && row < a.m) val = stream_load<V>(rp + col);
         av[r][v] = val;
       }
     }
