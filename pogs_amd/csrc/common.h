@@ -82,7 +82,7 @@ struct PinnedBuf {
     if (p) (void)hipHostFree(p);
     p = nullptr;
     n = count;
-    if (count) POGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), count * sizeof(T), hipHostMallocDefault));
+    if (count) POGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), count * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent));
   }
   T *get() const { return p; }
 };

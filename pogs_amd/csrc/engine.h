@@ -107,7 +107,15 @@ struct Ctx {
     POGS_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     S.alloc(kNumSlots);
     S.zero(stream);
-    S_host.alloc(kNumSlots);
+    S_host.alloc(kNumSlots + 1);   // + the sequence word of fetch_scalars
+    std::memset(S_host.p, 0, (kNumSlots + 1) * sizeof(double));
+    {
+      const char *fe = std::getenv("POGS_AMD_FETCH");
+      poll_fetch = !(fe && fe[0] == 'm');
+      void *dp = nullptr;
+      if (poll_fetch && hipHostGetDevicePointer(&dp, S_host.p, 0) == hipSuccess && dp) S_host_dev = static_cast<double *>(dp);
+      else poll_fetch = false;
+    }
     std::memset(&stats, 0, sizeof(stats));
     stream_timer.enable(profile);
   }
@@ -118,12 +126,41 @@ struct Ctx {
       spart_cap = count;
     }
   }
-  // Copies the scalar block to the host and waits for the stream.
+  // Brings the scalar block to the host and waits for everything enqueued so far.  Default: a
+  // one-wave kernel writes the block into the host-mapped mirror and then a sequence word the
+  // host polls (the stream is in order, so seeing the word means all earlier work is done);
+  // that saves the copy-engine round trip and the synchronize call of the plain path
+  // (POGS_AMD_FETCH=memcpy), which is also the fallback if the poll sees no progress.
   const double *fetch_scalars() {
-    POGS_HIP_CHECK(hipMemcpyAsync(S_host.p, S.p, kNumSlots * sizeof(double), hipMemcpyDeviceToHost, stream));
-    POGS_HIP_CHECK(hipStreamSynchronize(stream));
+    if (!poll_fetch) {
+      POGS_HIP_CHECK(hipMemcpyAsync(S_host.p, S.p, kNumSlots * sizeof(double), hipMemcpyDeviceToHost, stream));
+      POGS_HIP_CHECK(hipStreamSynchronize(stream));
+      return S_host.p;
+    }
+    const unsigned long long want = ++fetch_seq;
+    unsigned long long *seqp = reinterpret_cast<unsigned long long *>(S_host.p + kNumSlots);
+    launch_publish_scalars(S.p, kNumSlots, S_host_dev, reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots),
+                           want, stream);
+    unsigned spins = 0;
+    while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != want) {
+      if (++spins == (1u << 14)) {   // ~ every few hundred microseconds: surface a failed stream
+        spins = 0;
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) {
+          if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == want) break;
+        } else if (q != hipErrorNotReady) {
+          POGS_HIP_CHECK(q);
+        }
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
     return S_host.p;
   }
+  bool poll_fetch = true;
+  unsigned long long fetch_seq = 0;
+  double *S_host_dev = nullptr;   // device address of the host-mapped mirror
   void sync() { POGS_HIP_CHECK(hipStreamSynchronize(stream)); }
   // POGS_AMD_TRACE=1: host-side setup timeline on stderr (time to reach the mark on the host,
   // then the extra wait for the stream to drain) -- finds host stalls the kernel trace hides.

@@ -89,6 +89,12 @@ struct SumJob {
   int stride = 0;   // doubles between consecutive partial records (0: ns)
   int offset = 0;   // first scalar of the record to sum
 };
+// Copies the device scalar block to a host-mapped mirror and then raises *host_seq to `seq`
+// (system-scope release): the host reads the block after polling the sequence word, with no
+// copy-engine round trip and no stream-synchronize call.
+void launch_publish_scalars(const double *S, int count, double *host_S, unsigned long long *host_seq,
+                            unsigned long long seq, hipStream_t s);
+
 void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s);
 
 // Misc vector helpers.

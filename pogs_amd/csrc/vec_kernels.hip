@@ -213,6 +213,22 @@ void launch_unscale(const UnscaleArgs<T> &a, hipStream_t s) {
   hipLaunchKernelGGL(unscale_kernel<T>, dim3(bx + vec_blocks(a.n_y)), dim3(kVecTpb), 0, s, a, bx);
 }
 
+namespace {
+__global__ void __launch_bounds__(64) publish_scalars_kernel(const double *S, int count, double *host_S,
+                                                           unsigned long long *host_seq, unsigned long long seq) {
+  const int t = threadIdx.x;
+  if (t < count) host_S[t] = S[t];
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+void launch_publish_scalars(const double *S, int count, double *host_S, unsigned long long *host_seq,
+                            unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, s, S, count, host_S, host_seq, seq);
+}
+
 void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s) {
   POGS_CHECK(njobs >= 1 && njobs <= 4, "sum jobs");
   SumJobs j;
