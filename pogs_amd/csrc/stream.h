@@ -18,6 +18,7 @@
 // Column sums are written per workgroup to `col_partials` and combined by
 // reduce_cols (fixed order, no atomics => bit-reproducible).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -458,12 +459,13 @@ void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, 
   if (p.tpb == TPB_ && p.nv == NV_) {                                                           \
     constexpr int R_ = stream2_rows_c(ND, NV_);                                                 \
     const size_t lds = (ND > 1) ? static_cast<size_t>(a.n_pad) * sizeof(T) : 0;                 \
-    static size_t attr_bytes = 48 * 1024;                                                       \
-    if (lds > attr_bytes) {                                                                     \
+    static std::atomic<size_t> attr_bytes{48 * 1024};   /* concurrent solvers share it */       \
+    if (lds > attr_bytes.load(std::memory_order_acquire)) {                                     \
       POGS_HIP_CHECK(hipFuncSetAttribute(                                                       \
           reinterpret_cast<const void *>(&stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>),   \
           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                  \
-      attr_bytes = lds;                                                                         \
+      size_t cur = attr_bytes.load(std::memory_order_relaxed);                                  \
+      while (cur < lds && !attr_bytes.compare_exchange_weak(cur, lds)) {}                       \
     }                                                                                           \
     hipLaunchKernelGGL((stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>), dim3(grid),         \
                        dim3(TPB_), lds, s, a, op);                                              \

@@ -535,3 +535,40 @@ def test_row_sharded_engine_matches_single_rank(dtype, world):
     for out in res[1:]:
         assert out["iterations"] == res[0]["iterations"]
         assert np.array_equal(out["x"], res[0]["x"])
+
+
+@pytest.mark.gpu
+def test_concurrent_one_shot_calls_are_reentrant():
+    """The reference ABI is re-entrant for distinct data (docs/api/c-api.md:333-337): three threads
+    call the one-shot entry at once (dense fp32, dense fp64, sparse) and must get what the same
+    calls return one after the other."""
+    import threading
+
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A1, b1, _ = synth.dense_lasso(1500, 200, seed=41, dtype=np.float32)
+    A2, b2, _ = synth.dense_lasso(700, 90, seed=42, dtype=np.float64)
+    A3, b3, _ = synth.csr_lasso(2500, 600, 15, seed=43, dtype=np.float64)
+    jobs = [lambda: pogs.solve_lasso(A1, b1, 0.1, dtype=np.float32), lambda: pogs.solve_ridge(A2, b2, 0.5),
+            lambda: pogs.solve_lasso(A3, b3, 0.1)]
+    want = [j() for j in jobs]
+    for _ in range(3):
+        got, errs = [None] * 3, []
+
+        def run(i):
+            try:
+                got[i] = jobs[i]()
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(300)
+        assert not errs, errs
+        for g, w in zip(got, want):
+            assert g["status"] == w["status"] == 0
+            assert g["iterations"] == w["iterations"]
+            assert np.array_equal(g["x"], w["x"])
