@@ -252,7 +252,7 @@ struct BcsrDims {
 template <typename T, bool SQ, bool DIRECT, typename Op>
 __global__ void __launch_bounds__(kBlkTpb) spmv_blocked_kernel(const T *__restrict__ a_val,
                                                                 const unsigned short *__restrict__ a_loc,
-                                                                const int *__restrict__ a_bptr,
+                                                                const unsigned short *__restrict__ a_boff,
                                                                 const int2 *__restrict__ a_desc, BcsrDims A,
                                                                 const T *__restrict__ x, const double *x_nrm2, Op op,
                                                                 T *__restrict__ part, double *scalar_partials) {
@@ -288,8 +288,9 @@ __global__ void __launch_bounds__(kBlkTpb) spmv_blocked_kernel(const T *__restri
     const int p0 = lo.y, cnt = hi.y - lo.y;
     if (cnt > kSpCap) return;
     // streamed once per SpMV: non-temporal
-    R.bp[0] = (t <= nq) ? __builtin_nontemporal_load(a_bptr + q0 + t) : 0;
-    R.bp[1] = (t + kBlkTpb <= nq) ? __builtin_nontemporal_load(a_bptr + q0 + kBlkTpb + t) : 0;
+    // row offsets relative to the row block's first non-zero (uint16); slot nq holds the count
+    R.bp[0] = (t < nq) ? static_cast<int>(__builtin_nontemporal_load(a_boff + q0 + t)) : cnt;
+    R.bp[1] = (t + kBlkTpb < nq) ? static_cast<int>(__builtin_nontemporal_load(a_boff + q0 + kBlkTpb + t)) : cnt;
 #pragma unroll
     for (int u = 0; u < kBlkU; ++u) {
       const int k = u * kBlkTpb + t;
@@ -342,8 +343,8 @@ __global__ void __launch_bounds__(kBlkTpb) spmv_blocked_kernel(const T *__restri
       const int k = u * kBlkTpb + t;
       if (k < cnt) sp[k] = (SQ ? R.v[u] * R.v[u] : R.v[u]) * s_x[R.l[u]];
     }
-    spt[t] = static_cast<unsigned short>(R.bp[0] - p0);   // entries past nq are never read
-    spt[kBlkTpb + t] = static_cast<unsigned short>(R.bp[1] - p0);
+    spt[t] = static_cast<unsigned short>(R.bp[0]);   // entries past nq are never read
+    spt[kBlkTpb + t] = static_cast<unsigned short>(R.bp[1]);
     fetch(d + 2, Dc, Dd, R);   // in flight during this and the next row block's reduction
     __syncthreads();
     const int nq = q1 - q0;
@@ -562,6 +563,16 @@ __global__ void bcsr_compact_kernel(const int *flag, const int *pos, const int *
   if (blockIdx.x == 0 && threadIdx.x == 0) desc[pos[nq]] = make_int2(nq, bptr[nq]);
 }
 
+// boff[q] = bptr[q] - (first non-zero of the row block that holds pseudo-row q)
+__global__ void bcsr_offsets_kernel(const int *flag, const int *pos, const int *bptr, const int2 *desc, int nq,
+                                    unsigned short *boff) {
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+    const int d = pos[q] + flag[q] - 1;
+    const int rel = bptr[q] - desc[d].y;
+    boff[q] = static_cast<unsigned short>(rel < 65535 ? rel : 65535);   // only a long row's own offset (0) matters
+  }
+}
+
 // scatter (row, val) of every non-zero into its column segment (order within a
 // segment is fixed afterwards by sort_segments_kernel)
 template <typename T>
@@ -660,7 +671,7 @@ struct DevCsr {
   Csr<T> view() const { return Csr<T>{val.p, ind.p, ptr.p, blocks.p, nrows, nblocks}; }
   // column-blocked copy (see the file header); ncb == 0: not built, the plain kernel runs
   DevBuf<T> bval, part;
-  DevBuf<unsigned short> loc;
+  DevBuf<unsigned short> loc, boff;
   DevBuf<int> bptr;
   DevBuf<int2> bdesc;
   int ncb = 0, nbblocks = 0;
@@ -921,6 +932,9 @@ class SparseSolver final : public SolverBase {
       M.bdesc.alloc(nb + 1);
       hipLaunchKernelGGL(bcsr_compact_kernel, dim3(gq), dim3(256), 0, s, flag.p, pos.p, M.bptr.p, static_cast<int>(nq),
                          M.bdesc.p);
+      M.boff.alloc(nq + 1);
+      hipLaunchKernelGGL(bcsr_offsets_kernel, dim3(gq), dim3(256), 0, s, flag.p, pos.p, M.bptr.p, M.bdesc.p,
+                         static_cast<int>(nq), M.boff.p);
       ctx_.sync();
     }
     if (ncb > 1) M.part.alloc(nq);
@@ -970,14 +984,14 @@ class SparseSolver final : public SolverBase {
         static const bool once = allow_smem(reinterpret_cast<const void *>(&spmv_blocked_kernel<T, SQ, true, Op>), smem);
         (void)once;
         hipLaunchKernelGGL((spmv_blocked_kernel<T, SQ, true, Op>), dim3(g1), dim3(kBlkTpb), smem, s, M.bval.p,
-                           M.loc.p, M.bptr.p, M.bdesc.p, M.bdims(), x, x_nrm2, op, static_cast<T *>(nullptr),
+                           M.loc.p, M.boff.p, M.bdesc.p, M.bdims(), x, x_nrm2, op, static_cast<T *>(nullptr),
                            ctx_.spart.p);
         grid = g1;
       } else {
         static const bool once = allow_smem(reinterpret_cast<const void *>(&spmv_blocked_kernel<T, SQ, false, Op>), smem);
         (void)once;
         hipLaunchKernelGGL((spmv_blocked_kernel<T, SQ, false, Op>), dim3(g1), dim3(kBlkTpb), smem, s, M.bval.p,
-                           M.loc.p, M.bptr.p, M.bdesc.p, M.bdims(), x, x_nrm2, op, M.part.p, ctx_.spart.p);
+                           M.loc.p, M.boff.p, M.bdesc.p, M.bdims(), x, x_nrm2, op, M.part.p, ctx_.spart.p);
         grid = std::max(1, std::min((M.nrows + 255) / 256, spmv_grid_));
         hipLaunchKernelGGL((reduce_parts_kernel<T, Op>), dim3(grid), dim3(256), 0, s, M.part.p, M.nrows, M.ncb, op,
                            ctx_.spart.p);
