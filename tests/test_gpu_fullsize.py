@@ -1,0 +1,175 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through size-independent properties
+(the oracle needs minutes at these sizes): KKT conditions of the returned point, idempotence of the
+projection, linearity of the operator.  Conventions (pinned on small cases against the oracle):
+lambda = grad f(y), mu = -A^T lambda in dg(x), y ~ A x."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LAM = 0.1
+
+
+def _pogs():
+    import pogs_amd
+
+    return pogs_amd
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch
+
+
+def test_c2_dense_lasso_100000x10000_kkt_and_operator_properties():
+    """configs[1]: dense fp32 lasso 100000 x 10000, A resident in HBM (device pointer)."""
+    torch = _torch()
+    pogs = _pogs()
+    m, n = 100000, 10000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float32)
+    xt = torch.randn(n, generator=g, device=dev) * (torch.rand(n, generator=g, device=dev) < 0.1)
+    b = A @ xt + 0.1 * torch.randn(m, generator=g, device=dev)
+    torch.cuda.synchronize()
+    f, gg = pogs.graph.lasso_functions(b.double().cpu().numpy(), LAM, n)
+    with pogs.Solver(A.data_ptr(), dtype=np.float32, shape=(m, n), device_ptr=True) as s:
+        r = s.solve(f, gg)
+        st = s.stats()
+        # operator linearity on the equilibrated matrix the engine holds: A(au + bv) = a Au + b Av
+        rng = np.random.default_rng(1)
+        u, v = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+        zero = np.zeros(m, np.float32)
+        Au, Av = s.mul("n", 1.0, u, 0.0, zero), s.mul("n", 1.0, v, 0.0, zero)
+        Auv = s.mul("n", 1.0, 2.0 * u - 3.0 * v, 0.0, zero)
+        assert np.linalg.norm(Auv - (2.0 * Au - 3.0 * Av)) < 2e-5 * np.linalg.norm(Auv)
+        # adjoint identity <Au, w> = <u, A^T w>
+        w = rng.standard_normal(m).astype(np.float32)
+        Atw = s.mul("t", 1.0, w, 0.0, np.zeros(n, np.float32))
+        assert abs(float(Au.astype(np.float64) @ w) - float(u.astype(np.float64) @ Atw)) < 1e-4 * np.linalg.norm(Au) * np.linalg.norm(w)
+        # projection onto {y = A x}: lands on the graph and is idempotent
+        x0, y0 = rng.standard_normal(n), rng.standard_normal(m)
+        x1, y1 = s.project(x0, y0)
+        x2, y2 = s.project(x1, y1)
+        assert np.linalg.norm(x2 - x1) < 2e-5 * np.linalg.norm(x1)
+        assert np.linalg.norm(y2 - y1) < 2e-5 * np.linalg.norm(y1)
+        assert np.linalg.norm(s.mul("n", 1.0, x1.astype(np.float32), 0.0, zero) - y1) < 2e-5 * np.linalg.norm(y1)
+    assert r["status"] == 0
+    assert 80 <= r["iterations"] + 1 <= 140          # the oracle needs 104-106 on this recipe at smaller m
+    assert st["exact_iters"] >= 1
+    x = torch.from_numpy(r["x"]).to(dev)
+    y = torch.from_numpy(r["y"]).to(dev)
+    lam = torch.from_numpy(r["l"]).to(dev)
+    mu = torch.from_numpy(r["mu"]).to(dev)
+    # primal feasibility at the stopping tolerance (pogs.cpp:272: sqrt(m) atol + rtol |y|), original scale
+    pri = torch.linalg.norm(A @ x - y).item()
+    assert pri < 20 * (np.sqrt(m) * 1e-4 + 1e-4 * torch.linalg.norm(y).item())
+    # lambda = grad f(y) = y - b ; mu = -A^T lambda
+    assert (torch.linalg.norm(lam - (y - b)) / torch.linalg.norm(lam)).item() < 2e-2
+    # the engine's own mu against -A^T lambda: their distance is the dual residual, which the
+    # stopping rule bounds by rho (sqrt(n) atol + rtol |x|) (pogs.cpp:273, up to the equilibration scaling)
+    dua = torch.linalg.norm(mu + A.T @ lam).item()
+    assert dua < 5 * st["rho_final"] * (np.sqrt(n) * 1e-4 + 1e-4 * np.linalg.norm(r["x"]))
+    # mu in the subdifferential of LAM |x|_1
+    muh = (-(A.T @ (y - b))).cpu().numpy().astype(np.float64)
+    xs = r["x"].astype(np.float64)
+    on = np.abs(xs) > 1e-3
+    assert on.sum() > 500
+    # (tolerance-sized: the dual residual above is spread over the n coordinates)
+    print("c2 kkt: max|mu|/lam %.3f, on-support rms %.3f, off-support violation rms %.4f" % (
+        np.max(np.abs(muh)) / LAM, np.linalg.norm(muh[on] - LAM * np.sign(xs[on])) / (LAM * np.sqrt(on.sum())),
+        np.sqrt(np.mean(np.maximum(np.abs(muh[~on]) - LAM, 0) ** 2)) / LAM))
+    assert np.max(np.abs(muh)) < LAM * 3.0
+    assert np.linalg.norm(muh[on] - LAM * np.sign(xs[on])) / (LAM * np.sqrt(on.sum())) < 0.3
+    assert np.sqrt(np.mean(np.maximum(np.abs(muh[~on]) - LAM, 0) ** 2)) < 0.1 * LAM
+    # objective: the returned value matches f(y) + g(x) recomputed, and improves on the planted x_true
+    obj = 0.5 * torch.sum((y - b) ** 2).item() + LAM * np.abs(xs).sum()
+    assert r["optval"] == pytest.approx(obj, rel=2e-3)
+    obj_true = 0.5 * torch.sum((A @ xt - b) ** 2).item() + LAM * torch.sum(torch.abs(xt)).item()
+    assert 0.5 * torch.sum((A @ x - b) ** 2).item() + LAM * np.abs(xs).sum() < obj_true
+
+
+def test_c4_sparse_lasso_2e6x5e5_kkt():
+    """configs[3]: CSR fp32 2e6 x 5e5 with ~1e8 non-zeros (50 per row, duplicates summed)."""
+    torch = _torch()
+    import scipy.sparse as sp
+
+    pogs = _pogs()
+    m, n, k = 2000000, 500000, 50
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    cols, _ = torch.sort(torch.randint(0, n, (m, k), generator=g, device=dev, dtype=torch.int32), dim=1)
+    vals = torch.randn((m, k), generator=g, device=dev, dtype=torch.float32)
+    A = sp.csr_matrix((vals.cpu().numpy().ravel(), cols.cpu().numpy().ravel(), np.arange(0, m * k + 1, k, dtype=np.int32)),
+                      shape=(m, n))
+    del cols, vals
+    A.sum_duplicates()
+    rng = np.random.default_rng(0)
+    xt = rng.standard_normal(n) * (rng.random(n) < 0.05)
+    b = A @ xt + 0.1 * rng.standard_normal(m)
+    r = pogs.solve_lasso(A, b, LAM, dtype=np.float32)
+    assert r["status"] == 0
+    assert r["iterations"] + 1 < 800
+    x, y, lam = r["x"].astype(np.float64), r["y"].astype(np.float64), r["l"].astype(np.float64)
+    Ax = A @ x
+    assert np.linalg.norm(Ax - y) < 20 * (np.sqrt(m) * 1e-4 + 1e-4 * np.linalg.norm(y))
+    assert np.linalg.norm(lam - (y - b)) / np.linalg.norm(lam) < 5e-2
+    mu = -(A.T @ (y - b))
+    on = np.abs(x) > 1e-3
+    assert on.sum() > 1000
+    print("c4 kkt: max|mu|/lam %.3f, on-support rms %.3f, off-support violation rms %.4f, iterations %d" % (
+        np.max(np.abs(mu)) / LAM, np.linalg.norm(mu[on] - LAM * np.sign(x[on])) / (LAM * np.sqrt(on.sum())),
+        np.sqrt(np.mean(np.maximum(np.abs(mu[~on]) - LAM, 0) ** 2)) / LAM, r["iterations"] + 1))
+    assert np.max(np.abs(mu)) < LAM * 3.0
+    assert np.linalg.norm(mu[on] - LAM * np.sign(x[on])) / (LAM * np.sqrt(on.sum())) < 0.3
+    assert np.sqrt(np.mean(np.maximum(np.abs(mu[~on]) - LAM, 0) ** 2)) < 0.1 * LAM
+    obj = 0.5 * np.sum((y - b) ** 2) + LAM * np.abs(x).sum()
+    assert r["optval"] == pytest.approx(obj, rel=5e-3)
+    assert 0.5 * np.sum((Ax - b) ** 2) + LAM * np.abs(x).sum() < 0.5 * np.sum((A @ xt - b) ** 2) + LAM * np.abs(xt).sum()
+
+
+def test_c3_dense_logistic_200000x5000_kkt():
+    """configs[2]: dense fp32 logistic regression 200000 x 5000, lambda = 0.01 (labels from a
+    planted model with logit std 2)."""
+    torch = _torch()
+    pogs = _pogs()
+    m, n, lam1 = 200000, 5000, 0.01
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float32)
+    w = torch.randn(n, generator=g, device=dev) * (torch.rand(n, generator=g, device=dev) < 0.3)
+    w = w * (2.0 / torch.linalg.norm(w))
+    lab = 2.0 * (torch.rand(m, generator=g, device=dev) < torch.sigmoid(A @ w)).float() - 1.0
+    torch.cuda.synchronize()
+    f, gg = pogs.graph.logistic_functions(lab.double().cpu().numpy(), lam1, n)
+    with pogs.Solver(A.data_ptr(), dtype=np.float32, shape=(m, n), device_ptr=True) as s:
+        r = s.solve(f, gg)
+        st = s.stats()
+    assert r["status"] == 0
+    assert r["iterations"] + 1 < 600
+    x = torch.from_numpy(r["x"]).to(dev)
+    y = torch.from_numpy(r["y"]).to(dev)
+    lam = torch.from_numpy(r["l"]).to(dev)
+    pri = torch.linalg.norm(A @ x - y).item()
+    assert pri < 20 * (np.sqrt(m) * 1e-4 + 1e-4 * torch.linalg.norm(y).item())
+    # lambda = grad f(y): d/dy log(1 + exp(-b y)) = -b sigmoid(-b y)
+    grad = -lab * torch.sigmoid(-lab * y)
+    assert (torch.linalg.norm(lam - grad) / torch.linalg.norm(grad)).item() < 5e-2
+    mu = (-(A.T @ grad)).cpu().numpy().astype(np.float64)
+    xs = r["x"].astype(np.float64)
+    on = np.abs(xs) > 1e-3
+    assert on.sum() > 100
+    print("c3 kkt: max|mu|/lam %.3f, on-support rms %.3f, iterations %d" % (
+        np.max(np.abs(mu)) / lam1, np.linalg.norm(mu[on] - lam1 * np.sign(xs[on])) / (lam1 * np.sqrt(on.sum())),
+        r["iterations"] + 1))
+    dua = np.linalg.norm(r["mu"].astype(np.float64) - mu)
+    assert dua < 5 * st["rho_final"] * (np.sqrt(n) * 1e-4 + 1e-4 * np.linalg.norm(xs))
+    loss = lambda yy, xx: torch.sum(torch.nn.functional.softplus(-lab * yy)).item() + lam1 * float(torch.sum(torch.abs(xx)))  # noqa: E731
+    assert r["optval"] == pytest.approx(loss(y, x), rel=2e-3)
+    assert loss(A @ x, x) < loss(torch.zeros(m, device=dev), torch.zeros(n, device=dev))
