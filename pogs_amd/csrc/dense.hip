@@ -103,11 +103,19 @@ class DenseSolver final : public SolverBase {
     POGS_CHECK(!(use_cgls_ && multi_), "the CGLS projector is single-GPU");
     constexpr int VEC = Vec16<T>::N;
     n_pad_ = static_cast<int>(round_up(n, VEC));
+    m_pad_ = static_cast<int>(round_up(m, VEC));
     k_ = tall_ ? n_ : m_;
     k_pad_ = static_cast<int>(round_up(k_, VEC));
-    lda_ = n_pad_;
-    planA_ = make_stream_plan<T>(n_pad_, ctx_.num_cu);
-    POGS_CHECK(planA_.ok, "n too large for the register-tiled streaming kernel");
+    // m <= n with the direct projector: the solver keeps T = A^T (n stored rows of length m), so
+    // the register-tiled row kernel sees rows of min(m, n) elements whatever n is; A x becomes a
+    // column-sum pass and A^T u a row-dot pass (see the adaptors in ops.h)
+    tmode_ = !tall_ && !use_cgls_;
+    srows_ = tmode_ ? n_ : m_;
+    scols_pad_ = tmode_ ? m_pad_ : n_pad_;
+    lda_ = scols_pad_;
+    planA_ = make_stream_plan<T>(scols_pad_, ctx_.num_cu);
+    POGS_CHECK(planA_.ok, tmode_ || tall_ ? "min(m, n) too large for the register-tiled streaming kernel"
+                                          : "n too large for the register-tiled streaming kernel (CGLS projector)");
     ctx_.tmark_last = t0;
     ctx_.tmark("ctx init");
     upload(ord, A, mem);
@@ -190,9 +198,15 @@ class DenseSolver final : public SolverBase {
 
   void get_equil(void *A_eq, void *d, void *e, double *nrmA) override {
     ctx_.sync();
-    if (A_eq)
+    if (A_eq && tmode_) {
+      DevBuf<T> rm(static_cast<size_t>(m_) * n_);
+      launch_transpose<T>(A_.p, lda_, n_, m_, rm.p, n_, ctx_.stream);
+      ctx_.sync();
+      POGS_HIP_CHECK(hipMemcpy(A_eq, rm.p, static_cast<size_t>(m_) * n_ * sizeof(T), hipMemcpyDeviceToHost));
+    } else if (A_eq) {
       POGS_HIP_CHECK(hipMemcpy2D(A_eq, n_ * sizeof(T), A_.p, lda_ * sizeof(T), n_ * sizeof(T), m_,
                                  hipMemcpyDeviceToHost));
+    }
     if (d) POGS_HIP_CHECK(hipMemcpy(d, d_.p, m_ * sizeof(T), hipMemcpyDeviceToHost));
     if (e) POGS_HIP_CHECK(hipMemcpy(e, e_.p, n_ * sizeof(T), hipMemcpyDeviceToHost));
     if (nrmA) *nrmA = nrmA_;
@@ -218,15 +232,12 @@ class DenseSolver final : public SolverBase {
       launch_stream<T, true, false, false, kFull>(planA_, a, GemvNOp<T>{1, 0, y_[0].p}, s);
     } else {
       // projector_direct_dense.cpp:128-135: t = (A A^T + I)^{-1} (A x0 - y0); x = x0 - A^T t; y = y0 + t
-      StreamArgs<T> a = argsA();
-      a.xin = xtemp_.p;
-      launch_stream<T, true, false, false, kFull>(planA_, a, ResidOp<T>{ytemp_.p, rhs_.p}, s);
+      t_mul_n(xtemp_.p, nullptr, ResidOp<T>{ytemp_.p, rhs_.p}, nullptr);
       solve_gram(rhs_.p, static_cast<const T *>(nullptr), GemvNOp<T>{1, 0, tmpn_.p}, nullptr);
       launch_axpby<T>(m_, static_cast<T>(1), ytemp_.p, static_cast<T>(0), y_[0].p, s);
       launch_axpby<T>(m_, static_cast<T>(1), tmpn_.p, static_cast<T>(1), y_[0].p, s);
-      gemv_t_partials(tmpn_.p);
       launch_axpby<T>(n_, static_cast<T>(1), xtemp_.p, static_cast<T>(0), x_[0].p, s);
-      finish_cols(StoreColOp<T>{static_cast<T>(-1), static_cast<T>(1), x_[0].p, n_}, nullptr, 0, 0);
+      t_mul_t(tmpn_.p, StoreColOp<T>{static_cast<T>(-1), static_cast<T>(1), x_[0].p, n_}, nullptr);
     }
     POGS_HIP_CHECK(hipMemcpyAsync(x, x_[0].p, n_ * sizeof(T), hipMemcpyDeviceToHost, s));
     POGS_HIP_CHECK(hipMemcpyAsync(y, y_[0].p, m_ * sizeof(T), hipMemcpyDeviceToHost, s));
@@ -236,6 +247,21 @@ class DenseSolver final : public SolverBase {
   void mul(char trans, double alpha, const void *x, double beta, void *y) override {
     hipStream_t s = ctx_.stream;
     const bool tr = (trans == 't' || trans == 'T');
+    if (tmode_) {
+      if (!tr) {
+        POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, x, n_ * sizeof(T), hipMemcpyHostToDevice, s));
+        POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, y, m_ * sizeof(T), hipMemcpyHostToDevice, s));
+        t_mul_n(xtemp_.p, nullptr, GemvNOp<T>{static_cast<T>(alpha), static_cast<T>(beta), ytemp_.p}, nullptr);
+        POGS_HIP_CHECK(hipMemcpyAsync(y, ytemp_.p, m_ * sizeof(T), hipMemcpyDeviceToHost, s));
+      } else {
+        POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, x, m_ * sizeof(T), hipMemcpyHostToDevice, s));
+        POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, y, n_ * sizeof(T), hipMemcpyHostToDevice, s));
+        t_mul_t(ytemp_.p, StoreColOp<T>{static_cast<T>(alpha), static_cast<T>(beta), xtemp_.p, n_}, nullptr);
+        POGS_HIP_CHECK(hipMemcpyAsync(y, xtemp_.p, n_ * sizeof(T), hipMemcpyDeviceToHost, s));
+      }
+      ctx_.sync();
+      return;
+    }
     if (!tr) {
       POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, x, n_ * sizeof(T), hipMemcpyHostToDevice, s));
       POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, y, m_ * sizeof(T), hipMemcpyHostToDevice, s));
@@ -263,9 +289,25 @@ class DenseSolver final : public SolverBase {
   // ---- setup ---------------------------------------------------------------
   void upload(int ord, const void *A, int mem) {
     hipStream_t s = ctx_.stream;
-    A_.alloc(static_cast<size_t>(m_) * lda_);
+    A_.alloc(static_cast<size_t>(srows_) * lda_);
     const hipMemcpyKind kind = (mem == POGS_AMD_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (ord == ROW_MAJ) {
+    if (tmode_) {
+      // stored matrix = A^T, n rows of m: column-major input already is that; row-major is transposed
+      if (lda_ != static_cast<size_t>(m_)) A_.zero(s);
+      if (ord != ROW_MAJ) {
+        POGS_HIP_CHECK(hipMemcpy2DAsync(A_.p, lda_ * sizeof(T), A, m_ * sizeof(T), m_ * sizeof(T), n_, kind, s));
+      } else {
+        DevBuf<T> stage;
+        const T *src = static_cast<const T *>(A);
+        if (mem != POGS_AMD_DEVICE) {
+          stage.alloc(static_cast<size_t>(m_) * n_);
+          POGS_HIP_CHECK(hipMemcpyAsync(stage.p, A, static_cast<size_t>(m_) * n_ * sizeof(T), kind, s));
+          src = stage.p;
+        }
+        launch_transpose<T>(src, n_, m_, n_, A_.p, lda_, s);
+        ctx_.sync();   // stage is freed at scope exit
+      }
+    } else if (ord == ROW_MAJ) {
       if (lda_ != static_cast<size_t>(n_)) A_.zero(s);
       POGS_HIP_CHECK(hipMemcpy2DAsync(A_.p, lda_ * sizeof(T), A, n_ * sizeof(T), n_ * sizeof(T), m_, kind, s));
     } else {
@@ -287,16 +329,18 @@ class DenseSolver final : public SolverBase {
   void alloc_state() {
     hipStream_t s = ctx_.stream;
     const size_t np = n_pad_;
-    for (int i = 0; i < 2; ++i) { x_[i].alloc(np); y_[i].alloc(m_); x_[i].zero(s); y_[i].zero(s); }
-    xt_.alloc(np); yt_.alloc(m_); xtemp_.alloc(np); ytemp_.alloc(m_);
+    const size_t mp = m_pad_;   // y-sized vectors are vector-loaded by the row kernel when T = A^T is stored
+    for (int i = 0; i < 2; ++i) { x_[i].alloc(np); y_[i].alloc(mp); x_[i].zero(s); y_[i].zero(s); }
+    xt_.alloc(np); yt_.alloc(mp); xtemp_.alloc(np); ytemp_.alloc(mp);
     const size_t kp = std::max<size_t>(np, k_pad_);
-    x12_.alloc(np); y12_.alloc(m_); rhs_.alloc(kp); tvec_.alloc(kp); tmpn_.alloc(kp);
+    x12_.alloc(np); y12_.alloc(mp); rhs_.alloc(kp); tvec_.alloc(kp); tmpn_.alloc(kp);
     xt_.zero(s); yt_.zero(s); xtemp_.zero(s); ytemp_.zero(s); x12_.zero(s); y12_.zero(s);
     rhs_.zero(s); tvec_.zero(s); tmpn_.zero(s);
-    d_.alloc(m_); e_.alloc(np); e_.zero(s);
+    d_.alloc(mp); d_.zero(s); e_.alloc(np); e_.zero(s);
+    if (tmode_) { uvec_.alloc(mp); uvec_.zero(s); }
     xout_.alloc(np); yout_.alloc(m_); lout_.alloc(m_); muout_.alloc(np);
     f_.alloc(m_); g_.alloc(n_); fs_.alloc(m_); gs_.alloc(n_);
-    colpart_.alloc(static_cast<size_t>(planA_.grid_max) * np);
+    colpart_.alloc(static_cast<size_t>(planA_.grid_max) * scols_pad_);
     if (use_cgls_) {
       cg_p_.alloc(np); cg_s_.alloc(np); cg_q_.alloc(m_); cg_r_.alloc(m_); cg_.alloc(kCgNumSlots);
       cg_p_.zero(s); cg_s_.zero(s); cg_.zero(s);
@@ -316,10 +360,52 @@ class DenseSolver final : public SolverBase {
 
   StreamArgs<T> argsA() const {
     StreamArgs<T> a;
-    a.A = A_.p; a.lda = lda_; a.m = m_; a.n_pad = n_pad_;
+    a.A = A_.p; a.lda = lda_; a.m = srows_; a.n_pad = scols_pad_;
     a.xin = nullptr; a.xin_add = nullptr; a.xin_nrm2 = nullptr;
     a.col_partials = colpart_.p; a.scalar_partials = ctx_.spart.p;
     return a;
+  }
+
+  // ---- products on the transposed storage (tmode_): same contracts as a row-dot pass with a row
+  // functor over the m rows of A / a column-sum pass with a column functor over its n columns
+  template <typename RowOp>
+  void t_mul_n(const T *xin, const T *xin_add, const RowOp &op, double *scalar_out, const double *x_nrm2 = nullptr) {
+    hipStream_t s = ctx_.stream;
+    if (!tmode_) {
+      StreamArgs<T> a = argsA();
+      a.xin = xin; a.xin_add = xin_add; a.xin_nrm2 = x_nrm2;
+      ctx_.stream_timer.begin(s);
+      launch_stream<T, true, false, false, kFull>(planA_, a, op, s);
+      ctx_.stream_timer.end(s);
+      if (RowOp::NS > 0 && scalar_out) sum_row_scalars(stream_grid<true, false>(planA_, srows_), RowOp::NS, scalar_out);
+      return;
+    }
+    StreamArgs<T> a = argsA();
+    ctx_.stream_timer.begin(s);
+    launch_stream<T, false, true, false, kFull>(planA_, a, VecCoefOp<T>{xin, xin_add, x_nrm2}, s);
+    ctx_.stream_timer.end(s);
+    double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
+    launch_reduce_cols<T, RowAsColOp<T, RowOp>>(colpart_.p, stream_grid<false, true>(planA_, srows_), scols_pad_,
+                                                RowAsColOp<T, RowOp>{op, m_}, sp, s);
+    if (RowOp::NS > 0 && scalar_out) {
+      SumJob j{sp, reduce_cols_grid(scols_pad_, Vec16<T>::N), RowOp::NS, scalar_out};
+      launch_sum_jobs(&j, 1, s);
+    }
+  }
+  template <typename ColOp>
+  void t_mul_t(const T *u, const ColOp &op, double *scalar_out) {
+    hipStream_t s = ctx_.stream;
+    if (!tmode_) {
+      gemv_t_partials(u);
+      finish_cols(op, scalar_out, 0, 0);
+      return;
+    }
+    StreamArgs<T> a = argsA();
+    a.xin = u;   // length m, zero-padded to the vector width
+    ctx_.stream_timer.begin(s);
+    launch_stream<T, true, false, false, kFull>(planA_, a, ColAsRowOp<T, ColOp>{op}, s);
+    ctx_.stream_timer.end(s);
+    if (ColOp::NS > 0 && scalar_out) sum_row_scalars(stream_grid<true, false>(planA_, srows_), ColOp::NS, scalar_out);
   }
 
   // Second stage of a column-sum pass.  With row shards the totals are
@@ -367,36 +453,51 @@ class DenseSolver final : public SolverBase {
     const double mg = static_cast<double>(ctx_.m_global), nn = n_;
     const T ce = static_cast<T>(1e-4) * static_cast<T>(mg + nn) / static_cast<T>(mg);   // equil_helper.h:152-153
     const T cd = static_cast<T>(1e-4) * static_cast<T>(mg + nn) / static_cast<T>(nn);   // :159-160
-    const int gridACC = stream_grid<false, true>(planA_, m_);
-    const int gridBOTH = stream_grid<true, true>(planA_, m_);
+    const int gridACC = stream_grid<false, true>(planA_, srows_);
+    const int gridBOTH = stream_grid<true, true>(planA_, srows_);
     StreamArgs<T> a = argsA();
     ctx_.tmark("  eq: start");
-    launch_stream<T, false, true, true, kFull>(planA_, a, OnesOp<T>{}, s);
-    ctx_.tmark("  eq: first pass");
-    finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_}, nullptr, 0, 0, gridACC);
-    ctx_.tmark("  eq: first cols");
-    for (int k = 0; k < 50; ++k) {
-      a.xin = e_.p;
-      if (k < 49) {
-        launch_stream<T, true, true, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
-        finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_}, nullptr, 0, 0, gridBOTH);
-      } else {
-        launch_stream<T, true, false, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
+    if (tmode_) {
+      // stored rows are the columns of A: one fused pass per iteration, the row dot (with d) gives
+      // e_j, the column sums (weighted by e_j) give d   (equil_helper.h:149-163, d = 1 to start)
+      double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
+      launch_fill<T>(d_.p, static_cast<T>(1), m_, s);
+      for (int k = 0; k < 50; ++k) {
+        a.xin = d_.p;
+        launch_stream<T, true, true, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(mg), ce, e_.p}, s);
+        launch_reduce_cols<T, SkColOp<T>>(colpart_.p, gridBOTH, scols_pad_, SkColOp<T>{static_cast<T>(nn), cd, d_.p, m_},
+                                          sp, s);
       }
+      ctx_.stats.matvecs_init += 50;
+    } else {
+      launch_stream<T, false, true, true, kFull>(planA_, a, OnesOp<T>{}, s);
+      ctx_.tmark("  eq: first pass");
+      finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_}, nullptr, 0, 0, gridACC);
+      ctx_.tmark("  eq: first cols");
+      for (int k = 0; k < 50; ++k) {
+        a.xin = e_.p;
+        if (k < 49) {
+          launch_stream<T, true, true, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
+          finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_}, nullptr, 0, 0, gridBOTH);
+        } else {
+          launch_stream<T, true, false, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
+        }
+      }
+      ctx_.stats.matvecs_init += 51;
     }
-    ctx_.stats.matvecs_init += 51;
     ctx_.tmark("  eq: sk loop");
     launch_sqrt_inplace<T>(d_.p, m_, s);                                  // matrix_dense.cpp:176-177
     launch_sqrt_inplace<T>(e_.p, n_, s);
-    const int sgrid = std::min(m_, ctx_.num_cu * 8);
-    hipLaunchKernelGGL(scale_de_kernel<T>, dim3(sgrid), dim3(256), 0, s, A_.p, lda_, m_, n_pad_, d_.p, e_.p,
-                       ctx_.spart.p);
+    const int sgrid = std::min(srows_, ctx_.num_cu * 8);
+    // rows of the stored matrix are scaled by the first vector, its columns by the second
+    hipLaunchKernelGGL(scale_de_kernel<T>, dim3(sgrid), dim3(256), 0, s, A_.p, lda_, srows_, scols_pad_,
+                       tmode_ ? e_.p : d_.p, tmode_ ? d_.p : e_.p, ctx_.spart.p);
     sum_row_scalars(sgrid, 1, ctx_.S.p + kFro2);
     if (multi_) ctx_.dist.allreduce(ctx_.S.p + kFro2, 1, s);
     const double *S = ctx_.fetch_scalars();
     const T normA = static_cast<T>(std::sqrt(S[kFro2])) /
                     std::sqrt(static_cast<T>(std::min<double>(mg, nn)));   // :215-218
-    const size_t nvec = static_cast<size_t>(m_) * lda_ / Vec16<T>::N;
+    const size_t nvec = static_cast<size_t>(srows_) * lda_ / Vec16<T>::N;
     hipLaunchKernelGGL(scale_all_kernel<T>, dim3(ctx_.num_cu * 8), dim3(256), 0, s, A_.p, nvec,
                        static_cast<T>(1) / normA);                         // :186
     const T invs = static_cast<T>(1) / std::sqrt(normA);                   // :191-192
@@ -416,9 +517,20 @@ class DenseSolver final : public SolverBase {
     T *xa = xtemp_.p, *xb = rhs_.p;
     const T kTol = static_cast<T>(1e-4);
     T norm_est = 0, last;
-    const int grid = stream_grid<true, true>(planA_, m_);
+    const int grid = stream_grid<true, true>(planA_, srows_);
     unsigned i = 0;
-    for (i = 0; i < 50; ++i) {
+    for (i = 0; tmode_ && i < 50; ++i) {
+      // transposed storage: Sx = A (x / |x|) is a column-sum pass, x' = A^T Sx a row-dot pass
+      last = norm_est;
+      t_mul_n(xa, nullptr, StoreNormRowOp<T>{ytemp_.p}, ctx_.S.p + kPowSx2, (i == 0) ? nullptr : ctx_.S.p + kPowX2);
+      t_mul_t(ytemp_.p, PowerColOp<T>{xb, n_}, ctx_.S.p + kPowX2);
+      const double *S = ctx_.fetch_scalars();
+      norm_est = static_cast<T>(std::sqrt(S[kPowX2])) / static_cast<T>(std::sqrt(S[kPowSx2]));
+      std::swap(xa, xb);
+      ctx_.stats.matvecs_init += 2;
+      if (std::abs(last - norm_est) < kTol * norm_est) { ++i; break; }
+    }
+    for (; !tmode_ && i < 50; ++i) {
       last = norm_est;
       StreamArgs<T> a = argsA();
       a.xin = xa;
@@ -442,6 +554,7 @@ class DenseSolver final : public SolverBase {
     // leave the work vectors clean
     xtemp_.zero(s);
     rhs_.zero(s);
+    ytemp_.zero(s);
     ctx_.stats.normest_ms = pt.stop_ms();
   }
 
@@ -545,7 +658,7 @@ class DenseSolver final : public SolverBase {
         g.ks0 = ks;
         g.ksplit = nb;
         g.C = first ? G : G + slab;
-        launch_gemm<T>(tall_, tall_, true, g, s);
+        launch_gemm<T>(tall_ || tmode_, tall_ || tmode_, true, g, s);   // K-major when the stored rows are the K index
         if (ksplit > 1) launch_sum_slabs<T>(G, slab, first ? nb : nb + 1, G, ld, k_, s);   // in place: slab 0 is G
         ks += nb;
       }
@@ -717,12 +830,17 @@ class DenseSolver final : public SolverBase {
     POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, warm_x_.data(), n_ * sizeof(T), hipMemcpyHostToDevice, s));
     POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, warm_l_.data(), m_ * sizeof(T), hipMemcpyHostToDevice, s));
     launch_scale_by<T>(n_, static_cast<T>(1), xtemp_.p, e_.p, true, x_[cur_].p, s);            // x = x0 / e
-    StreamArgs<T> a = argsA();
-    a.xin = x_[cur_].p;
-    launch_stream<T, true, false, false, kFull>(planA_, a, GemvNOp<T>{1, 0, y_[cur_].p}, s);     // y = A x
     launch_scale_by<T>(m_, static_cast<T>(1), ytemp_.p, d_.p, true, yt_.p, s);                  // l0 / d
-    gemv_t_partials(yt_.p);
-    finish_cols(StoreColOp<T>{static_cast<T>(1) / rho, 0, xt_.p, n_}, nullptr, 0, 0);           // xt = A^T (l0/d) / rho
+    if (tmode_) {
+      t_mul_n(x_[cur_].p, nullptr, GemvNOp<T>{1, 0, y_[cur_].p}, nullptr);                      // y = A x
+      t_mul_t(yt_.p, StoreColOp<T>{static_cast<T>(1) / rho, 0, xt_.p, n_}, nullptr);            // xt = A^T (l0/d) / rho
+    } else {
+      StreamArgs<T> a = argsA();
+      a.xin = x_[cur_].p;
+      launch_stream<T, true, false, false, kFull>(planA_, a, GemvNOp<T>{1, 0, y_[cur_].p}, s);   // y = A x
+      gemv_t_partials(yt_.p);
+      finish_cols(StoreColOp<T>{static_cast<T>(1) / rho, 0, xt_.p, n_}, nullptr, 0, 0);         // xt = A^T (l0/d) / rho
+    }
     launch_scal<T>(yt_.p, static_cast<T>(-1) / rho, m_, s);                                     // yt = -(l0/d) / rho
     ctx_.sync();
     xtemp_.zero(s);
@@ -784,15 +902,10 @@ class DenseSolver final : public SolverBase {
       if (multi) ctx_.dist.allreduce(ctx_.S.p + kDYprev2, 2, s);
     } else {
       // (2') m <= n: t = (A A^T + I)^{-1} (A xtemp - ytemp); x = xtemp - A^T t; y = ytemp + t   (:128-135)
-      StreamArgs<T> a = argsA();
-      a.xin = xtemp_.p;
-      ctx_.stream_timer.begin(s);
-      launch_stream<T, true, false, false, kFull>(planA_, a, ResidOp<T>{ytemp_.p, rhs_.p}, s);
-      ctx_.stream_timer.end(s);
+      t_mul_n(xtemp_.p, nullptr, ResidOp<T>{ytemp_.p, rhs_.p}, nullptr);
       solve_gram(rhs_.p, static_cast<const T *>(nullptr),
                  ProjTailAddOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p}, ctx_.S.p + kDYprev2);
-      gemv_t_partials(tmpn_.p);
-      finish_cols(ProjTailColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_}, ctx_.S.p + kDXprev2, 0, 0);
+      t_mul_t(tmpn_.p, ProjTailColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_}, ctx_.S.p + kDXprev2);
     }
     if (!use_cgls_) ctx_.stats.matvecs += 2;
     const double *S = ctx_.fetch_scalars();
@@ -801,14 +914,29 @@ class DenseSolver final : public SolverBase {
     if (ctl_.set_approx(S, nrmA_)) {
       // (3) exact residuals in one fused pass (pogs.cpp:352-376)
       StreamArgs<T> a = argsA();
-      a.xin = x12_.p;
-      ctx_.stream_timer.begin(s);
-      launch_stream<T, true, true, false, kFull>(planA_, a,
-                                                 ExactRowOp<T>{y12_.p, yt_.p, y_[cur_].p, zt_scale_}, s);
-      ctx_.stream_timer.end(s);
-      const int grid = stream_grid<true, true>(planA_, m_);
-      sum_row_scalars(grid, 1, ctx_.S.p + kExactR2);
-      finish_cols(ExactColOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_, n_}, ctx_.S.p + kExactS2, kExactR2, 1, grid);
+      const int grid = stream_grid<true, true>(planA_, srows_);
+      if (tmode_) {
+        // stored rows = columns of A: the row dot with u = y12 + c yt - yprev is (A^T u)_j (dual
+        // residual), the column sums weighted by x12_j are A x12 (primal residual)
+        launch_exact_u<T>(m_, y12_.p, yt_.p, y_[cur_].p, zt_scale_, uvec_.p, s);
+        a.xin = uvec_.p;
+        ctx_.stream_timer.begin(s);
+        launch_stream<T, true, true, false, kFull>(planA_, a, ExactTRowOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_}, s);
+        ctx_.stream_timer.end(s);
+        sum_row_scalars(grid, 1, ctx_.S.p + kExactS2);
+        double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
+        launch_reduce_cols<T, ExactTColOp<T>>(colpart_.p, grid, scols_pad_, ExactTColOp<T>{y12_.p, m_}, sp, s);
+        SumJob j{sp, reduce_cols_grid(scols_pad_, Vec16<T>::N), 1, ctx_.S.p + kExactR2};
+        launch_sum_jobs(&j, 1, s);
+      } else {
+        a.xin = x12_.p;
+        ctx_.stream_timer.begin(s);
+        launch_stream<T, true, true, false, kFull>(planA_, a,
+                                                   ExactRowOp<T>{y12_.p, yt_.p, y_[cur_].p, zt_scale_}, s);
+        ctx_.stream_timer.end(s);
+        sum_row_scalars(grid, 1, ctx_.S.p + kExactR2);
+        finish_cols(ExactColOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_, n_}, ctx_.S.p + kExactS2, kExactR2, 1, grid);
+      }
       ctx_.stats.matvecs += 1;
       S = ctx_.fetch_scalars();
       ctl_.set_exact(S);
@@ -995,6 +1123,9 @@ class DenseSolver final : public SolverBase {
   Ctx ctx_;
   int m_ = 0, n_ = 0, n_pad_ = 0, k_ = 0, k_pad_ = 0;
   bool tall_ = true, multi_ = false, use_cgls_ = false;
+  bool tmode_ = false;          // A^T is what is stored (m <= n, direct projector)
+  int m_pad_ = 0, srows_ = 0, scols_pad_ = 0;   // stored rows / padded stored row length
+  DevBuf<T> uvec_;              // tmode_: y12 + c yt - yprev for the exact-residual pass
   DevBuf<T> cg_p_, cg_s_, cg_q_, cg_r_;
   DevBuf<double> cg_;
   size_t lda_ = 0;

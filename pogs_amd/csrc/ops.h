@@ -36,6 +36,91 @@ struct GemvTOp {
   __device__ __forceinline__ T u(int i) const { return alpha * x[i]; }
 };
 
+// ---- transposed storage (m <= n: the solver keeps T = A^T, rows of length m) ----------------
+// A x is then a column-sum pass over T (coefficient x_j per stored row j) and A^T u a
+// row-dot pass, so the functors trade places: these adaptors let a row functor finish a
+// column-sum pass and a column functor finish a row-dot pass.
+template <typename T, typename Op>
+struct RowAsColOp {
+  static constexpr int NS = Op::NS;
+  Op op;
+  int n;   // valid entries (padding columns are skipped)
+  template <int N>
+  __device__ __forceinline__ void col(int j, T total, double (&s)[N]) const {
+    if (j < n) (void)op.row(j, total, s);
+  }
+};
+template <typename T, typename Op>
+struct ColAsRowOp {
+  static constexpr int NS = Op::NS;
+  Op op;
+  template <int N>
+  __device__ __forceinline__ T row(int i, T dot, double (&s)[N]) const {
+    op.col(i, dot, s);
+    return 0;
+  }
+  __device__ __forceinline__ T u(int) const { return 0; }
+};
+
+// ACC-only: u_j = (x_j + add_j) * sc, sc = 1 / sqrt(*x_nrm2) when given (lazy normalisation)
+template <typename T>
+struct VecCoefOp {
+  static constexpr int NS = 0;
+  const T *x, *add;
+  const double *x_nrm2;
+  template <int N>
+  __device__ __forceinline__ T row(int, T, double (&)[N]) const { return 0; }
+  __device__ __forceinline__ T u(int j) const {
+    T v = add ? x[j] + add[j] : x[j];
+    if (x_nrm2) v *= static_cast<T>(1.0 / sqrt(*x_nrm2));
+    return v;
+  }
+};
+
+// row-dot pass: out_j = dot, accumulates |out|^2
+template <typename T>
+struct StoreNormRowOp {
+  static constexpr int NS = 1;
+  T *out;
+  template <int N>
+  __device__ __forceinline__ T row(int j, T dot, double (&s)[N]) const {
+    out[j] = dot;
+    s[0] += static_cast<double>(dot) * dot;
+    return dot;
+  }
+  __device__ __forceinline__ T u(int) const { return 0; }
+};
+
+// Exact residuals on T in one pass (pogs.cpp:352-376): the stored row j sees dot = (A^T u)_j,
+// u = y12 + c yt - yprev given as a vector; dual residual s_j = dot + x12_j + c xt_j - xprev_j,
+// and x12_j is returned so that the same pass accumulates A x12 for the primal residual.
+template <typename T>
+struct ExactTRowOp {
+  static constexpr int NS = 1;
+  const T *x12, *xt, *xprev;
+  T zt_scale;
+  template <int N>
+  __device__ __forceinline__ T row(int j, T dot, double (&s)[N]) const {
+    const T v = dot + x12[j] + zt_scale * xt[j] - xprev[j];
+    s[0] += static_cast<double>(v) * v;
+    return x12[j];
+  }
+  __device__ __forceinline__ T u(int) const { return 0; }
+};
+template <typename T>
+struct ExactTColOp {   // r_i = (A x12)_i - y12_i
+  static constexpr int NS = 1;
+  const T *y12;
+  int m;
+  template <int N>
+  __device__ __forceinline__ void col(int i, T total, double (&s)[N]) const {
+    if (i < m) {
+      const T r = total - y12[i];
+      s[0] += static_cast<double>(r) * r;
+    }
+  }
+};
+
 // ACC-only with u = 1: column sums (of squares) -- first Sinkhorn-Knopp half step
 // with d = 1 (equil_helper.h:146-151).
 template <typename T>

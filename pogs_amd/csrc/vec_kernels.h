@@ -95,6 +95,10 @@ struct SumJob {
 void launch_publish_scalars(const double *S, int count, double *host_S, unsigned long long *host_seq,
                             unsigned long long seq, hipStream_t s);
 
+// u = y12 + c yt - yprev   (pogs.cpp:366-368, y half)
+template <typename T>
+void launch_exact_u(int m, const T *y12, const T *yt, const T *yprev, T c, T *u, hipStream_t s);
+
 void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s);
 
 // Misc vector helpers.

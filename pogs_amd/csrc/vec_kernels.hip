@@ -236,6 +236,18 @@ void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s) {
   hipLaunchKernelGGL(sum_jobs_kernel, dim3(njobs), dim3(256), 0, s, j);
 }
 
+namespace {
+template <typename T>
+__global__ void exact_u_vec_kernel(int m, const T *y12, const T *yt, const T *yprev, T c, T *u) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) u[i] = y12[i] + c * yt[i] - yprev[i];
+}
+}  // namespace
+template <typename T>
+void launch_exact_u(int m, const T *y12, const T *yt, const T *yprev, T c, T *u, hipStream_t s) {
+  if (m) hipLaunchKernelGGL(exact_u_vec_kernel<T>, dim3((m + 255) / 256), dim3(256), 0, s, m, y12, yt, yprev, c, u);
+}
+
 template <typename T>
 void launch_fill(T *p, T v, size_t n, hipStream_t s) {
   if (n) hipLaunchKernelGGL(fill_kernel<T>, grid1d(n), dim3(256), 0, s, p, v, n);
@@ -263,6 +275,7 @@ void launch_axpby(size_t n, T a, const T *x, T b, T *y, hipStream_t s) {
   template void launch_func_eval<T>(int, FnView<T>, const T *, double *, hipStream_t);                   \
   template void launch_prox_eval<T>(int, FnView<T>, T, const T *, T *, hipStream_t);                     \
   template void launch_unscale<T>(const UnscaleArgs<T> &, hipStream_t);                                  \
+  template void launch_exact_u<T>(int, const T *, const T *, const T *, T, T *, hipStream_t);            \
   template void launch_fill<T>(T *, T, size_t, hipStream_t);                                             \
   template void launch_sqrt_inplace<T>(T *, size_t, hipStream_t);                                        \
   template void launch_scal<T>(T *, T, size_t, hipStream_t);                                             \

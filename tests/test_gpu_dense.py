@@ -572,3 +572,49 @@ def test_concurrent_one_shot_calls_are_reentrant():
             assert g["status"] == w["status"] == 0
             assert g["iterations"] == w["iterations"]
             assert np.array_equal(g["x"], w["x"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,shape", [(np.float32, (300, 50000)), (np.float64, (200, 20000)), (np.float32, (33, 40001))])
+def test_wide_matrix_with_many_columns(dtype, shape):
+    """m <= n with n far beyond one register-tiled row (32768 fp32 / 16384 fp64 columns): the
+    engine stores A^T (rows of length m), so only min(m, n) is bounded.  Equilibration, norm
+    estimate, operator, projection and the full solve against the oracle (AA^T branch,
+    projector_direct_dense.cpp:128-135)."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    m, n = shape
+    A, b, _ = synth.dense_lasso(m, n, seed=29, dtype=dtype)
+    lam = 0.3 * np.max(np.abs(A.T.astype(np.float64) @ b))   # (lambda = 0.1 needs > 2500 iterations this wide)
+    f, g = pogs.graph.lasso_functions(b, lam, n)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype, want_de=True)
+    rng = np.random.default_rng(3)
+    with pogs.Solver(A, dtype=dtype) as s:
+        A_eq, d, e, nrmA = s.equilibrated()
+        assert relerr(d, want["d"]) < _tol(dtype, 1e-9, 2e-4)
+        assert relerr(e, want["e"]) < _tol(dtype, 1e-9, 2e-4)
+        assert relerr(A_eq, (want["d"][:, None] * A.astype(np.float64)) * want["e"][None, :]) < _tol(dtype, 1e-9, 3e-4)
+        assert nrmA == pytest.approx(want["info"]["nrmA"], rel=_tol(dtype, 1e-6, 1e-3))
+        x, y = rng.standard_normal(n), rng.standard_normal(m)
+        A64 = A_eq.astype(np.float64)
+        assert relerr(s.mul("n", 1.0, x, 0.0, y), A64 @ x) < _tol(dtype, 1e-12, 2e-5)
+        assert relerr(s.mul("t", 2.0, y, -1.0, x), 2.0 * (A64.T @ y) - x) < _tol(dtype, 1e-12, 2e-5)
+        px, py = s.project(x, y)
+        eps = _tol(dtype, 1e-9, 2e-4)
+        assert np.linalg.norm(A64 @ px - py) / np.sqrt(m) < eps
+        assert np.linalg.norm(A64.T @ (py - y) + (px - x)) / np.sqrt(n) < eps
+        got = s.solve(f, g)
+        warm = s.solve(f, g, x0=got["x"], l0=got["l"])
+        fr, gr = pogs.graph.ridge_functions(b, 1.0, n)
+        ridge = s.solve(fr, gr)
+    want_r = ob.oracle_solve(A, soa(fr), soa(gr), dtype=dtype)
+    assert ridge["status"] == want_r["status"] == 0
+    assert abs(int(ridge["iterations"]) - int(want_r["iterations"])) <= (1 if dtype == np.float64 else 10)
+    assert relerr(ridge["x"], want_r["x"]) < _tol(dtype, 1e-6, 3e-4)
+    assert got["status"] == want["status"] == 0
+    assert abs(int(got["iterations"]) - int(want["iterations"])) <= (1 if dtype == np.float64 else max(3, want["iterations"] // 10))
+    assert relerr(got["x"], want["x"]) < _tol(dtype, 1e-6, 3e-4)
+    assert relerr(got["y"], want["y"]) < _tol(dtype, 1e-6, 3e-4)
+    assert got["optval"] == pytest.approx(want["optval"], rel=_tol(dtype, 1e-7, 2e-4))
+    assert warm["status"] == 0 and warm["iterations"] * 2 < got["iterations"]
