@@ -618,3 +618,37 @@ def test_wide_matrix_with_many_columns(dtype, shape):
     assert relerr(got["y"], want["y"]) < _tol(dtype, 1e-6, 3e-4)
     assert got["optval"] == pytest.approx(want["optval"], rel=_tol(dtype, 1e-7, 2e-4))
     assert warm["status"] == 0 and warm["iterations"] * 2 < got["iterations"]
+
+
+@pytest.mark.gpu
+def test_degenerate_inputs_behave_like_the_reference_algorithm():
+    """Zero / empty matrices (0/0 in the normalisation -> NaN iterates, MAX_ITER), max_iter 1 and 2,
+    a NaN entry, rank deficiency, duplicated columns: same status, iteration count and (non-)finite
+    result as the oracle, through the one-shot entry points."""
+    import scipy.sparse as sp
+
+    pogs = _pogs()
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((60, 30))
+    An = A.copy()
+    An[3, 4] = np.nan
+    cases = [
+        ("zero tall", np.zeros((50, 20)), rng.standard_normal(50), 2500),
+        ("zero wide", np.zeros((20, 50)), rng.standard_normal(20), 2500),
+        ("empty csr", sp.csr_matrix((50, 20)), rng.standard_normal(50), 2500),
+        ("max_iter 1", A, rng.standard_normal(60), 1),
+        ("max_iter 2", A, rng.standard_normal(60), 2),
+        ("nan entry", An, rng.standard_normal(60), 50),
+        ("rank one", np.outer(rng.standard_normal(80), rng.standard_normal(25)), rng.standard_normal(80), 2500),
+        ("duplicate columns", np.hstack([A, A]), rng.standard_normal(60), 2500),
+    ]
+    for tag, M, b, max_iter in cases:
+        n = M.shape[1]
+        f, g = pogs.graph.lasso_functions(b, 0.1, n)
+        got = pogs.graph._solve_graph_form(M, f, g, 1e-4, 1e-4, max_iter, 0, 1.0, dtype=np.float64)
+        want = ob.oracle_solve(M, soa(f), soa(g), dtype=np.float64, max_iter=max_iter)
+        assert got["status"] == want["status"], tag
+        assert got["iterations"] == want["iterations"], tag
+        assert np.array_equal(np.isfinite(got["x"]), np.isfinite(want["x"])), tag
+        if np.all(np.isfinite(want["x"])) and np.linalg.norm(want["x"]) > 0:
+            assert relerr(got["x"], want["x"]) < 1e-6, tag
