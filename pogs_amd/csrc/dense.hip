@@ -125,7 +125,7 @@ class DenseSolver final : public SolverBase {
     ctx_.tmark("alloc_state");
     equilibrate();
     ctx_.tmark("equilibrate");
-    if (!tall_ || use_cgls_) norm_est();   // direct, m > n: estimated from the Gram matrix inside factor()
+    if (use_cgls_) norm_est();   // direct projector: estimated from the Gram matrix inside factor()
     if (!use_cgls_) factor();
     ctx_.sync();
     ctx_.stats.t_init_s = wall_s() - t0;
@@ -606,6 +606,59 @@ class DenseSolver final : public SolverBase {
     ctx_.stats.normest_ms = pt.stop_ms();
   }
 
+  // Norm2Est for m <= n on G = A A^T.  With y = A x^ (x^ the normalised iterate) the reference's
+  // step x' = A^T (A x^), est = |x'| / |A x^|, x^ <- x' / |x'| reads  |x'|^2 = y^T G y,
+  // |A x^| = |y|,  y <- G y / |x'|:  after ONE product with A (y0 = A x0, x0 the same random
+  // start vector, un-normalised as in equil_helper.h:113-121) every power step is a symmetric
+  // m x m product instead of two passes over A.
+  void norm_est_gram_wide(T *G, size_t ld) {
+    hipStream_t s = ctx_.stream;
+    PhaseTimer pt(s);
+    launch_zero_upper<T>(G, ld, k_, s);
+    std::vector<T> x0(n_pad_, 0);
+    rand_uniform_host(x0.data(), n_);
+    POGS_HIP_CHECK(hipMemcpyAsync(xtemp_.p, x0.data(), n_pad_ * sizeof(T), hipMemcpyHostToDevice, s));
+    ctx_.sync();
+    T *ya = ytemp_.p, *yb = uvec_.p;
+    t_mul_n(xtemp_.p, nullptr, StoreNormRowOp<T>{ya}, ctx_.S.p + kPowSx2);   // y0 = A x0, |y0|^2
+    ctx_.stats.matvecs_init += 1;
+    const T kTol = static_cast<T>(1e-4);
+    T norm_est = 0, last;
+    const int grid = stream_grid<true, true>(planW_, k_);
+    double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
+    double y2 = ctx_.fetch_scalars()[kPowSx2];   // |y^|^2 of the current iterate
+    unsigned i = 0;
+    for (i = 0; i < 50; ++i) {
+      last = norm_est;
+      // the stored iterate is w = G y^_prev; y^ = w / sqrt(y^_prev^T G y^_prev): normaliser = previous kPowXGx
+      const double *nrm = (i == 0) ? nullptr : ctx_.S.p + kPowXGx;
+      StreamArgs<T> a;
+      a.A = G; a.lda = ld; a.m = k_; a.n_pad = k_pad_;
+      a.xin = ya; a.xin_add = nullptr; a.xin_nrm2 = nrm;
+      a.col_partials = colpart_.p; a.scalar_partials = ctx_.spart.p;
+      launch_stream<T, true, true, false, kLower>(planW_, a, SymRowOp<T>{G, ld, ya, nrm, tvec_.p}, s);
+      launch_reduce_cols<T, SymColOp<T>>(colpart_.p, grid, k_pad_, SymColOp<T>{tvec_.p, ya, nrm, yb, k_}, sp, s);
+      double *tmp2 = ctx_.S.p + kPowX2;   // -> kPowX2 = |G y^|^2, kPowXGx = y^^T G y^ = |x'|^2
+      const double prev_xgx = (i == 0) ? 1.0 : ctx_.S_host.p[kPowXGx];
+      const double prev_w2 = (i == 0) ? y2 : ctx_.S_host.p[kPowX2];
+      SumJob j{sp, reduce_cols_grid(k_pad_, Vec16<T>::N), 2, tmp2};
+      launch_sum_jobs(&j, 1, s);
+      const double *S = ctx_.fetch_scalars();
+      y2 = prev_w2 / prev_xgx;                                   // |y^|^2 = |w|^2 / normaliser^2
+      norm_est = static_cast<T>(std::sqrt(S[kPowXGx])) / static_cast<T>(std::sqrt(y2));
+      std::swap(ya, yb);
+      if (std::abs(last - norm_est) < kTol * norm_est) { ++i; break; }
+    }
+    nrmA_ = norm_est;
+    ctx_.stats.nrmA = nrmA_;
+    ctx_.stats.norm_est_iters = i;
+    xtemp_.zero(s);
+    ytemp_.zero(s);
+    uvec_.zero(s);
+    tvec_.zero(s);
+    ctx_.stats.normest_ms = pt.stop_ms();
+  }
+
   // ProjectorDirect::Init + the first-call factorisation (s = 1 always,
   // pogs.cpp:293,296): G = A^T A (m > n) or A A^T (m <= n) on MFMA tiles,
   // L L^T = G + I, W = L^{-1}, U = W^T.
@@ -670,6 +723,7 @@ class DenseSolver final : public SolverBase {
     }
     ctx_.tmark("gram");
     if (tall_) norm_est_gram(G, ld);
+    else if (tmode_) norm_est_gram_wide(G, ld);
     ctx_.tmark("norm_est_gram");
     launch_add_diag<T>(G, ld, k_, static_cast<T>(1), s);                 // projector_direct_dense.cpp:118-119
     {
