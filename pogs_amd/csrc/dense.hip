@@ -346,8 +346,12 @@ class DenseSolver final : public SolverBase {
       cg_p_.zero(s); cg_s_.zero(s); cg_.zero(s);
     }
     const char *fe = std::getenv("POGS_AMD_FUSED");
-    fused_ok_ = tall_ && !use_cgls_ && stream2_supported(planA_) && !(fe && fe[0] == '0');
-    if (fused_ok_) {
+    fused_ok_ = (tall_ || tmode_) && !use_cgls_ && stream2_supported(planA_) && !(fe && fe[0] == '0');
+    if (fused_ok_ && tmode_) {
+      colpart2_.alloc(static_cast<size_t>(planA_.grid_max) * scols_pad_);
+      x12s_.alloc(np); xtemps_.alloc(np);
+      x12s_.zero(s); xtemps_.zero(s);
+    } else if (fused_ok_) {
       colpart2_.alloc(static_cast<size_t>(planA_.grid_max) * np);
       pair_.alloc(2 * np);
       pair_.zero(s);
@@ -841,9 +845,14 @@ class DenseSolver final : public SolverBase {
     up(g_, g, n_);
     // the one-pass kernel evaluates prox_f inline: only for the cheap base functions
     bool all_cheap = true, all_logistic = true;
-    for (int i = 0; i < m_; ++i) {
-      all_cheap = all_cheap && is_cheap_prox(f.h[i]);
-      all_logistic = all_logistic && f.h[i] == kLogistic;
+    if (tmode_) {   // transposed storage: it is prox_g that runs inside the pass
+      all_logistic = false;
+      for (int j = 0; j < n_; ++j) all_cheap = all_cheap && is_cheap_prox(g.h[j]);
+    } else {
+      for (int i = 0; i < m_; ++i) {
+        all_cheap = all_cheap && is_cheap_prox(f.h[i]);
+        all_logistic = all_logistic && f.h[i] == kLogistic;
+      }
     }
     fused_now_ = fused_ok_ && (all_cheap || all_logistic);
     fused_logistic_ = fused_now_ && all_logistic && !all_cheap;
@@ -903,7 +912,7 @@ class DenseSolver final : public SolverBase {
 
   // One ADMM iteration (pogs.cpp:253-470).  Returns true when the solve stops.
   bool iteration(unsigned verbose) {
-    if (fused_now_) return iteration_fused(verbose);
+    if (fused_now_) return tmode_ ? iteration_fused_wide(verbose) : iteration_fused(verbose);
     hipStream_t s = ctx_.stream;
     const int nw = cur_ ^ 1;
     const bool multi = multi_;
@@ -1141,6 +1150,108 @@ class DenseSolver final : public SolverBase {
     return false;
   }
 
+  // The one-pass iteration for m <= n on the transposed storage: the mirror image of
+  // iteration_fused with x and y (g and f) trading places.  The pass over T = A^T that forms
+  // x_{k+1} = xhat_k - A^T t_k (dot 0, t_k from the m x m solve) also evaluates the exact dual
+  // residual of iteration k (dot 1 with u_k = y12 + c yt - y), finishes the x half of k, runs the
+  // x half of k+1 per stored row with the predicted rho, and accumulates A xhat_{k+1}
+  // (next right-hand side) and A x12_{k+1} (next exact primal residual).
+  bool iteration_fused_wide(unsigned verbose) {
+    hipStream_t s = ctx_.stream;
+    const int nw = cur_ ^ 1;
+    const int bx = vec_blocks(n_), by = vec_blocks(m_);
+    // (A) prox / over-relaxation: y half always, x half unless already speculated
+    AdmmPreArgs<T> pa;
+    pa.n_x = spec_valid_ ? 0 : n_; pa.n_y = m_;
+    pa.g = gview(); pa.f = fview();
+    pa.x_cur = x_[cur_].p; pa.y_cur = y_[cur_].p;
+    pa.xt = xt_.p; pa.yt = yt_.p;
+    pa.zt_scale = zt_scale_;
+    pa.x12 = x12_.p; pa.y12 = y12_.p;
+    pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
+    pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
+    pa.partials = ctx_.spart.p;
+    pa.blocks_x = spec_valid_ ? 0 : bx;
+    launch_admm_pre<T>(pa, s);
+    if (spec_valid_) {
+      SumJob j{ctx_.spart.p, by, 3, ctx_.S.p + kGapY};
+      launch_sum_jobs(&j, 1, s);
+      POGS_HIP_CHECK(hipMemcpyAsync(ctx_.S.p + kGapX, ctx_.S.p + kSpecGapX, 3 * sizeof(double),
+                                    hipMemcpyDeviceToDevice, s));
+    } else {
+      SumJob j[2] = {{ctx_.spart.p, bx, 3, ctx_.S.p + kGapX},
+                     {ctx_.spart.p + static_cast<size_t>(bx) * 3, by, 3, ctx_.S.p + kGapY}};
+      launch_sum_jobs(j, 2, s);
+    }
+    // u_k = y12 + c yt - y: the second dot vector of the pass (exact dual residual, pogs.cpp:366-369)
+    launch_exact_u<T>(m_, y12_.p, yt_.p, y_[cur_].p, zt_scale_, uvec_.p, s);
+    int nparts;
+    if (spec_valid_) {
+      nparts = stream2_grid<2>(planA_, srows_);
+    } else {
+      // (B) column sums A xhat_k and A x12_k
+      StreamArgs2<T> a2{A_.p, lda_, srows_, scols_pad_, nullptr, nullptr, colpart_.p, colpart2_.p, ctx_.spart.p};
+      ctx_.stream_timer.begin(s);
+      launch_stream2<T, 0, 2>(planA_, a2, PreAcc2Op<T>{xtemp_.p, x12_.p}, s);
+      ctx_.stream_timer.end(s);
+      nparts = stream2_grid<0>(planA_, srows_);
+      ctx_.stats.matvecs += 1;
+    }
+    // (C) t = (A A^T + I)^{-1} (A xhat - yhat), y = yhat + t; exact primal residual |A x12 - y12|
+    {
+      double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
+      launch_reduce_cols<T, ResidColOp<T>>(colpart_.p, nparts, scols_pad_, ResidColOp<T>{ytemp_.p, rhs_.p, m_}, sp, s);
+      launch_reduce_cols<T, ExactTColOp<T>>(colpart2_.p, nparts, scols_pad_, ExactTColOp<T>{y12_.p, m_}, sp, s);
+      SumJob j{sp, reduce_cols_grid(scols_pad_, Vec16<T>::N), 1, ctx_.S.p + kExactR2};
+      launch_sum_jobs(&j, 1, s);
+    }
+    solve_gram(rhs_.p, static_cast<const T *>(nullptr),
+               ProjTailAddOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p}, ctx_.S.p + kDYprev2);
+    // (D) the pass over T
+    {
+      StreamArgs2<T> a2{A_.p, lda_, srows_, scols_pad_, tmpn_.p, uvec_.p, colpart_.p, colpart2_.p, ctx_.spart.p};
+      ctl_.predict(&rho_pred_, &zs_pred_);
+      ctx_.stream_timer.begin(s);
+      FusedIterOp<T, false, true> op{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, gview(), rho_pred_, ctl_.alpha(), zs_pred_,
+                                     x12s_.p, xtemps_.p, xt_.p, zt_scale_};
+      launch_stream2<T, 2, 2>(planA_, a2, op, s);
+      ctx_.stream_timer.end(s);
+      const int grid = stream2_grid<2>(planA_, srows_);
+      SumJob j[2] = {{ctx_.spart.p, grid, 3, ctx_.S.p + kDXprev2, 6, 0},
+                     {ctx_.spart.p, grid, 3, ctx_.S.p + kSpecGapX, 6, 3}};
+      launch_sum_jobs(j, 2, s);
+      ctx_.stats.matvecs += 1;
+    }
+    // (E) host decisions (pogs.cpp:270-273, 342-394)
+    const double *S = ctx_.fetch_scalars();
+    ctl_.set_pre(S);
+    bool exact = false;
+    if (ctl_.set_approx(S, nrmA_)) {
+      ctl_.set_exact(S);
+      exact = true;
+    }
+    const bool stop = ctl_.check_stop(exact);
+    if (verbose > 1 && ((verbose > 2 && ctl_.k % 10 == 0) || ctl_.k % 100 == 0 || ctl_.converged))
+      std::printf("%5u : %.2e  %.2e  %.2e  %.2e  %.2e  %.2e\n", ctl_.k, (double)ctl_.nrm_r, (double)ctl_.eps_pri,
+                  (double)ctl_.nrm_s, (double)ctl_.eps_dua, (double)ctl_.gap, (double)ctl_.eps_gap);
+    if (stop) return true;
+    std::swap(xt_, xtemp_);            // xt = xtilde_{k+1}
+    std::swap(yt_, ytemp_);
+    cur_ = nw;
+    zt_scale_ = ctl_.adapt();
+    if (ctl_.rho == rho_pred_ && zt_scale_ == zs_pred_) {
+      std::swap(xtemp_, xtemps_);      // xtemp = speculative xhat_{k+1}
+      std::swap(x12_, x12s_);          // x12 = speculative x12_{k+1}
+      spec_valid_ = true;
+      ctx_.stats.reserved[0] += 1;
+    } else {
+      spec_valid_ = false;
+      ctx_.stats.reserved[1] += 1;
+    }
+    ++ctl_.k;
+    return false;
+  }
+
   // optval, status, un-scaling, copy out (pogs.cpp:473-482, 510-518, 567-570).
   int epilogue(void *x, void *y, void *l, void *mu, double *optval) {
     hipStream_t s = ctx_.stream;
@@ -1180,6 +1291,7 @@ class DenseSolver final : public SolverBase {
   bool tmode_ = false;          // A^T is what is stored (m <= n, direct projector)
   int m_pad_ = 0, srows_ = 0, scols_pad_ = 0;   // stored rows / padded stored row length
   DevBuf<T> uvec_;              // tmode_: y12 + c yt - yprev for the exact-residual pass
+  DevBuf<T> x12s_, xtemps_;     // tmode_, one-pass iteration: speculative x12_{k+1}, xhat_{k+1}
   DevBuf<T> cg_p_, cg_s_, cg_q_, cg_r_;
   DevBuf<double> cg_;
   size_t lda_ = 0;

@@ -310,6 +310,36 @@ struct PreAccOp {
   }
 };
 
+// Column-sum-only pass of the transposed storage (m <= n) when the previous pass could not
+// speculate: u0 = xhat_k (A xhat, projector_direct_dense.cpp:130), u1 = x12_k (exact primal residual).
+template <typename T>
+struct PreAcc2Op {
+  static constexpr int NS = 0;
+  struct Pre {};
+  const T *v0, *v1;
+  __device__ __forceinline__ Pre prefetch(int) const { return Pre{}; }
+  template <int N, int ND, int NA>
+  __device__ __forceinline__ void row(int, const Pre &, const T (&)[ND], double (&)[N], T (&)[NA]) const {}
+  template <int NA>
+  __device__ __forceinline__ void uonly(int j, T (&u)[NA]) const {
+    u[0] = v0[j];
+    u[1] = v1[j];
+  }
+};
+
+// out_i = total - yin_i (rhs of the m <= n projection: A xhat - yhat), padding forced to zero
+template <typename T>
+struct ResidColOp {
+  static constexpr int NS = 0;
+  const T *yin;
+  T *out;
+  int m;
+  template <int N>
+  __device__ __forceinline__ void col(int i, T total, double (&)[N]) const {
+    out[i] = (i < m) ? total - yin[i] : static_cast<T>(0);
+  }
+};
+
 // The single pass of iteration k (after x_{k+1} is known):
 //   y_{k+1} = dot0; residual sums and dual update as ProjTailOp (pogs.cpp:342-348,397-399);
 //   exact primal residual r_i = dot1 - y12_i with dot1 = (A x12_k)_i (pogs.cpp:353-364);
@@ -318,11 +348,16 @@ struct PreAccOp {
 // Scalars: [ |yprev-y|^2, |y12-y|^2, |A x12 - y12|^2, sum w h, |w|^2, |h|^2 ].
 // LOGISTIC = true: every f_i is kLogistic (solve_logistic); the guarded-Newton prox
 // (prox_lib.h:131-170) is inlined on its own so the register footprint stays small.
-template <typename T, bool LOGISTIC = false>
+//
+// XSIDE = true is the mirror image for m <= n on the transposed storage: the stored rows are
+// the x coordinates, dot0 = (A^T t)_j gives x_{k+1,j} = xhat_j - dot0, dot1 = (A^T u)_j the
+// exact DUAL residual dot1 + x12_j + c xt_j - x_j (pogs.cpp:366-373), the function view is g,
+// and the two column sums are A xhat_{k+1} and A x12_{k+1}.
+template <typename T, bool LOGISTIC = false, bool XSIDE = false>
 struct FusedIterOp {
   static constexpr int NS = 6;
   struct Pre {
-    T ycur, y12, ytemp, a, b, c, d, e;
+    T ycur, y12, ytemp, a, b, c, d, e, zt;
     int h;
   };
   T *ynew;
@@ -332,21 +367,24 @@ struct FusedIterOp {
   T rho, alpha;    // rho: the PREDICTED rho of iteration k+1
   T zs;            // predicted lazy scale of ytilde_{k+1} (rho_k / rho_{k+1})
   T *y12s, *ytemps;  // speculative y12_{k+1}, yhat_{k+1}
+  const T *zt_old = nullptr;   // XSIDE: xtilde_k and its lazy scale, for the exact dual residual
+  T c_old = 0;
   __device__ __forceinline__ Pre prefetch(int i) const {
     Pre p;
     p.ycur = ycur[i]; p.y12 = y12[i]; p.ytemp = ytemp[i];
+    p.zt = XSIDE ? zt_old[i] : static_cast<T>(0);
     p.h = f.h[i]; p.a = f.a[i]; p.b = f.b[i]; p.c = f.c[i]; p.d = f.d[i]; p.e = f.e[i];
     return p;
   }
   template <int N, int ND, int NA>
   __device__ __forceinline__ void row(int i, const Pre &p, const T (&dot)[ND], double (&s)[N], T (&u)[NA]) const {
-    const T yn = dot[0];
+    const T yn = XSIDE ? p.ytemp - dot[0] : dot[0];
     const T h0 = p.y12;
     ynew[i] = yn;
     const T a = p.ycur - yn, b = h0 - yn;
     s[0] += static_cast<double>(a) * a;
     s[1] += static_cast<double>(b) * b;
-    const T r = dot[1] - h0;
+    const T r = XSIDE ? dot[1] + h0 + c_old * p.zt - p.ycur : dot[1] - h0;
     s[2] += static_cast<double>(r) * r;
     const T ztn = p.ytemp - yn;
     ytemp[i] = ztn;
@@ -369,7 +407,7 @@ struct FusedIterOp {
     s[4] += static_cast<double>(w) * w;
     s[5] += static_cast<double>(h) * h;
     u[0] = yh;
-    u[1] = h + zts - yn;
+    u[1] = XSIDE ? h : h + zts - yn;
   }
   template <int NA>
   __device__ __forceinline__ void uonly(int, T (&)[NA]) const {}
