@@ -175,8 +175,10 @@ def _check_solution(A, f, g, got, want, dtype, tight):
     xtol = 1e-6 if tight else 1e-4
     assert relerr(got["x"], want["x"]) < xtol
     assert relerr(got["y"], want["y"]) < xtol
-    assert relerr(got["l"], want["l"]) < 10 * xtol
-    assert got["optval"] == pytest.approx(want["optval"], rel=1e-4 if not tight else 1e-7)
+    # (the dual can be ~0 when the fit is exact, e.g. wide least squares: measure it on the scale of y)
+    l_scale = max(np.linalg.norm(want["l"]), 1e-2 * np.linalg.norm(want["y"]))
+    assert np.linalg.norm(got["l"].astype(np.float64) - want["l"]) / l_scale < 10 * xtol
+    assert got["optval"] == pytest.approx(want["optval"], rel=1e-4 if not tight else 1e-7, abs=1e-9 if tight else 1e-6)
     # optval is sum f(y) + sum g(x) at the returned prox point (pogs.cpp:473), where
     # y only approximately equals A x; check it independently in float64 numpy.
     obj = _fsum(f, got["y"].astype(np.float64)) + _fsum(g, got["x"].astype(np.float64))
@@ -214,6 +216,24 @@ def test_solve_families_200x100(problem, dtype):
     f, g = PROBLEMS[problem](b, n)
     got = pogs._solve_graph_form(A, f, g, dtype=dtype)
     want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype)
+    _check_solution(A, f, g, got, want, dtype, tight=(dtype == np.float64))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("problem", ["lasso", "ridge", "elastic_net", "logistic", "huber", "svm", "nonneg_ls"])
+def test_solve_families_wide_100x240(problem, dtype):
+    """The same encodings on a wide matrix (m <= n: transposed storage, A A^T projector, and the
+    mirrored one-pass iteration where prox_g is one of the cheap functions)."""
+    pogs = _pogs()
+    rng = np.random.default_rng(11)
+    m, n = 100, 240
+    A = rng.standard_normal((m, n))
+    b = A @ (rng.standard_normal(n) * (rng.random(n) < 0.1)) + 0.1 * rng.standard_normal(m)
+    f, g = PROBLEMS[problem](b, n)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype)
+    if want["status"] != 0:
+        pytest.skip("the reference algorithm itself does not converge on this instance within max_iter")
+    got = pogs._solve_graph_form(A, f, g, dtype=dtype)
     _check_solution(A, f, g, got, want, dtype, tight=(dtype == np.float64))
 
 
