@@ -61,7 +61,7 @@ struct StreamArgs {
 };
 
 struct StreamPlan {
-  int tpb = 0;   // threads per workgroup: 64, 256 or 1024
+  int tpb = 0;   // threads per workgroup: 64, 256, 512 or 1024
   int nv = 0;    // 16-byte vectors per thread per row
   int grid_max = 0;
   bool ok = false;
@@ -73,13 +73,19 @@ inline StreamPlan make_stream_plan(int n_pad, int num_cu) {
   constexpr int VEC = Vec16<T>::N;
   const int vpr = n_pad / VEC;
   StreamPlan p;
+  // <= 10 vectors per thread wherever possible: that is what the one-pass kernel's register
+  // budget allows (stream2_supported), so 512-thread workgroups (one per CU, 256 VGPRs) take
+  // rows of 2561..5120 vectors (fp32 n <= 20480, fp64 n <= 10240) before the 1024-thread shapes
   static const int nv64[] = {1, 2, 4};
-  static const int nv256[] = {2, 3, 4, 5, 6, 8, 10, 12, 16};
-  static const int nv1024[] = {5, 6, 8};
+  static const int nv256[] = {2, 3, 4, 5, 6, 8, 10};
+  static const int nv512[] = {6, 8, 10};
+  static const int nv1024[] = {6, 8};
   for (int nv : nv64)
     if (vpr <= 64 * nv) { p.tpb = 64; p.nv = nv; p.grid_max = num_cu * 8; p.ok = true; return p; }
   for (int nv : nv256)
     if (vpr <= 256 * nv) { p.tpb = 256; p.nv = nv; p.grid_max = num_cu * 2; p.ok = true; return p; }
+  for (int nv : nv512)
+    if (vpr <= 512 * nv) { p.tpb = 512; p.nv = nv; p.grid_max = num_cu; p.ok = true; return p; }
   for (int nv : nv1024)
     if (vpr <= 1024 * nv) { p.tpb = 1024; p.nv = nv; p.grid_max = num_cu; p.ok = true; return p; }
   return p;
@@ -268,9 +274,9 @@ void launch_stream(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hi
   POGS_STREAM_CASE(256, 6)
   POGS_STREAM_CASE(256, 8)
   POGS_STREAM_CASE(256, 10)
-  POGS_STREAM_CASE(256, 12)
-  POGS_STREAM_CASE(256, 16)
-  POGS_STREAM_CASE(1024, 5)
+  POGS_STREAM_CASE(512, 6)
+  POGS_STREAM_CASE(512, 8)
+  POGS_STREAM_CASE(512, 10)
   POGS_STREAM_CASE(1024, 6)
   POGS_STREAM_CASE(1024, 8)
 #undef POGS_STREAM_CASE
@@ -481,6 +487,9 @@ void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, 
   POGS_STREAM2_CASE(256, 6)
   POGS_STREAM2_CASE(256, 8)
   POGS_STREAM2_CASE(256, 10)
+  POGS_STREAM2_CASE(512, 6)
+  POGS_STREAM2_CASE(512, 8)
+  POGS_STREAM2_CASE(512, 10)
 #undef POGS_STREAM2_CASE
   throw Error("no stream2 kernel instance for plan");
 }

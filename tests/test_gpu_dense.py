@@ -451,25 +451,63 @@ def test_edge_shapes_fp64(shape):
 
 
 def test_wide_register_plan_fp32():
-    """n = 16500 > 16384: the 1024-thread plan (no one-pass kernel), m > n."""
+    """n = 20600 > 20480: the 1024-thread plan (no one-pass kernel), m > n."""
     pogs = _pogs()
     from pogs_amd import synth
 
-    A, b, _ = synth.dense_lasso(17000, 16500, seed=31, dtype=np.float32)
+    m, n = 20700, 20600
+    A, b, _ = synth.dense_lasso(m, n, seed=31, dtype=np.float32)
     rng = np.random.default_rng(2)
-    x0, y0 = rng.standard_normal(16500), rng.standard_normal(17000)
+    x0, y0 = rng.standard_normal(n), rng.standard_normal(m)
     with pogs.Solver(A, dtype=np.float32) as s:
         x, y = s.project(x0, y0)
-        xx = rng.standard_normal(16500)
-        yy = s.mul("n", 1.0, xx, 0.0, np.zeros(17000))
-        xt = s.mul("t", 1.0, y0, 0.0, np.zeros(16500))
+        xx = rng.standard_normal(n)
+        yy = s.mul("n", 1.0, xx, 0.0, np.zeros(m))
+        xt = s.mul("t", 1.0, y0, 0.0, np.zeros(n))
         A_eq, _, _, _ = s.equilibrated()
     A64 = A_eq.astype(np.float64)
     assert relerr(yy, A64 @ xx) < 2e-5
     assert relerr(xt, A64.T @ y0) < 2e-5
-    assert np.linalg.norm(A64 @ x.astype(np.float64) - y) / np.sqrt(17000) < 3e-4
+    assert np.linalg.norm(A64 @ x.astype(np.float64) - y) / np.sqrt(m) < 3e-4
     kkt = A64.T @ (A64 @ x.astype(np.float64) - y0) + (x - x0)
-    assert np.linalg.norm(kkt) / np.sqrt(16500) < 3e-4
+    assert np.linalg.norm(kkt) / np.sqrt(n) < 3e-4
+
+
+@pytest.mark.parametrize("dtype,shape", [(np.float64, (5400, 5200)), (np.float64, (5200, 5600)), (np.float32, (10700, 10400))])
+def test_512_thread_plan_one_pass_iteration(dtype, shape, monkeypatch):
+    """Rows of 2561..5120 16-byte vectors (fp64 n up to 10240, fp32 up to 20480) run on 512-thread
+    workgroups and still take the one-pass iteration: tall fp64, wide fp64 (transposed storage),
+    tall fp32.  The oracle needs a minute at these sizes, so the one-pass solve is held against
+    the two-pass path of the same engine (POGS_AMD_FUSED=0, itself pinned to the oracle at small
+    sizes) and the operator / projection against numpy."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    m, n = shape
+    A, b, _ = synth.dense_lasso(m, n, seed=37, dtype=dtype)
+    lam = 0.1 if m > n else 0.3 * np.max(np.abs(A.T.astype(np.float64) @ b))
+    f, g = pogs.graph.lasso_functions(b, lam, n)
+    rng = np.random.default_rng(4)
+    with pogs.Solver(A, dtype=dtype) as s:
+        got = s.solve(f, g)
+        st = s.stats()
+        A_eq, _, _, _ = s.equilibrated()
+        A64 = A_eq.astype(np.float64)
+        x0, y0 = rng.standard_normal(n), rng.standard_normal(m)
+        assert relerr(s.mul("n", 1.0, x0, 0.0, y0), A64 @ x0) < _tol(dtype, 1e-12, 2e-5)
+        assert relerr(s.mul("t", 1.0, y0, 0.0, x0), A64.T @ y0) < _tol(dtype, 1e-12, 2e-5)
+        px, py = s.project(x0, y0)
+        assert np.linalg.norm(A64.T @ (py - y0) + (px - x0)) / np.sqrt(n) < _tol(dtype, 1e-9, 3e-4)
+    monkeypatch.setenv("POGS_AMD_FUSED", "0")
+    with pogs.Solver(A, dtype=dtype) as s:
+        ref = s.solve(f, g)
+        st_ref = s.stats()
+    assert got["status"] == ref["status"] == 0
+    assert st["spec_hits"] > 0.8 * got["iterations"] and st_ref["spec_hits"] == 0   # one-pass vs two-pass
+    assert st["matvecs"] < 0.7 * st_ref["matvecs"]
+    assert abs(int(got["iterations"]) - int(ref["iterations"])) <= (1 if dtype == np.float64 else max(3, ref["iterations"] // 10))
+    assert relerr(got["x"], ref["x"]) < _tol(dtype, 1e-7, 5e-4)
+    assert got["optval"] == pytest.approx(ref["optval"], rel=_tol(dtype, 1e-8, 2e-4))
 
 
 @pytest.mark.gpu
