@@ -341,6 +341,7 @@ class DenseSolver final : public SolverBase {
     xout_.alloc(np); yout_.alloc(m_); lout_.alloc(m_); muout_.alloc(np);
     f_.alloc(m_); g_.alloc(n_); fs_.alloc(m_); gs_.alloc(n_);
     colpart_.alloc(static_cast<size_t>(planA_.grid_max) * scols_pad_);
+    ensure_xl(planA_, srows_, scols_pad_);
     if (use_cgls_) {
       cg_p_.alloc(np); cg_s_.alloc(np); cg_q_.alloc(m_); cg_r_.alloc(m_); cg_.alloc(kCgNumSlots);
       cg_p_.zero(s); cg_s_.zero(s); cg_.zero(s);
@@ -367,7 +368,16 @@ class DenseSolver final : public SolverBase {
     a.A = A_.p; a.lda = lda_; a.m = srows_; a.n_pad = scols_pad_;
     a.xin = nullptr; a.xin_add = nullptr; a.xin_nrm2 = nullptr;
     a.col_partials = colpart_.p; a.scalar_partials = ctx_.spart.p;
+    a.xl_scratch = xl_buf_.p;
     return a;
+  }
+  // scratch of the windowed passes (rows wider than one register tile), grown on demand
+  void ensure_xl(const StreamPlan &p, int rows, int n_pad) {
+    const size_t need = stream_xl_scratch<T>(p, rows, n_pad);
+    if (need > xl_buf_.n) {
+      ctx_.sync();
+      xl_buf_.alloc(need);
+    }
   }
 
   // ---- products on the transposed storage (tmode_): same contracts as a row-dot pass with a row
@@ -590,6 +600,7 @@ class DenseSolver final : public SolverBase {
       a.A = G; a.lda = ld; a.m = n_; a.n_pad = n_pad_;
       a.xin = xa; a.xin_add = nullptr; a.xin_nrm2 = nrm;
       a.col_partials = colpart_.p; a.scalar_partials = ctx_.spart.p;
+      a.xl_scratch = xl_buf_.p;
       launch_stream<T, true, true, false, kLower>(planW_, a, SymRowOp<T>{G, ld, xa, nrm, tvec_.p}, s);
       launch_reduce_cols<T, SymColOp<T>>(colpart_.p, grid, n_pad_, SymColOp<T>{tvec_.p, xa, nrm, xb, n_}, sp, s);
       SumJob j{sp, reduce_cols_grid(n_pad_, Vec16<T>::N), 2, ctx_.S.p + kPowX2};   // -> kPowX2, kPowXGx
@@ -640,6 +651,7 @@ class DenseSolver final : public SolverBase {
       a.A = G; a.lda = ld; a.m = k_; a.n_pad = k_pad_;
       a.xin = ya; a.xin_add = nullptr; a.xin_nrm2 = nrm;
       a.col_partials = colpart_.p; a.scalar_partials = ctx_.spart.p;
+      a.xl_scratch = xl_buf_.p;
       launch_stream<T, true, true, false, kLower>(planW_, a, SymRowOp<T>{G, ld, ya, nrm, tvec_.p}, s);
       launch_reduce_cols<T, SymColOp<T>>(colpart_.p, grid, k_pad_, SymColOp<T>{tvec_.p, ya, nrm, yb, k_}, sp, s);
       double *tmp2 = ctx_.S.p + kPowX2;   // -> kPowX2 = |G y^|^2, kPowXGx = y^^T G y^ = |x'|^2
@@ -670,7 +682,7 @@ class DenseSolver final : public SolverBase {
     hipStream_t s = ctx_.stream;
     const size_t ld = k_pad_;
     planW_ = make_stream_plan<T>(k_pad_, ctx_.num_cu);
-    POGS_CHECK(planW_.ok, "min(m, n) too large for the register-tiled streaming kernel");
+    ensure_xl(planW_, k_, k_pad_);
     // One allocation, four k x k slabs: [G -> L | scratch | W = L^-1 | U = W^T].
     const size_t slab = static_cast<size_t>(k_) * ld;
     fac_.alloc(slab * 4);
@@ -755,6 +767,7 @@ class DenseSolver final : public SolverBase {
     a.A = Wp_; a.lda = k_pad_; a.m = k_; a.n_pad = k_pad_;
     a.xin = rhs; a.xin_add = add; a.xin_nrm2 = nullptr;
     a.col_partials = nullptr; a.scalar_partials = ctx_.spart.p;
+    a.xl_scratch = xl_buf_.p;
     launch_stream<T, true, false, false, kLower>(planW_, a, GemvNOp<T>{1, 0, tvec_.p}, s);
     a.A = Up_;
     a.xin = tvec_.p; a.xin_add = nullptr;
@@ -1290,6 +1303,7 @@ class DenseSolver final : public SolverBase {
   bool tall_ = true, multi_ = false, use_cgls_ = false;
   bool tmode_ = false;          // A^T is what is stored (m <= n, direct projector)
   int m_pad_ = 0, srows_ = 0, scols_pad_ = 0;   // stored rows / padded stored row length
+  DevBuf<T> xl_buf_;            // windowed passes: partial row dots per window + the coefficient vector
   DevBuf<T> uvec_;              // tmode_: y12 + c yt - yprev for the exact-residual pass
   DevBuf<T> x12s_, xtemps_;     // tmode_, one-pass iteration: speculative x12_{k+1}, xhat_{k+1}
   DevBuf<T> cg_p_, cg_s_, cg_q_, cg_r_;

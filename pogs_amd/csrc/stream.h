@@ -19,6 +19,7 @@
 // reduce_cols (fixed order, no atomics => bit-reproducible).
 #pragma once
 #include <atomic>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -58,6 +59,8 @@ struct StreamArgs {
   const double *xin_nrm2;  // DOT: optional device scalar; scale = 1/sqrt(*xin_nrm2)
   T *col_partials;         // ACC: [gridDim.x][n_pad]
   double *scalar_partials; // Op::NS > 0: [gridDim.x][Op::NS]
+  int col0 = 0;            // first column of the window this launch covers (chunked wide rows)
+  T *xl_scratch = nullptr; // chunked plans: (chunks + 1) * m elements
 };
 
 struct StreamPlan {
@@ -65,7 +68,20 @@ struct StreamPlan {
   int nv = 0;    // 16-byte vectors per thread per row
   int grid_max = 0;
   bool ok = false;
+  // rows wider than one register tile: the pass is run window by window (tpb * nv vectors of
+  // columns each) -- column sums window-wise, row dots as partial dots that a small kernel adds
+  // before the row functor runs; a fused row-dot + column-sum pass becomes those two in turn
+  bool xl = false;
 };
+template <typename T> inline int stream_window_cols(const StreamPlan &p) { return p.tpb * p.nv * Vec16<T>::N; }
+template <typename T> inline int stream_windows(const StreamPlan &p, int n_pad) {
+  const int w = stream_window_cols<T>(p);
+  return p.xl ? (n_pad + w - 1) / w : 1;
+}
+// scratch elements a chunked plan needs for a matrix with `rows` rows
+template <typename T> inline size_t stream_xl_scratch(const StreamPlan &p, int rows, int n_pad) {
+  return p.xl ? static_cast<size_t>(stream_windows<T>(p, n_pad) + 1) * rows : 0;
+}
 
 // Chooses the workgroup shape for rows of n_pad elements.
 template <typename T>
@@ -80,14 +96,27 @@ inline StreamPlan make_stream_plan(int n_pad, int num_cu) {
   static const int nv256[] = {2, 3, 4, 5, 6, 8, 10};
   static const int nv512[] = {6, 8, 10};
   static const int nv1024[] = {6, 8};
+  const char *xl_env = std::getenv("POGS_AMD_XL_LIMIT");
+  const bool forced_xl = xl_env && vpr > std::atoi(xl_env);
   for (int nv : nv64)
-    if (vpr <= 64 * nv) { p.tpb = 64; p.nv = nv; p.grid_max = num_cu * 8; p.ok = true; return p; }
+    if (!forced_xl && vpr <= 64 * nv) { p.tpb = 64; p.nv = nv; p.grid_max = num_cu * 8; p.ok = true; return p; }
   for (int nv : nv256)
-    if (vpr <= 256 * nv) { p.tpb = 256; p.nv = nv; p.grid_max = num_cu * 2; p.ok = true; return p; }
+    if (!forced_xl && vpr <= 256 * nv) { p.tpb = 256; p.nv = nv; p.grid_max = num_cu * 2; p.ok = true; return p; }
   for (int nv : nv512)
-    if (vpr <= 512 * nv) { p.tpb = 512; p.nv = nv; p.grid_max = num_cu; p.ok = true; return p; }
-  for (int nv : nv1024)
-    if (vpr <= 1024 * nv) { p.tpb = 1024; p.nv = nv; p.grid_max = num_cu; p.ok = true; return p; }
+    if (!forced_xl && vpr <= 512 * nv) { p.tpb = 512; p.nv = nv; p.grid_max = num_cu; p.ok = true; return p; }
+  // POGS_AMD_XL_LIMIT=<vectors> (testing aid): rows wider than that take the windowed form below,
+  // with small windows so that small test matrices span several of them
+  int limit = 1024 * 8;
+  bool small_windows = false;
+  if (const char *ev = std::getenv("POGS_AMD_XL_LIMIT")) { limit = std::atoi(ev); small_windows = true; }
+  if (vpr <= limit) {
+    for (int nv : nv1024)
+      if (vpr <= 1024 * nv) { p.tpb = 1024; p.nv = nv; p.grid_max = num_cu; p.ok = true; return p; }
+  }
+  p.xl = true;
+  p.ok = true;
+  if (small_windows) { p.tpb = 64; p.nv = 2; p.grid_max = num_cu * 8; }
+  else { p.tpb = 256; p.nv = 8; p.grid_max = num_cu * 2; }
   return p;
 }
 
@@ -140,7 +169,7 @@ __global__ void __launch_bounds__(TPB) stream_rows_kernel(StreamArgs<T> a, Op op
     if (a.xin_nrm2) sc = static_cast<T>(1.0 / sqrt(*a.xin_nrm2));
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const int col = (v * TPB + t) * VEC;
+      const int col = a.col0 + (v * TPB + t) * VEC;
       V x = dev::vzero<V>();
       if (col < a.n_pad) {
         x = *reinterpret_cast<const V *>(a.xin + col);
@@ -170,7 +199,7 @@ __global__ void __launch_bounds__(TPB) stream_rows_kernel(StreamArgs<T> a, Op op
       const T *rp = a.A + static_cast<size_t>(row) * a.lda;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        const int col = (v * TPB + t) * VEC;
+        const int col = a.col0 + (v * TPB + t) * VEC;
         bool ok = (col < a.n_pad) && (row < a.m);
         if (TRI == kLower) ok = ok && (col <= row);
         if (TRI == kUpper) ok = ok && (col + VEC - 1 >= row);
@@ -224,7 +253,7 @@ __global__ void __launch_bounds__(TPB) stream_rows_kernel(StreamArgs<T> a, Op op
     T *out = a.col_partials + static_cast<size_t>(blockIdx.x) * a.n_pad;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const int col = (v * TPB + t) * VEC;
+      const int col = a.col0 + (v * TPB + t) * VEC;
       if (col < a.n_pad) *reinterpret_cast<V *>(out + col) = acc[v];
     }
   }
@@ -253,10 +282,53 @@ inline int stream_grid(const StreamPlan &p, int m) {
   return nblk < p.grid_max ? (nblk > 0 ? nblk : 1) : p.grid_max;
 }
 
+// ---- windowed form for rows wider than one register tile (StreamPlan::xl) -------------------
+template <typename T>
+struct XlStoreDotOp {   // partial row dots of one window
+  static constexpr int NS = 0;
+  T *out;
+  template <int N>
+  __device__ __forceinline__ T row(int i, T dot, double (&)[N]) const {
+    out[i] = dot;
+    return 0;
+  }
+  __device__ __forceinline__ T u(int) const { return 0; }
+};
+template <typename T>
+struct XlVecUOp {       // column-sum coefficients from a vector
+  static constexpr int NS = 0;
+  const T *uvec;
+  template <int N>
+  __device__ __forceinline__ T row(int, T, double (&)[N]) const { return 0; }
+  __device__ __forceinline__ T u(int i) const { return uvec[i]; }
+};
+// dot_i = sum of the window partials (window order), then the row functor; its return value is
+// kept when a column-sum pass follows.  Scalar partials in the layout of the plain kernel.
+template <typename T, typename Op, bool KEEP_U>
+__global__ void __launch_bounds__(256) xl_apply_rows_kernel(const T *part, int m, int nwin, Op op, T *uvec,
+                                                            double *scalar_partials) {
+  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+  __shared__ double s_red[NS * 4];
+  double sacc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+    T dot = part[i];
+    for (int c = 1; c < nwin; ++c) dot += part[static_cast<size_t>(c) * m + i];
+    const T u = op.row(i, dot, sacc);
+    if (KEEP_U) uvec[i] = u;
+  }
+  if (Op::NS > 0) {
+    dev::block_sum<NS, 256>(sacc, s_red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) scalar_partials[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
+    }
+  }
+}
+
 template <typename T, bool DOT, bool ACC, bool SQ, int TRI, typename Op>
-void launch_stream(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hipStream_t s) {
-  POGS_CHECK(p.ok, "matrix too wide for the row-streaming kernel");
-  const int grid = stream_grid<DOT, ACC>(p, a.m);
+void launch_stream_plain(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hipStream_t s, int grid) {
 #define POGS_STREAM_CASE(TPB_, NV_)                                                             \
   if (p.tpb == TPB_ && p.nv == NV_) {                                                           \
     constexpr int R_ = RowsPerStep<DOT, ACC, TPB_>::value;                                      \
@@ -281,6 +353,38 @@ void launch_stream(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hi
   POGS_STREAM_CASE(1024, 8)
 #undef POGS_STREAM_CASE
   throw Error("no stream kernel instance for plan");
+}
+
+template <typename T, bool DOT, bool ACC, bool SQ, int TRI, typename Op>
+void launch_stream(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hipStream_t s) {
+  POGS_CHECK(p.ok, "matrix too wide for the row-streaming kernel");
+  const int grid = stream_grid<DOT, ACC>(p, a.m);
+  if (!p.xl) {
+    launch_stream_plain<T, DOT, ACC, SQ, TRI, Op>(p, a, op, s, grid);
+    return;
+  }
+  POGS_CHECK(a.xl_scratch != nullptr, "windowed pass without scratch");
+  const int w = stream_window_cols<T>(p);
+  const int nwin = stream_windows<T>(p, a.n_pad);
+  T *part = a.xl_scratch, *uvec = a.xl_scratch + static_cast<size_t>(nwin) * a.m;
+  StreamArgs<T> aw = a;
+  if (DOT) {
+    const int gdot = stream_grid<true, false>(p, a.m);
+    for (int c = 0; c < nwin; ++c) {
+      aw.col0 = c * w;
+      launch_stream_plain<T, true, false, SQ, TRI, XlStoreDotOp<T>>(p, aw, XlStoreDotOp<T>{part + static_cast<size_t>(c) * a.m},
+                                                                    s, gdot);
+    }
+    hipLaunchKernelGGL((xl_apply_rows_kernel<T, Op, ACC>), dim3(grid), dim3(256), 0, s, part, a.m, nwin, op, uvec,
+                       a.scalar_partials);
+  }
+  if (ACC) {
+    for (int c = 0; c < nwin; ++c) {
+      aw.col0 = c * w;
+      if (DOT) launch_stream_plain<T, false, true, SQ, TRI, XlVecUOp<T>>(p, aw, XlVecUOp<T>{uvec}, s, grid);
+      else launch_stream_plain<T, false, true, SQ, TRI, Op>(p, aw, op, s, grid);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -438,7 +542,7 @@ __global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op 
 // Whether the two-dot / two-accumulator kernel fits the register file for this plan
 // (row tile 4*R*NV + 2 x vectors 8*NV + 2 accumulators 8*NV VGPRs, R = 1).
 inline bool stream2_supported(const StreamPlan &p) {
-  if (!p.ok) return false;
+  if (!p.ok || p.xl) return false;
   if (p.tpb == 1024) return false;  // 128-VGPR budget: would spill
   return p.nv <= 10;
 }

@@ -710,3 +710,68 @@ def test_degenerate_inputs_behave_like_the_reference_algorithm():
         assert np.array_equal(np.isfinite(got["x"]), np.isfinite(want["x"])), tag
         if np.all(np.isfinite(want["x"])) and np.linalg.norm(want["x"]) > 0:
             assert relerr(got["x"], want["x"]) < 1e-6, tag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(16700, 16500), (16450, 16900)])
+def test_rows_wider_than_one_register_tile_fp64(shape):
+    """min(m, n) > 16384 doubles: the passes run window by window (StreamPlan::xl).  Operator,
+    projection and a full solve, checked against numpy and the KKT conditions (the whole dense
+    suite also runs through this path on small matrices with POGS_AMD_XL_LIMIT=100)."""
+    pogs = _pogs()
+    m, n = shape
+    rng = np.random.default_rng(41)
+    A = rng.standard_normal((m, n))
+    xt = rng.standard_normal(n) * (rng.random(n) < 0.05)
+    b = A @ xt + 0.1 * rng.standard_normal(m)
+    lam = 0.3 * np.max(np.abs(A.T @ b))
+    f, g = pogs.graph.lasso_functions(b, lam, n)
+    with pogs.Solver(A, dtype=np.float64) as s:
+        A_eq, d, e, _ = s.equilibrated()
+        assert relerr(A_eq, (d[:, None] * A) * e[None, :]) < 1e-12
+        x0, y0 = rng.standard_normal(n), rng.standard_normal(m)
+        assert relerr(s.mul("n", 1.0, x0, 0.0, y0), A_eq @ x0) < 1e-12
+        assert relerr(s.mul("t", 1.0, y0, 0.0, x0), A_eq.T @ y0) < 1e-12
+        px, py = s.project(x0, y0)
+        assert np.linalg.norm(A_eq @ px - py) / np.sqrt(m) < 1e-9
+        assert np.linalg.norm(A_eq.T @ (py - y0) + (px - x0)) / np.sqrt(n) < 1e-9
+        r = s.solve(f, g)
+    assert r["status"] == 0
+    x, y, l = r["x"], r["y"], r["l"]
+    assert np.linalg.norm(A @ x - y) < 20 * (np.sqrt(m) * 1e-4 + 1e-4 * np.linalg.norm(y))
+    assert np.linalg.norm(l - (y - b)) / max(np.linalg.norm(l), 1e-2 * np.linalg.norm(y)) < 5e-2
+    mu = -(A.T @ (y - b))
+    assert np.max(np.abs(mu)) < lam * 1.5
+    assert r["optval"] == pytest.approx(0.5 * np.sum((y - b) ** 2) + lam * np.abs(x).sum(), rel=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape,cgls", [((900, 300), False), ((200, 700), False), ((700, 260), True)])
+def test_windowed_passes_on_small_matrices(dtype, shape, cgls, monkeypatch):
+    """POGS_AMD_XL_LIMIT forces the window-by-window form of every pass (rows "wider than one
+    register tile") on matrices small enough for the oracle: equilibration, norm estimate and the
+    whole solve must follow it exactly as the single-tile kernels do."""
+    pogs = _pogs()
+    from pogs_amd import _lib, synth
+
+    monkeypatch.setenv("POGS_AMD_XL_LIMIT", "40")
+    m, n = shape
+    A, b, _ = synth.dense_lasso(m, n, seed=43, dtype=dtype)
+    lam = 0.1 if m > n else 0.3 * np.max(np.abs(A.T.astype(np.float64) @ b))
+    f, g = pogs.graph.lasso_functions(b, lam, n)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype, want_de=True, use_cgls=cgls)
+    with pogs.Solver(A, dtype=dtype, projector=_lib.PROJ_CGLS if cgls else _lib.PROJ_DEFAULT) as s:
+        _, d, e, nrmA = s.equilibrated(want_matrix=False)
+        got = s.solve(f, g)
+    assert relerr(d, want["d"]) < _tol(dtype, 1e-9, 2e-4)
+    assert relerr(e, want["e"]) < _tol(dtype, 1e-9, 2e-4)
+    assert nrmA == pytest.approx(want["info"]["nrmA"], rel=_tol(dtype, 1e-6, 1e-3))
+    if want["status"] != 0:
+        pytest.skip("the reference algorithm does not converge on this instance (fp32 CGLS)")
+    assert got["status"] == 0
+    slack = 2 if dtype == np.float64 else max(3, want["iterations"] // 10)
+    assert abs(int(got["iterations"]) - int(want["iterations"])) <= slack
+    # (fp32: the window partial sums round differently, the solve may stop an iteration apart)
+    assert relerr(got["x"], want["x"]) < _tol(dtype, 1e-6, 2e-3)
+    assert got["optval"] == pytest.approx(want["optval"], rel=_tol(dtype, 1e-7, 5e-3))
