@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(_HERE, "libpogs_amd.so")
-SOURCES = ["abi.hip", "dense.hip", "sparse.hip", "gemm.hip", "vec_kernels.hip", "dist.hip"]
+SOURCES = ["abi.hip", "dense_f32.hip", "dense_f64.hip", "sparse.hip", "gemm.hip", "vec_kernels.hip", "dist.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

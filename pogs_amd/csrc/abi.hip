@@ -10,8 +10,16 @@
 
 namespace pogs_amd {
 
-SolverBase *make_dense_solver(int dtype, int ord, size_t m, size_t n, const void *A, int mem,
-                              const PogsAmdOptions *opt, const PogsAmdDist *dist);
+SolverBase *make_dense_solver_f32(int ord, size_t m, size_t n, const void *A, int mem, const PogsAmdOptions *opt,
+                                  const PogsAmdDist *dist);
+SolverBase *make_dense_solver_f64(int ord, size_t m, size_t n, const void *A, int mem, const PogsAmdOptions *opt,
+                                  const PogsAmdDist *dist);
+inline SolverBase *make_dense_solver(int dtype, int ord, size_t m, size_t n, const void *A, int mem,
+                                     const PogsAmdOptions *opt, const PogsAmdDist *dist) {
+  if (dtype == POGS_AMD_F32) return make_dense_solver_f32(ord, m, n, A, mem, opt, dist);
+  if (dtype == POGS_AMD_F64) return make_dense_solver_f64(ord, m, n, A, mem, opt, dist);
+  throw Error("unknown dtype");
+}
 SolverBase *make_sparse_solver(int dtype, int ord, size_t m, size_t n, size_t nnz, const void *data,
                                const int *ptr, const int *ind, int mem, const PogsAmdOptions *opt,
                                const PogsAmdDist *dist);

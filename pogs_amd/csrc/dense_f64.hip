@@ -1,0 +1,9 @@
+// DenseSolver<double> (see dense_solver.h).
+#include "dense_solver.h"
+
+namespace pogs_amd {
+SolverBase *make_dense_solver_f64(int ord, size_t m, size_t n, const void *A, int mem, const PogsAmdOptions *opt,
+                                  const PogsAmdDist *dist) {
+  return make_dense_solver_t<double>(ord, m, n, A, mem, opt, dist);
+}
+}  // namespace pogs_amd

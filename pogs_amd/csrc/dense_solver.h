@@ -1,3 +1,4 @@
+#pragma once
 // Dense graph-form ADMM solver with the direct (Gram + Cholesky) projector.
 //
 // Reference call stack being replaced:
@@ -721,6 +722,27 @@ class DenseSolver final : public SolverBase {
         ctx_.sync();   // order is a host temporary
         g.tile_map = tmap.p;
       }
+      // fp32, K-major operand, enough rows: the bf16 matrix cores at fp32 accuracy (three-way
+      // operand split, six products; gemm.h).  1024-row K ranges, four at a time into the four
+      // slabs, each launch adding to what the slabs hold; then the slabs are added in order.
+      const char *gsel = std::getenv("POGS_AMD_GRAM");
+      const bool bf16x6 = std::is_same<T, float>::value && (tall_ || tmode_) && kdim >= 8192 && k_ >= 256 &&
+                          !(gsel && gsel[0] == 'f');
+      if (bf16x6) {
+        constexpr int kRows = 1024;
+        const int nchunks = (kdim + kRows - 1) / kRows;
+        GramBf16Args gb{reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, reinterpret_cast<float *>(G), ld, 4, kRows,
+                        0, slab, 0, g.tile_map};
+        for (int c0 = 0; c0 < nchunks; c0 += 4) {
+          gb.ks0 = c0;
+          gb.nslabs = std::min(4, nchunks - c0);
+          gb.accumulate = c0 > 0 ? 1 : 0;
+          launch_gram_bf16(gb, s);
+        }
+        launch_sum_slabs<T>(G, slab, std::min(4, nchunks), G, ld, k_, s);
+        ksplit = 0;   // skip the fp32 rounds below
+        POGS_HIP_CHECK(hipMemsetAsync(G + slab, 0, 3 * slab * sizeof(T), s));
+      }
       for (int ks = 0; ks < ksplit;) {
         const bool first = ks == 0;
         const int nb = std::min(first ? 4 : 3, ksplit - ks);
@@ -1327,11 +1349,13 @@ class DenseSolver final : public SolverBase {
 
 }  // namespace
 
-SolverBase *make_dense_solver(int dtype, int ord, size_t m, size_t n, const void *A, int mem,
-                              const PogsAmdOptions *opt, const PogsAmdDist *dist) {
-  if (dtype == POGS_AMD_F32) return new DenseSolver<float>(ord, m, n, A, mem, opt, dist);
-  if (dtype == POGS_AMD_F64) return new DenseSolver<double>(ord, m, n, A, mem, opt, dist);
-  throw Error("unknown dtype");
+// One translation unit per arithmetic type (dense_f32.hip, dense_f64.hip): the HIP runtime loads a
+// code object as a whole at its first kernel launch, and the row kernels come in ~700 variants
+// per type (plan x mode x functor), so a float solve should not pay for the double kernels.
+template <typename T>
+SolverBase *make_dense_solver_t(int ord, size_t m, size_t n, const void *A, int mem, const PogsAmdOptions *opt,
+                                const PogsAmdDist *dist) {
+  return new DenseSolver<T>(ord, m, n, A, mem, opt, dist);
 }
 
 }  // namespace pogs_amd

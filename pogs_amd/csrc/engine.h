@@ -306,7 +306,7 @@ struct AdmmControl {
   }
   // What adapt() would do at this iteration if the residuals equalled the previous
   // iteration's (they drift slowly): returns the predicted (rho, zt scale) without
-  // touching the state.  Used to speculate across a rho change (dense.hip).
+  // touching the state.  Used to speculate across a rho change (dense_solver.h).
   void predict(T *rho_out, T *scale_out) const {
     AdmmControl<T> c = *this;   // nrm_r, nrm_s, eps_* still hold the previous iteration's values
     *scale_out = c.adapt();

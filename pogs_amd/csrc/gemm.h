@@ -43,6 +43,22 @@ struct GemmArgs {
   const int *tile_map = nullptr;
 };
 
+// G += / = P^T P (lower 128 x 128 tiles) for a K-major fp32 operand P (K rows of N, leading
+// dimension ld) on the bf16 matrix cores at fp32 accuracy: every operand splits exactly into
+// three bf16 parts (8 + 8 + 8 mantissa bits) and the six products that matter (hh, hm, mh, hl,
+// lh, mm) are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The MFMA accumulate truncates,
+// so a chain drifts in proportion to its length: a unit covers `kchunk` (<= ~1024) rows and
+// adds into its slab tile (beta) -- short chains joined by IEEE adds are more exact than a
+// sequential fp32 sum.  Slab ks of this launch takes rows [(ks0 + ks) kchunk, (ks0 + ks + 1) kchunk).
+struct GramBf16Args {
+  const float *P; size_t ld; int K, N;
+  float *C; size_t ldc;           // slab 0 of this launch
+  int nslabs, kchunk, ks0; size_t slab_stride;
+  int accumulate;                 // 0: C = product, 1: C += product
+  const int *tile_map;            // optional, see gram_tile_order
+};
+void launch_gram_bf16(const GramBf16Args &g, hipStream_t s);
+
 // Lower-triangular tile order in 8 x 8 super-tiles for an n x n Gram product: the ~64
 // workgroups an XCD runs at a time then touch 16 operand panels instead of 65.
 std::vector<int> gram_tile_order(int n);

@@ -422,6 +422,163 @@ void launch_gemm_ab(bool lower, const GemmArgs<T> &g, hipStream_t s) {
 
 }  // namespace
 
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 8 fp32 -> three vectors of 8 packed bf16: exact three-way split by truncation (a = h + m + l)
+__device__ __forceinline__ void split8_bf16(const float (&v)[8], u32x4 &h, u32x4 &m, u32x4 &l) {
+  unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const unsigned u = __float_as_uint(v[q]);
+    hb[q] = u & 0xffff0000u;
+    const float r1 = v[q] - __uint_as_float(hb[q]);
+    mb[q] = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb[q]);
+    lb[q] = __float_as_uint(r2) & 0xffff0000u;
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    h[p] = (hb[2 * p] >> 16) | hb[2 * p + 1];
+    m[p] = (mb[2 * p] >> 16) | mb[2 * p + 1];
+    l[p] = (lb[2 * p] >> 16) | lb[2 * p + 1];
+  }
+}
+
+constexpr int GBK = 16;   // rows per k-tile: one 32x32x16 MFMA step
+
+// 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles of 32 x 32.  Thread t stages column t & 127,
+// k-group t >> 7 (8 consecutive rows): 8 coalesced dword loads per operand panel, split in
+// registers, three 16-byte LDS stores in operand order [part][k / 8][column].
+__global__ void __launch_bounds__(GT) gram_bf16_kernel(GramBf16Args g) {
+  __shared__ __attribute__((aligned(16))) u32x4 sh[2][2][3][2][BM];
+  const int tm = (g.N + BM - 1) / BM;
+  const int ntiles = tm * (tm + 1) / 2;
+  const int nunits = ntiles * g.nslabs;
+  const int per_xcd = (nunits + kNumXcd - 1) / kNumXcd;
+  const int unit = static_cast<int>(blockIdx.x % kNumXcd) * per_xcd + static_cast<int>(blockIdx.x / kNumXcd);
+  if (unit >= nunits || static_cast<int>(blockIdx.x / kNumXcd) >= per_xcd) return;
+  const int ks = unit / ntiles, tile = unit % ntiles;
+  int ti, tj;
+  if (g.tile_map) {
+    const int e = g.tile_map[tile];
+    ti = e >> 16;
+    tj = e & 0xffff;
+  } else {
+    ti = static_cast<int>((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > tile) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    tj = tile - ti * (ti + 1) / 2;
+  }
+  const int i0 = ti * BM, j0 = tj * BM;
+  const int kbeg = (g.ks0 + ks) * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  float *Cout = g.C + static_cast<size_t>(ks) * g.slab_stride;
+  const bool diag = ti == tj;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = t & 127, lk8 = t >> 7;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int r32 = lane & 31, kh = lane >> 5;
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float va[8], vb[8];
+  auto gload = [&](int k0) {
+    const int gi = i0 + li, gj = j0 + li;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = k0 + lk8 * 8 + q;
+      const bool kok = k < kend;
+      va[q] = (kok && gi < g.N) ? g.P[static_cast<size_t>(k) * g.ld + gi] : 0.f;
+      if (!diag) vb[q] = (kok && gj < g.N) ? g.P[static_cast<size_t>(k) * g.ld + gj] : 0.f;
+    }
+  };
+  auto lstore = [&](int st) {
+    u32x4 h, m, l;
+    split8_bf16(va, h, m, l);
+    sh[st][0][0][lk8][li] = h; sh[st][0][1][lk8][li] = m; sh[st][0][2][lk8][li] = l;
+    if (!diag) {
+      split8_bf16(vb, h, m, l);
+      sh[st][1][0][lk8][li] = h; sh[st][1][1][lk8][li] = m; sh[st][1][2][lk8][li] = l;
+    }
+  };
+  const int bop = diag ? 0 : 1;
+  auto compute = [&](int st) {
+    bf16x8 A[2][3], B[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const u32x4 xa = sh[st][0][p][kh][wm + a * 32 + r32];
+        const u32x4 xb = sh[st][bop][p][kh][wn + a * 32 + r32];
+        A[a][p] = *reinterpret_cast<const bf16x8 *>(&xa);
+        B[a][p] = *reinterpret_cast<const bf16x8 *>(&xb);
+      }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        floatx16 c = acc[a][b];   // smallest products first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], B[b][1], c, 0, 0, 0);   // m m
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][2], c, 0, 0, 0);   // h l
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][2], B[b][0], c, 0, 0, 0);   // l h
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][1], c, 0, 0, 0);   // h m
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], B[b][0], c, 0, 0, 0);   // m h
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][0], c, 0, 0, 0);   // h h
+        acc[a][b] = c;
+      }
+  };
+  const int nk = ((kend - kbeg + GBK - 1) / GBK + 1) & ~1;   // even; rows past kend load as zero
+  if (kend > kbeg) {
+    gload(kbeg);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      gload(kbeg + (kt + 1) * GBK);
+      compute(0);
+      lstore(1);
+      __syncthreads();
+      gload(kbeg + (kt + 2) * GBK);
+      compute(1);
+      lstore(0);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm + a * 32 + (r / 4) * 8 + kh * 4 + (r % 4);
+        const int col = j0 + wn + b * 32 + r32;
+        if (row < g.N && col < g.N) {
+          float *c = Cout + static_cast<size_t>(row) * g.ldc + col;
+          *c = g.accumulate ? *c + acc[a][b][r] : acc[a][b][r];
+        }
+      }
+}
+
+}  // namespace
+
+void launch_gram_bf16(const GramBf16Args &g, hipStream_t s) {
+  const int tm = (g.N + BM - 1) / BM;
+  const int nunits = tm * (tm + 1) / 2 * g.nslabs;
+  if (nunits <= 0) return;
+  const int grid = (nunits + kNumXcd - 1) / kNumXcd * kNumXcd;
+  hipLaunchKernelGGL(gram_bf16_kernel, dim3(grid), dim3(GT), 0, s, g);
+}
+
 std::vector<int> gram_tile_order(int n) {
   constexpr int G = 8;
   const int tm = (n + BM - 1) / BM;

@@ -1221,7 +1221,7 @@ class SparseSolver final : public SolverBase {
     launch_axpby<T>(n_, static_cast<T>(1), x0, static_cast<T>(1), x, s);
   }
 
-  // (x0, lambda0) -> (z, z~)   (pogs.cpp:144-156), see dense.hip
+  // (x0, lambda0) -> (z, z~)   (pogs.cpp:144-156), see dense_solver.h
   void apply_warm_start() {
     if (!warm_pending_) return;
     warm_pending_ = false;

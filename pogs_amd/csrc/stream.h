@@ -355,6 +355,20 @@ void launch_stream_plain(const StreamPlan &p, const StreamArgs<T> &a, const Op &
   throw Error("no stream kernel instance for plan");
 }
 
+// the two window shapes of a windowed plan only (keeps the number of kernel variants down)
+template <typename T, bool DOT, bool ACC, bool SQ, int TRI, typename Op>
+void launch_stream_window(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hipStream_t s, int grid) {
+  if (p.tpb == 256 && p.nv == 8) {
+    hipLaunchKernelGGL((stream_rows_kernel<T, 256, 8, RowsPerStep<DOT, ACC, 256>::value, DOT, ACC, SQ, TRI, Op>),
+                       dim3(grid), dim3(256), 0, s, a, op);
+  } else if (p.tpb == 64 && p.nv == 2) {
+    hipLaunchKernelGGL((stream_rows_kernel<T, 64, 2, RowsPerStep<DOT, ACC, 64>::value, DOT, ACC, SQ, TRI, Op>),
+                       dim3(grid), dim3(64), 0, s, a, op);
+  } else {
+    throw Error("no window kernel instance for plan");
+  }
+}
+
 template <typename T, bool DOT, bool ACC, bool SQ, int TRI, typename Op>
 void launch_stream(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hipStream_t s) {
   POGS_CHECK(p.ok, "matrix too wide for the row-streaming kernel");
@@ -372,8 +386,8 @@ void launch_stream(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hi
     const int gdot = stream_grid<true, false>(p, a.m);
     for (int c = 0; c < nwin; ++c) {
       aw.col0 = c * w;
-      launch_stream_plain<T, true, false, SQ, TRI, XlStoreDotOp<T>>(p, aw, XlStoreDotOp<T>{part + static_cast<size_t>(c) * a.m},
-                                                                    s, gdot);
+      launch_stream_window<T, true, false, SQ, TRI, XlStoreDotOp<T>>(p, aw, XlStoreDotOp<T>{part + static_cast<size_t>(c) * a.m},
+                                                                     s, gdot);
     }
     hipLaunchKernelGGL((xl_apply_rows_kernel<T, Op, ACC>), dim3(grid), dim3(256), 0, s, part, a.m, nwin, op, uvec,
                        a.scalar_partials);
@@ -381,8 +395,8 @@ void launch_stream(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hi
   if (ACC) {
     for (int c = 0; c < nwin; ++c) {
       aw.col0 = c * w;
-      if (DOT) launch_stream_plain<T, false, true, SQ, TRI, XlVecUOp<T>>(p, aw, XlVecUOp<T>{uvec}, s, grid);
-      else launch_stream_plain<T, false, true, SQ, TRI, Op>(p, aw, op, s, grid);
+      if (DOT) launch_stream_window<T, false, true, SQ, TRI, XlVecUOp<T>>(p, aw, XlVecUOp<T>{uvec}, s, grid);
+      else launch_stream_window<T, false, true, SQ, TRI, Op>(p, aw, op, s, grid);
     }
   }
 }

@@ -5,7 +5,7 @@ replicated, sum all-reduce of A_k^T y_k partials, of the Gram matrix and of the
 row-sums) is run by two processes through the oracle's sharded entry with
 torch.distributed all_reduce as the collective, and must reproduce the
 single-process solve.  The HIP engine uses the same decomposition with RCCL in
-place of gloo (pogs_amd/csrc/dense.hip: finish_cols / allreduce call sites).
+place of gloo (pogs_amd/csrc/dense_solver.h: finish_cols / allreduce call sites).
 Also covers the launcher-side plumbing bench.py uses: per-rank shard generation
 and broadcasting an opaque 128-byte id from rank 0.
 """
