@@ -775,3 +775,36 @@ def test_windowed_passes_on_small_matrices(dtype, shape, cgls, monkeypatch):
     # (fp32: the window partial sums round differently, the solve may stop an iteration apart)
     assert relerr(got["x"], want["x"]) < _tol(dtype, 1e-6, 2e-3)
     assert got["optval"] == pytest.approx(want["optval"], rel=_tol(dtype, 1e-7, 5e-3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(20000, 1500), (1300, 21000)])
+def test_bf16_split_gram_is_as_exact_as_the_fp32_product(shape, monkeypatch):
+    """fp32 Gram through the three-way bf16 split (six products on the bf16 matrix cores) against
+    the native fp32 MFMA product (POGS_AMD_GRAM=fp32): the projection built on it satisfies its
+    KKT conditions at least as well, and the solves agree."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    m, n = shape
+    A, b, _ = synth.dense_lasso(m, n, seed=47, dtype=np.float32)
+    lam = 0.1 if m > n else 0.3 * np.max(np.abs(A.T.astype(np.float64) @ b))
+    f, g = pogs.graph.lasso_functions(b, lam, n)
+    rng = np.random.default_rng(6)
+    x0, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    out = {}
+    for mode in ("bf16", "fp32"):
+        if mode == "fp32":
+            monkeypatch.setenv("POGS_AMD_GRAM", "fp32")
+        with pogs.Solver(A, dtype=np.float32) as s:
+            A_eq, _, _, _ = s.equilibrated()
+            px, py = s.project(x0, y0)
+            A64 = A_eq.astype(np.float64)
+            kkt = np.linalg.norm(A64.T @ (py - y0) + (px - x0)) / np.sqrt(n)
+            out[mode] = (kkt, s.solve(f, g))
+    assert out["bf16"][0] < 2e-5
+    assert out["bf16"][0] < 2.0 * out["fp32"][0] + 1e-7
+    rb, rf = out["bf16"][1], out["fp32"][1]
+    assert rb["status"] == rf["status"] == 0
+    assert abs(int(rb["iterations"]) - int(rf["iterations"])) <= max(3, rf["iterations"] // 10)
+    assert relerr(rb["x"], rf["x"]) < 5e-4
