@@ -38,12 +38,14 @@ namespace {
 // (MultDiag + NormEst(kNormFro), matrix_dense.cpp:181,184,215-237).
 template <typename T>
 __global__ void __launch_bounds__(256) scale_de_kernel(T *A, size_t lda, int m, int n_pad, const T *d,
-                                                       const T *e, double *partials) {
+                                                       const T *e, double *partials, double *max_partials) {
   using V = typename Vec16<T>::type;
   constexpr int VEC = Vec16<T>::N;
   __shared__ double s_red[4];
+  __shared__ double s_max[4];
   const int vpr = n_pad / VEC;
   double acc[1] = {0.0};
+  T amax = 0;
   for (int row = blockIdx.x; row < m; row += gridDim.x) {
     const T di = d[row];
     T *rp = A + static_cast<size_t>(row) * lda;
@@ -57,12 +59,20 @@ __global__ void __launch_bounds__(256) scale_de_kernel(T *A, size_t lda, int m, 
         const T val = ap[c] * (di * ep[c]);
         ap[c] = val;
         acc[0] += static_cast<double>(val) * val;
+        amax = fmax(amax, fabs(val));
       }
       *reinterpret_cast<V *>(rp + v * VEC) = a;
     }
   }
   dev::block_sum<1, 256>(acc, s_red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+  double mx = static_cast<double>(amax);
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = acc[0];
+    max_partials[blockIdx.x] = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+  }
 }
 
 template <typename T>
@@ -506,12 +516,14 @@ class DenseSolver final : public SolverBase {
     const int sgrid = std::min(srows_, ctx_.num_cu * 8);
     // rows of the stored matrix are scaled by the first vector, its columns by the second
     hipLaunchKernelGGL(scale_de_kernel<T>, dim3(sgrid), dim3(256), 0, s, A_.p, lda_, srows_, scols_pad_,
-                       tmode_ ? e_.p : d_.p, tmode_ ? d_.p : e_.p, ctx_.spart.p);
+                       tmode_ ? e_.p : d_.p, tmode_ ? d_.p : e_.p, ctx_.spart.p, ctx_.spart.p + sgrid);
     sum_row_scalars(sgrid, 1, ctx_.S.p + kFro2);
+    launch_max_partials(ctx_.spart.p + sgrid, sgrid, ctx_.S.p + kAmax, s);
     if (multi_) ctx_.dist.allreduce(ctx_.S.p + kFro2, 1, s);
     const double *S = ctx_.fetch_scalars();
     const T normA = static_cast<T>(std::sqrt(S[kFro2])) /
                     std::sqrt(static_cast<T>(std::min<double>(mg, nn)));   // :215-218
+    amax_ = S[kAmax] / static_cast<double>(normA);   // largest |entry| of the equilibrated matrix (this shard)
     const size_t nvec = static_cast<size_t>(srows_) * lda_ / Vec16<T>::N;
     hipLaunchKernelGGL(scale_all_kernel<T>, dim3(ctx_.num_cu * 8), dim3(256), 0, s, A_.p, nvec,
                        static_cast<T>(1) / normA);                         // :186
@@ -722,22 +734,30 @@ class DenseSolver final : public SolverBase {
         ctx_.sync();   // order is a host temporary
         g.tile_map = tmap.p;
       }
-      // fp32, K-major operand, enough rows: the bf16 matrix cores at fp32 accuracy (three-way
-      // operand split, six products; gemm.h).  1024-row K ranges, four at a time into the four
-      // slabs, each launch adding to what the slabs hold; then the slabs are added in order.
+      // fp32, K-major operand, enough rows: the fp16 matrix cores at (better than) fp32 accuracy --
+      // operands scaled by a power of two into fp16 range and split in two fp16 parts, three
+      // products (gemm.h).  1024-row K ranges, four at a time into the four slabs, each launch
+      // adding to what the slabs hold; then the slabs are added in order.
       const char *gsel = std::getenv("POGS_AMD_GRAM");
-      const bool bf16x6 = std::is_same<T, float>::value && (tall_ || tmode_) && kdim >= 8192 && k_ >= 256 &&
-                          !(gsel && gsel[0] == 'f');
-      if (bf16x6) {
+      bool split16 = std::is_same<T, float>::value && (tall_ || tmode_) && kdim >= 8192 && k_ >= 256 &&
+                     !(gsel && gsel[0] == 'f') && std::isfinite(amax_) && amax_ > 0;
+      float scale16 = 1.f;
+      if (split16) {
+        int ex = 0;
+        std::frexp(amax_, &ex);                       // amax_ = f * 2^ex, f in [0.5, 1)
+        scale16 = std::ldexp(1.f, 14 - ex);           // largest scaled entry in [8192, 16384)
+        split16 = std::isfinite(scale16) && scale16 > 0;
+      }
+      if (split16) {
         constexpr int kRows = 1024;
         const int nchunks = (kdim + kRows - 1) / kRows;
-        GramBf16Args gb{reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, reinterpret_cast<float *>(G), ld, 4, kRows,
-                        0, slab, 0, g.tile_map};
+        GramF16Args gb{reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, reinterpret_cast<float *>(G), ld, 4, kRows,
+                       0, slab, 0, g.tile_map, scale16};
         for (int c0 = 0; c0 < nchunks; c0 += 4) {
           gb.ks0 = c0;
           gb.nslabs = std::min(4, nchunks - c0);
           gb.accumulate = c0 > 0 ? 1 : 0;
-          launch_gram_bf16(gb, s);
+          launch_gram_f16(gb, s);
         }
         launch_sum_slabs<T>(G, slab, std::min(4, nchunks), G, ld, k_, s);
         ksplit = 0;   // skip the fp32 rounds below
@@ -1323,6 +1343,7 @@ class DenseSolver final : public SolverBase {
   Ctx ctx_;
   int m_ = 0, n_ = 0, n_pad_ = 0, k_ = 0, k_pad_ = 0;
   bool tall_ = true, multi_ = false, use_cgls_ = false;
+  double amax_ = 0;             // max |entry| of the equilibrated matrix (fp16 scaling of the Gram product)
   bool tmode_ = false;          // A^T is what is stored (m <= n, direct projector)
   int m_pad_ = 0, srows_ = 0, scols_pad_ = 0;   // stored rows / padded stored row length
   DevBuf<T> xl_buf_;            // windowed passes: partial row dots per window + the coefficient vector

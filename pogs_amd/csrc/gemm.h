@@ -44,20 +44,23 @@ struct GemmArgs {
 };
 
 // G += / = P^T P (lower 128 x 128 tiles) for a K-major fp32 operand P (K rows of N, leading
-// dimension ld) on the bf16 matrix cores at fp32 accuracy: every operand splits exactly into
-// three bf16 parts (8 + 8 + 8 mantissa bits) and the six products that matter (hh, hm, mh, hl,
-// lh, mm) are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The MFMA accumulate truncates,
-// so a chain drifts in proportion to its length: a unit covers `kchunk` (<= ~1024) rows and
-// adds into its slab tile (beta) -- short chains joined by IEEE adds are more exact than a
+// dimension ld) on the fp16 matrix cores at fp32 accuracy: gfx950 has no reduced-precision fast
+// path for fp32 inputs, but a scaled operand a s (s a power of two that puts the largest entry
+// near 2^14) splits into two fp16 numbers h + l with 22 significant bits, and the three products
+// hh, hl, lh carry everything above 2^-22 relative -- accumulated in fp32 by
+// v_mfma_f32_32x32x16_f16 and unscaled by 1 / s^2.  The MFMA accumulate truncates, so a chain
+// drifts in proportion to its length: a unit covers `kchunk` (<= ~1024) rows and adds into its
+// slab tile (accumulate) -- short chains joined by IEEE adds come out more exact than a
 // sequential fp32 sum.  Slab ks of this launch takes rows [(ks0 + ks) kchunk, (ks0 + ks + 1) kchunk).
-struct GramBf16Args {
+struct GramF16Args {
   const float *P; size_t ld; int K, N;
   float *C; size_t ldc;           // slab 0 of this launch
   int nslabs, kchunk, ks0; size_t slab_stride;
   int accumulate;                 // 0: C = product, 1: C += product
   const int *tile_map;            // optional, see gram_tile_order
+  float scale;                    // power of two; scale * max|P| must stay below 65504
 };
-void launch_gram_bf16(const GramBf16Args &g, hipStream_t s);
+void launch_gram_f16(const GramF16Args &g, hipStream_t s);
 
 // Lower-triangular tile order in 8 x 8 super-tiles for an n x n Gram product: the ~64
 // workgroups an XCD runs at a time then touch 16 operand panels instead of 65.

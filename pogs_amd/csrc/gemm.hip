@@ -424,27 +424,17 @@ void launch_gemm_ab(bool lower, const GemmArgs<T> &g, hipStream_t s) {
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// 8 fp32 -> three vectors of 8 packed bf16: exact three-way split by truncation (a = h + m + l)
-__device__ __forceinline__ void split8_bf16(const float (&v)[8], u32x4 &h, u32x4 &m, u32x4 &l) {
-  unsigned hb[8], mb[8], lb[8];
+// 8 fp32 -> two vectors of 8 fp16: h = fp16(a s), l = fp16(a s - h)
+__device__ __forceinline__ void split8_f16(const float (&v)[8], float sc, f16x8 &h, f16x8 &l) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const unsigned u = __float_as_uint(v[q]);
-    hb[q] = u & 0xffff0000u;
-    const float r1 = v[q] - __uint_as_float(hb[q]);
-    mb[q] = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(mb[q]);
-    lb[q] = __float_as_uint(r2) & 0xffff0000u;
-  }
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    h[p] = (hb[2 * p] >> 16) | hb[2 * p + 1];
-    m[p] = (mb[2 * p] >> 16) | mb[2 * p + 1];
-    l[p] = (lb[2 * p] >> 16) | lb[2 * p + 1];
+    const float a = v[q] * sc;
+    const _Float16 hh = static_cast<_Float16>(a);
+    h[q] = hh;
+    l[q] = static_cast<_Float16>(a - static_cast<float>(hh));
   }
 }
 
@@ -452,9 +442,11 @@ constexpr int GBK = 16;   // rows per k-tile: one 32x32x16 MFMA step
 
 // 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles of 32 x 32.  Thread t stages column t & 127,
 // k-group t >> 7 (8 consecutive rows): 8 coalesced dword loads per operand panel, split in
-// registers, three 16-byte LDS stores in operand order [part][k / 8][column].
-__global__ void __launch_bounds__(GT) gram_bf16_kernel(GramBf16Args g) {
-  __shared__ __attribute__((aligned(16))) u32x4 sh[2][2][3][2][BM];
+// registers, two 16-byte LDS stores in operand order [part][k / 8][column].  Four workgroups
+// per CU (128 VGPRs, 32 KB of LDS each): the loop is not software-pipelined beyond one
+// register stage, the resident waves hide the rest.
+__global__ void __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) gram_f16_kernel(GramF16Args g) {
+  __shared__ __attribute__((aligned(16))) f16x8 sh[2][2][2][2][BM];
   const int tm = (g.N + BM - 1) / BM;
   const int ntiles = tm * (tm + 1) / 2;
   const int nunits = ntiles * g.nslabs;
@@ -504,37 +496,32 @@ __global__ void __launch_bounds__(GT) gram_bf16_kernel(GramBf16Args g) {
     }
   };
   auto lstore = [&](int st) {
-    u32x4 h, m, l;
-    split8_bf16(va, h, m, l);
-    sh[st][0][0][lk8][li] = h; sh[st][0][1][lk8][li] = m; sh[st][0][2][lk8][li] = l;
+    f16x8 h, l;
+    split8_f16(va, g.scale, h, l);
+    sh[st][0][0][lk8][li] = h; sh[st][0][1][lk8][li] = l;
     if (!diag) {
-      split8_bf16(vb, h, m, l);
-      sh[st][1][0][lk8][li] = h; sh[st][1][1][lk8][li] = m; sh[st][1][2][lk8][li] = l;
+      split8_f16(vb, g.scale, h, l);
+      sh[st][1][0][lk8][li] = h; sh[st][1][1][lk8][li] = l;
     }
   };
   const int bop = diag ? 0 : 1;
   auto compute = [&](int st) {
-    bf16x8 A[2][3], B[2][3];
+    f16x8 A[2][2], B[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        const u32x4 xa = sh[st][0][p][kh][wm + a * 32 + r32];
-        const u32x4 xb = sh[st][bop][p][kh][wn + a * 32 + r32];
-        A[a][p] = *reinterpret_cast<const bf16x8 *>(&xa);
-        B[a][p] = *reinterpret_cast<const bf16x8 *>(&xb);
+      for (int p = 0; p < 2; ++p) {
+        A[a][p] = sh[st][0][p][kh][wm + a * 32 + r32];
+        B[a][p] = sh[st][bop][p][kh][wn + a * 32 + r32];
       }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        floatx16 c = acc[a][b];   // smallest products first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], B[b][1], c, 0, 0, 0);   // m m
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][2], c, 0, 0, 0);   // h l
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][2], B[b][0], c, 0, 0, 0);   // l h
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][1], c, 0, 0, 0);   // h m
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], B[b][0], c, 0, 0, 0);   // m h
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], B[b][0], c, 0, 0, 0);   // h h
+        floatx16 c = acc[a][b];   // small products first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][0], B[b][1], c, 0, 0, 0);   // h l
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][1], B[b][0], c, 0, 0, 0);   // l h
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][0], B[b][0], c, 0, 0, 0);   // h h
         acc[a][b] = c;
       }
   };
@@ -554,6 +541,7 @@ __global__ void __launch_bounds__(GT) gram_bf16_kernel(GramBf16Args g) {
       __syncthreads();
     }
   }
+  const float inv2 = 1.0f / (g.scale * g.scale);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -564,19 +552,20 @@ __global__ void __launch_bounds__(GT) gram_bf16_kernel(GramBf16Args g) {
         const int col = j0 + wn + b * 32 + r32;
         if (row < g.N && col < g.N) {
           float *c = Cout + static_cast<size_t>(row) * g.ldc + col;
-          *c = g.accumulate ? *c + acc[a][b][r] : acc[a][b][r];
+          const float v = acc[a][b][r] * inv2;
+          *c = g.accumulate ? *c + v : v;
         }
       }
 }
 
 }  // namespace
 
-void launch_gram_bf16(const GramBf16Args &g, hipStream_t s) {
+void launch_gram_f16(const GramF16Args &g, hipStream_t s) {
   const int tm = (g.N + BM - 1) / BM;
   const int nunits = tm * (tm + 1) / 2 * g.nslabs;
   if (nunits <= 0) return;
   const int grid = (nunits + kNumXcd - 1) / kNumXcd * kNumXcd;
-  hipLaunchKernelGGL(gram_bf16_kernel, dim3(grid), dim3(GT), 0, s, g);
+  hipLaunchKernelGGL(gram_f16_kernel, dim3(grid), dim3(GT), 0, s, g);
 }
 
 std::vector<int> gram_tile_order(int n) {

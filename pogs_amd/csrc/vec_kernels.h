@@ -15,6 +15,7 @@ namespace pogs_amd {
 // ranges).  The second group holds sums over columns (replicated data).
 enum Slot : int {
   kGapY = 0, kWY2, kHY2, kDYprev2, kDY12, kExactR2, kPowSx2, kFro2, kFvalF, kCgQ2,
+  kAmax = 10,   // max |entry| of the scaled matrix before the Frobenius normalisation (local shard)
   kGapX = 12, kWX2, kHX2, kDXprev2, kDX12, kExactS2, kPowX2, kPowXGx, kFvalG, kCgP2, kCgS2, kCgX2,
   kSpecGapY = 26, kSpecWY2, kSpecHY2,   // next iteration's y-half sums from the one-pass kernel
   kSpecGapX = 29, kSpecWX2, kSpecHX2,   // ... x-half sums (m <= n, transposed storage)
@@ -99,6 +100,9 @@ void launch_publish_scalars(const double *S, int count, double *host_S, unsigned
 // u = y12 + c yt - yprev   (pogs.cpp:366-368, y half)
 template <typename T>
 void launch_exact_u(int m, const T *y12, const T *yt, const T *yprev, T c, T *u, hipStream_t s);
+
+// *out = max_b partials[b]
+void launch_max_partials(const double *partials, int n, double *out, hipStream_t s);
 
 void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s);
 

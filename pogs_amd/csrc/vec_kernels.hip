@@ -229,6 +229,22 @@ void launch_publish_scalars(const double *S, int count, double *host_S, unsigned
   hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, s, S, count, host_S, host_seq, seq);
 }
 
+namespace {
+__global__ void __launch_bounds__(256) max_partials_kernel(const double *partials, int n, double *out) {
+  __shared__ double s_w[4];
+  double v = 0.0;
+  for (int b = threadIdx.x; b < n; b += 256) v = fmax(v, partials[b]);
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = fmax(fmax(s_w[0], s_w[1]), fmax(s_w[2], s_w[3]));
+}
+}  // namespace
+
+void launch_max_partials(const double *partials, int n, double *out, hipStream_t s) {
+  hipLaunchKernelGGL(max_partials_kernel, dim3(1), dim3(256), 0, s, partials, n, out);
+}
+
 void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s) {
   POGS_CHECK(njobs >= 1 && njobs <= 4, "sum jobs");
   SumJobs j;

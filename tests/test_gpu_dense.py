@@ -779,10 +779,10 @@ def test_windowed_passes_on_small_matrices(dtype, shape, cgls, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(20000, 1500), (1300, 21000)])
-def test_bf16_split_gram_is_as_exact_as_the_fp32_product(shape, monkeypatch):
-    """fp32 Gram through the three-way bf16 split (six products on the bf16 matrix cores) against
-    the native fp32 MFMA product (POGS_AMD_GRAM=fp32): the projection built on it satisfies its
-    KKT conditions at least as well, and the solves agree."""
+def test_fp16_split_gram_is_as_exact_as_the_fp32_product(shape, monkeypatch):
+    """fp32 Gram through the scaled two-way fp16 split (three products on the fp16 matrix cores)
+    against the native fp32 MFMA product (POGS_AMD_GRAM=fp32): the projection built on it
+    satisfies its KKT conditions at least as well, and the solves agree."""
     pogs = _pogs()
     from pogs_amd import synth
 
@@ -793,7 +793,7 @@ def test_bf16_split_gram_is_as_exact_as_the_fp32_product(shape, monkeypatch):
     rng = np.random.default_rng(6)
     x0, y0 = rng.standard_normal(n), rng.standard_normal(m)
     out = {}
-    for mode in ("bf16", "fp32"):
+    for mode in ("f16", "fp32"):
         if mode == "fp32":
             monkeypatch.setenv("POGS_AMD_GRAM", "fp32")
         with pogs.Solver(A, dtype=np.float32) as s:
@@ -802,9 +802,9 @@ def test_bf16_split_gram_is_as_exact_as_the_fp32_product(shape, monkeypatch):
             A64 = A_eq.astype(np.float64)
             kkt = np.linalg.norm(A64.T @ (py - y0) + (px - x0)) / np.sqrt(n)
             out[mode] = (kkt, s.solve(f, g))
-    assert out["bf16"][0] < 2e-5
-    assert out["bf16"][0] < 2.0 * out["fp32"][0] + 1e-7
-    rb, rf = out["bf16"][1], out["fp32"][1]
+    assert out["f16"][0] < 2e-5
+    assert out["f16"][0] < 2.0 * out["fp32"][0] + 1e-7
+    rb, rf = out["f16"][1], out["fp32"][1]
     assert rb["status"] == rf["status"] == 0
     assert abs(int(rb["iterations"]) - int(rf["iterations"])) <= max(3, rf["iterations"] // 10)
     assert relerr(rb["x"], rf["x"]) < 5e-4
