@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <cstring>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../include/pogs_amd.h"
@@ -85,6 +87,23 @@ struct PhaseTimer {
   }
 };
 
+// Streams and the host-mapped scalar mirror are recycled across solver handles of a process
+// (POGS_AMD_RECYCLE=0 turns that off): a one-shot solve creates and destroys a handle per
+// call, and stream / mapped-host churn costs milliseconds per call plus occasional
+// tens-of-milliseconds stalls inside the runtime.  Entries are never destroyed (a handful
+// of streams and 4 KB blocks per device for the life of the process).
+struct CtxResources {
+  hipStream_t stream = nullptr;
+  double *host = nullptr;       // kNumSlots + 1 doubles, hipHostMallocMapped | Coherent
+  int device = -1;
+};
+inline std::mutex &ctx_pool_mutex() { static std::mutex *m = new std::mutex; return *m; }
+inline std::vector<CtxResources> &ctx_pool() { static auto *v = new std::vector<CtxResources>; return *v; }
+inline bool ctx_recycle() {
+  static const bool on = [] { const char *e = std::getenv("POGS_AMD_RECYCLE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 struct Ctx {
   int device = 0;
   int num_cu = 256;
@@ -92,7 +111,7 @@ struct Ctx {
   DistComm dist;
   size_t m_global = 0;
   DevBuf<double> S;            // device scalar block [kNumSlots]
-  PinnedBuf<double> S_host;    // pinned mirror
+  struct HostMirror { double *p = nullptr; } S_host;   // host-mapped mirror (CtxResources)
   DevBuf<double> spart;        // scalar partial sums scratch
   size_t spart_cap = 0;
   EventTimer stream_timer;
@@ -104,10 +123,25 @@ struct Ctx {
     hipDeviceProp_t prop;
     POGS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    POGS_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (ctx_recycle()) {
+      std::lock_guard<std::mutex> lock(ctx_pool_mutex());
+      auto &pool = ctx_pool();
+      for (size_t i = 0; i < pool.size(); ++i)
+        if (pool[i].device == device) {
+          stream = pool[i].stream;
+          S_host.p = pool[i].host;
+          pool.erase(pool.begin() + static_cast<long>(i));
+          break;
+        }
+    }
+    if (!stream) {
+      POGS_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      // + the sequence word of fetch_scalars
+      POGS_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&S_host.p), (kNumSlots + 1) * sizeof(double),
+                                   hipHostMallocMapped | hipHostMallocCoherent));
+    }
     S.alloc(kNumSlots);
     S.zero(stream);
-    S_host.alloc(kNumSlots + 1);   // + the sequence word of fetch_scalars
     std::memset(S_host.p, 0, (kNumSlots + 1) * sizeof(double));
     {
       const char *fe = std::getenv("POGS_AMD_FETCH");
@@ -176,7 +210,19 @@ struct Ctx {
   }
   double tmark_last = 0;
   ~Ctx() {
-    if (stream) (void)hipStreamDestroy(stream);
+    if (!stream) return;
+    (void)hipStreamSynchronize(stream);
+    if (ctx_recycle()) {
+      std::lock_guard<std::mutex> lock(ctx_pool_mutex());
+      CtxResources r;
+      r.stream = stream;
+      r.host = S_host.p;
+      r.device = device;
+      ctx_pool().push_back(r);
+    } else {
+      (void)hipStreamDestroy(stream);
+      if (S_host.p) (void)hipHostFree(S_host.p);
+    }
   }
 };
 
