@@ -228,6 +228,36 @@ def test_column_blocked_spmv_several_blocks(dtype):
         assert relerr(got_t, 2.0 * (As.T @ y.astype(np.float64)) + 0.5 * x) < tol
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_column_blocked_spmv_skewed_structure(dtype):
+    """Adjacent nearly dense rows inside one column block (their fragment has to be split at the
+    16-bit offset limit), a fully dense column (a 40000-entry row of the transpose), empty rows at
+    both ends."""
+    pogs = _pogs()
+    from pogs_amd import _lib
+
+    rng = np.random.default_rng(3)
+    m0, n, k = 40000, 61000, 5
+    A = sp.csr_matrix((rng.standard_normal(m0 * k), (np.repeat(np.arange(m0), k), rng.integers(0, n, m0 * k))),
+                      shape=(m0, n)).tolil()
+    for r in range(100, 106):
+        A[r, rng.choice(28000, 26000, replace=False)] = rng.standard_normal(26000)
+    A = A.tocsr() + sp.csr_matrix((rng.standard_normal(m0), (np.arange(m0), np.full(m0, n - 7))), shape=(m0, n))
+    A = sp.vstack([sp.csr_matrix((3, n)), A, sp.csr_matrix((2, n))]).tocsr().astype(dtype)
+    A.sum_duplicates()
+    A.sort_indices()
+    m = A.shape[0]
+    x, y = rng.standard_normal(n).astype(dtype), rng.standard_normal(m).astype(dtype)
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    with pogs.Solver(A, dtype=dtype) as s:
+        buf = np.zeros(A.nnz, dtype)
+        nrm = ctypes.c_double()
+        assert _lib.lib.PogsAmdGetEquil(s._h, buf.ctypes.data_as(ctypes.c_void_p), None, None, ctypes.byref(nrm)) == 0
+        As = sp.csr_matrix((buf.astype(np.float64), A.indices, A.indptr), shape=(m, n))
+        assert relerr(s.mul("n", 1.0, x, 0.0, np.zeros(m, dtype)), As @ x.astype(np.float64)) < tol
+        assert relerr(s.mul("t", 1.0, y, 0.0, np.zeros(n, dtype)), As.T @ y.astype(np.float64)) < tol
+
+
 def test_plain_csr_kernel_still_matches(monkeypatch):
     """POGS_AMD_SPMV=plain keeps the un-blocked CSR-stream kernel (the fallback for shapes whose
     per-(block, row) bookkeeping would outweigh the non-zeros): same solve, same iterations."""
