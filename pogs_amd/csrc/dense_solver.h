@@ -482,33 +482,49 @@ class DenseSolver final : public SolverBase {
     const int gridBOTH = stream_grid<true, true>(planA_, srows_);
     StreamArgs<T> a = argsA();
     ctx_.tmark("  eq: start");
+    // The reference runs a fixed 50 iterations (equil_helper.h:147).  Once a whole iteration moves
+    // no entry of the scaling vector by more than 8 ulp the remaining ones reproduce the same
+    // numbers, so they are skipped (POGS_AMD_SK_FULL=1 keeps all 50); matrices on which the
+    // iteration keeps drifting simply run the full count.
+    const char *sk_env = std::getenv("POGS_AMD_SK_FULL");
+    const bool sk_full = sk_env && sk_env[0] == '1';
+    double *mark = sk_full ? nullptr : ctx_.S.p + kSkMark;
+    const T sk_tol = 8 * std::numeric_limits<T>::epsilon();
+    auto sk_stationary = [&](int k) {
+      if (!mark || k < 2) return false;
+      return ctx_.fetch_scalars()[kSkMark] < k + 1.0;
+    };
     if (tmode_) {
       // stored rows are the columns of A: one fused pass per iteration, the row dot (with d) gives
       // e_j, the column sums (weighted by e_j) give d   (equil_helper.h:149-163, d = 1 to start)
       double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
       launch_fill<T>(d_.p, static_cast<T>(1), m_, s);
-      for (int k = 0; k < 50; ++k) {
+      int k = 0;
+      for (; k < 50; ++k) {
         a.xin = d_.p;
         launch_stream<T, true, true, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(mg), ce, e_.p}, s);
-        launch_reduce_cols<T, SkColOp<T>>(colpart_.p, gridBOTH, scols_pad_, SkColOp<T>{static_cast<T>(nn), cd, d_.p, m_},
-                                          sp, s);
+        launch_reduce_cols<T, SkColOp<T>>(colpart_.p, gridBOTH, scols_pad_,
+                                          SkColOp<T>{static_cast<T>(nn), cd, d_.p, m_, mark, k + 1.0, sk_tol}, sp, s);
+        if (sk_stationary(k)) { ++k; break; }
       }
-      ctx_.stats.matvecs_init += 50;
+      ctx_.stats.matvecs_init += k;
     } else {
       launch_stream<T, false, true, true, kFull>(planA_, a, OnesOp<T>{}, s);
       ctx_.tmark("  eq: first pass");
       finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_}, nullptr, 0, 0, gridACC);
       ctx_.tmark("  eq: first cols");
-      for (int k = 0; k < 50; ++k) {
+      int k = 0;
+      for (; k < 50; ++k) {
         a.xin = e_.p;
         if (k < 49) {
           launch_stream<T, true, true, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
-          finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_}, nullptr, 0, 0, gridBOTH);
+          finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_, mark, k + 1.0, sk_tol}, nullptr, 0, 0, gridBOTH);
+          if (sk_stationary(k)) { ++k; break; }
         } else {
           launch_stream<T, true, false, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
         }
       }
-      ctx_.stats.matvecs_init += 51;
+      ctx_.stats.matvecs_init += k + 1;
     }
     ctx_.tmark("  eq: sk loop");
     launch_sqrt_inplace<T>(d_.p, m_, s);                                  // matrix_dense.cpp:176-177

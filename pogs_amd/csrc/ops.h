@@ -437,9 +437,20 @@ struct SkColOp {
   T mm, c;
   T *e;
   int n;
+  // stationarity probe: an entry that moved by more than tol (relative) stamps *mark with the
+  // number of the pass (every writer stores the same value); the host stops the iteration once
+  // a pass leaves no stamp
+  double *mark = nullptr;
+  double stamp = 0;
+  T tol = 0;
   template <int N>
   __device__ __forceinline__ void col(int j, T total, double (&)[N]) const {
-    e[j] = (j < n) ? mm / (total + c) : static_cast<T>(0);
+    const T v = (j < n) ? mm / (total + c) : static_cast<T>(0);
+    if (mark) {
+      const T old = e[j];
+      if (!(fabs(v - old) <= tol * fabs(v))) *mark = stamp;
+    }
+    e[j] = v;
   }
 };
 

@@ -87,8 +87,19 @@ struct SpSkOp {  // out[i] = num / (dot + c)   (equil_helper.h:149-162)
   static constexpr int NS = 0;
   T num, c;
   T *out;
+  // stationarity probe, see SkColOp in ops.h
+  double *mark = nullptr;
+  double stamp = 0;
+  T tol = 0;
   template <int N>
-  __device__ __forceinline__ void row(int i, T dot, double (&)[N]) const { out[i] = num / (dot + c); }
+  __device__ __forceinline__ void row(int i, T dot, double (&)[N]) const {
+    const T v = num / (dot + c);
+    if (mark) {
+      const T old = out[i];
+      if (!(fabs(v - old) <= tol * fabs(v))) *mark = stamp;
+    }
+    out[i] = v;
+  }
 };
 
 template <typename T>
@@ -1046,11 +1057,21 @@ class SparseSolver final : public SolverBase {
     const T cd = static_cast<T>(1e-4) * static_cast<T>(mg + nn) / static_cast<T>(nn);
     launch_fill<T>(d_.p, static_cast<T>(1), m_, s);
     launch_fill<T>(e_.p, static_cast<T>(1), n_, s);
-    for (int k = 0; k < 50; ++k) {
-      spmv_t<true>(d_.p, SpSkOp<T>{static_cast<T>(mg), ce, e_.p}, nullptr);
+    // 50 iterations in the reference (equil_helper.h:147); an iteration that moves no entry of e
+    // (replicated, so every rank of a sharded solve sees the same stamp) by more than 8 ulp ends
+    // the loop after its d update -- see DenseSolver::equilibrate.  POGS_AMD_SK_FULL=1: all 50.
+    const char *sk_env = std::getenv("POGS_AMD_SK_FULL");
+    const bool sk_full = sk_env && sk_env[0] == '1';
+    double *mark = sk_full ? nullptr : ctx_.S.p + kSkMark;
+    const T sk_tol = 8 * std::numeric_limits<T>::epsilon();
+    int k = 0;
+    while (k < 50) {
+      spmv_t<true>(d_.p, SpSkOp<T>{static_cast<T>(mg), ce, e_.p, mark, k + 1.0, sk_tol}, nullptr);
       spmv<true>(A_, e_.p, nullptr, SpSkOp<T>{static_cast<T>(nn), cd, d_.p}, nullptr, 0);
+      ++k;
+      if (mark && k >= 3 && ctx_.fetch_scalars()[kSkMark] < static_cast<double>(k)) break;
     }
-    ctx_.stats.matvecs_init += 100;
+    ctx_.stats.matvecs_init += 2 * k;
     launch_sqrt_inplace<T>(d_.p, m_, s);
     launch_sqrt_inplace<T>(e_.p, n_, s);
     const int g = ctx_.num_cu * 8;

@@ -173,3 +173,38 @@ def test_c3_dense_logistic_200000x5000_kkt():
     loss = lambda yy, xx: torch.sum(torch.nn.functional.softplus(-lab * yy)).item() + lam1 * float(torch.sum(torch.abs(xx)))  # noqa: E731
     assert r["optval"] == pytest.approx(loss(y, x), rel=2e-3)
     assert loss(A @ x, x) < loss(torch.zeros(m, device=dev), torch.zeros(n, device=dev))
+
+
+def test_c2_sinkhorn_knopp_early_exit_matches_full_count(monkeypatch):
+    """configs[1] shape: the stationarity probe ends the Sinkhorn-Knopp loop after a few passes; the
+    47 skipped iterations of the reference would only have moved the common factor (d * a, e / a) by
+    a few 1e-6, which D A E does not see.  Same iteration count and solution as the full count."""
+    torch = _torch()
+    pogs = _pogs()
+    m, n = 100000, 10000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float32)
+    xt = torch.randn(n, generator=g, device=dev) * (torch.rand(n, generator=g, device=dev) < 0.1)
+    b = (A @ xt + 0.1 * torch.randn(m, generator=g, device=dev)).double().cpu().numpy()
+    torch.cuda.synchronize()
+    f, gg = pogs.graph.lasso_functions(b, LAM, n)
+    got = {}
+    for mode in ("early", "full"):
+        if mode == "full":
+            monkeypatch.setenv("POGS_AMD_SK_FULL", "1")
+        with pogs.Solver(A.data_ptr(), dtype=np.float32, shape=(m, n), device_ptr=True) as s:
+            r = s.solve(f, gg)
+            _, d, e, nrm = s.equilibrated(want_matrix=False)
+            got[mode] = (d.astype(np.float64), e.astype(np.float64), nrm, r, s.stats()["matvecs_init"])
+    d0, e0, n0, r0, p0 = got["early"]
+    d1, e1, n1, r1, p1 = got["full"]
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert p0 < p1 and p0 <= 12
+    assert rel(d0, d1) < 2e-5 and rel(e0, e1) < 2e-5
+    assert rel(np.outer(d0[:100], e0[:100]), np.outer(d1[:100], e1[:100])) < 1e-6
+    assert n0 == pytest.approx(n1, rel=1e-5)
+    assert r0["status"] == r1["status"] == 0
+    assert abs(int(r0["iterations"]) - int(r1["iterations"])) <= 1
+    assert rel(r0["x"].astype(np.float64), r1["x"].astype(np.float64)) < 1e-4
