@@ -370,8 +370,14 @@ class DenseSolver final : public SolverBase {
       y12s_.alloc(m_); ytemps_.alloc(m_);
       y12s_.zero(s); ytemps_.zero(s);
     }
+    // scalar-partials scratch: [stream passes | column reductions, vector kernels | prox partials
+    // of the one-pass iteration | its projection-tail partials] -- the last two have regions of
+    // their own because that iteration sums everything in its closing launch (Ctx::queue_sum)
     const size_t vb = vec_blocks(n_) + vec_blocks(m_);
-    ctx_.ensure_spart(static_cast<size_t>(planA_.grid_max) * 6 + std::max<size_t>(4096, vb * 3 + 64));
+    const size_t r01 = static_cast<size_t>(planA_.grid_max) * 6 + std::max<size_t>(4096, vb * 3 + 64);
+    sp_pre_off_ = r01;
+    sp_tail_off_ = r01 + vb * 3 + 64;
+    ctx_.ensure_spart(sp_tail_off_ + static_cast<size_t>(ctx_.num_cu) * 32);
   }
 
   StreamArgs<T> argsA() const {
@@ -453,8 +459,19 @@ class DenseSolver final : public SolverBase {
     }
     if (ColOp::NS > 0 && colop_scalar_out) {
       SumJob j{sp, reduce_cols_grid(n_pad_, Vec16<T>::N), ColOp::NS, colop_scalar_out};
-      launch_sum_jobs(&j, 1, s);
+      sum_now_or_later(j);
     }
+  }
+
+  static bool defer_allowed() {   // POGS_AMD_DEFER=0: one launch per sum, as on row shards
+    static const bool on = [] { const char *e = std::getenv("POGS_AMD_DEFER"); return !(e && e[0] == '0'); }();
+    return on;
+  }
+  // Scalar sums of the one-pass iteration wait for its closing launch (single GPU); everywhere
+  // else they run at once.
+  void sum_now_or_later(const SumJob &j) {
+    if (defer_sums_) ctx_.queue_sum(j);
+    else launch_sum_jobs(&j, 1, ctx_.stream);
   }
 
   // col partials <- A^T u (ACC-only pass)
@@ -824,15 +841,16 @@ class DenseSolver final : public SolverBase {
     StreamArgs<T> a;
     a.A = Wp_; a.lda = k_pad_; a.m = k_; a.n_pad = k_pad_;
     a.xin = rhs; a.xin_add = add; a.xin_nrm2 = nullptr;
-    a.col_partials = nullptr; a.scalar_partials = ctx_.spart.p;
+    double *part = defer_sums_ ? ctx_.spart.p + sp_tail_off_ : ctx_.spart.p;
+    a.col_partials = nullptr; a.scalar_partials = part;
     a.xl_scratch = xl_buf_.p;
     launch_stream<T, true, false, false, kLower>(planW_, a, GemvNOp<T>{1, 0, tvec_.p}, s);
     a.A = Up_;
     a.xin = tvec_.p; a.xin_add = nullptr;
     launch_stream<T, true, false, false, kUpper>(planW_, a, tail, s);
     if (TailOp::NS > 0 && tail_scalars) {
-      SumJob j{ctx_.spart.p, stream_grid<true, false>(planW_, k_), TailOp::NS, tail_scalars};
-      launch_sum_jobs(&j, 1, s);
+      SumJob j{part, stream_grid<true, false>(planW_, k_), TailOp::NS, tail_scalars};
+      sum_now_or_later(j);
     }
   }
 
@@ -1101,6 +1119,14 @@ class DenseSolver final : public SolverBase {
     hipStream_t s = ctx_.stream;
     const int nw = cur_ ^ 1;
     const int bx = vec_blocks(n_), by = vec_blocks(m_);
+    // single GPU: every scalar sum of the iteration runs in the launch that publishes the scalar
+    // block (row shards need the sums on the device before their collectives)
+    struct DeferGuard {
+      bool &flag;
+      DeferGuard(bool &f, bool on) : flag(f) { flag = on; }
+      ~DeferGuard() { flag = false; }
+    } defer_guard(defer_sums_, !multi_ && defer_allowed());
+    const bool spec = spec_valid_;
     // (A) prox / over-relaxation: x half always, y half unless already speculated
     AdmmPreArgs<T> pa;
     pa.n_x = n_; pa.n_y = spec_valid_ ? 0 : m_;
@@ -1111,18 +1137,23 @@ class DenseSolver final : public SolverBase {
     pa.x12 = x12_.p; pa.y12 = y12_.p;
     pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
     pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
-    pa.partials = ctx_.spart.p;
+    pa.partials = ctx_.spart.p + sp_pre_off_;
     pa.blocks_x = bx;
     launch_admm_pre<T>(pa, s);
     {
-      SumJob j[2] = {{ctx_.spart.p, bx, 3, ctx_.S.p + kGapX},
-                     {ctx_.spart.p + static_cast<size_t>(bx) * 3, by, 3, ctx_.S.p + kGapY}};
-      launch_sum_jobs(j, spec_valid_ ? 1 : 2, s);
+      SumJob j[2] = {{pa.partials, bx, 3, ctx_.S.p + kGapX},
+                     {pa.partials + static_cast<size_t>(bx) * 3, by, 3, ctx_.S.p + kGapY}};
+      if (defer_sums_) {
+        ctx_.queue_sum(j[0]);
+        if (!spec) ctx_.queue_sum(j[1]);
+      } else {
+        launch_sum_jobs(j, spec ? 1 : 2, s);
+      }
     }
     int nparts;
     if (spec_valid_) {
-      POGS_HIP_CHECK(hipMemcpyAsync(ctx_.S.p + kGapY, ctx_.S.p + kSpecGapY, 3 * sizeof(double),
-                                    hipMemcpyDeviceToDevice, s));
+      // the y-half sums of this iteration came with the previous pass (kSpecGapY, already on the
+      // host -- and all-reduced on row shards): spec_gap_ stands in for kGapY after the fetch
       nparts = stream2_grid<2>(planA_, m_);
     } else {
       // (B) column sums A^T yhat_k and A^T (y12 + c yt - yprev)
@@ -1177,7 +1208,12 @@ class DenseSolver final : public SolverBase {
       const int grid = stream2_grid<2>(planA_, m_);
       SumJob j[2] = {{ctx_.spart.p, grid, 3, ctx_.S.p + kDYprev2, 6, 0},
                      {ctx_.spart.p, grid, 3, ctx_.S.p + kSpecGapY, 6, 3}};
-      launch_sum_jobs(j, 2, s);
+      if (defer_sums_) {
+        ctx_.queue_sum(j[0]);
+        ctx_.queue_sum(j[1]);
+      } else {
+        launch_sum_jobs(j, 2, s);
+      }
       if (multi_) {
         // this iteration's y-residual sums, and the speculative column sums / y-half sums of the
         // next one, in one group
@@ -1191,7 +1227,10 @@ class DenseSolver final : public SolverBase {
       ctx_.stats.matvecs += 1;
     }
     // (E) host decisions (pogs.cpp:270-273, 342-394)
-    const double *S = ctx_.fetch_scalars();
+    double S[kNumSlots];
+    std::memcpy(S, ctx_.fetch_scalars(), sizeof(S));
+    if (spec)
+      for (int q = 0; q < 3; ++q) S[kGapY + q] = spec_gap_[q];
     ctl_.set_pre(S);
     bool exact = false;
     if (ctl_.set_approx(S, nrmA_)) {
@@ -1211,6 +1250,7 @@ class DenseSolver final : public SolverBase {
     if (ctl_.rho == rho_pred_ && zt_scale_ == zs_pred_) {
       std::swap(ytemp_, ytemps_);      // ytemp = speculative yhat_{k+1}
       std::swap(y12_, y12s_);          // y12 = speculative y12_{k+1}
+      for (int q = 0; q < 3; ++q) spec_gap_[q] = S[kSpecGapY + q];
       spec_valid_ = true;
       ctx_.stats.reserved[0] += 1;     // speculation hits
     } else {
@@ -1360,6 +1400,9 @@ class DenseSolver final : public SolverBase {
   int m_ = 0, n_ = 0, n_pad_ = 0, k_ = 0, k_pad_ = 0;
   bool tall_ = true, multi_ = false, use_cgls_ = false;
   double amax_ = 0;             // max |entry| of the equilibrated matrix (fp16 scaling of the Gram product)
+  bool defer_sums_ = false;     // inside iteration_fused on one GPU: sums wait for the closing launch
+  size_t sp_pre_off_ = 0, sp_tail_off_ = 0;   // regions of ctx_.spart (alloc_state)
+  double spec_gap_[3] = {0, 0, 0};            // y-half sums of the speculated iteration (host copy)
   bool tmode_ = false;          // A^T is what is stored (m <= n, direct projector)
   int m_pad_ = 0, srows_ = 0, scols_pad_ = 0;   // stored rows / padded stored row length
   DevBuf<T> xl_buf_;            // windowed passes: partial row dots per window + the coefficient vector

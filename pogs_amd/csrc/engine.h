@@ -142,6 +142,8 @@ struct Ctx {
     }
     S.alloc(kNumSlots);
     S.zero(stream);
+    pub_counter.alloc(1);
+    pub_counter.zero(stream);
     std::memset(S_host.p, 0, (kNumSlots + 1) * sizeof(double));
     {
       const char *fe = std::getenv("POGS_AMD_FETCH");
@@ -165,16 +167,34 @@ struct Ctx {
   // host polls (the stream is in order, so seeing the word means all earlier work is done);
   // that saves the copy-engine round trip and the synchronize call of the plain path
   // (POGS_AMD_FETCH=memcpy), which is also the fallback if the poll sees no progress.
+  // Deferred scalar sums: jobs queued here run in the launch that publishes the scalar block
+  // (sum_publish_kernel), so an iteration ends with one small launch instead of one per sum plus
+  // the publish.  Whoever queues a job keeps its partials untouched until the next fetch.
+  void queue_sum(const SumJob &j) {
+    if (npending == kMaxSumJobs) flush_sums();
+    pending[npending++] = j;
+  }
+  void flush_sums() {
+    if (npending) launch_sum_jobs(pending, npending, stream);
+    npending = 0;
+  }
   const double *fetch_scalars() {
     if (!poll_fetch) {
+      flush_sums();
       POGS_HIP_CHECK(hipMemcpyAsync(S_host.p, S.p, kNumSlots * sizeof(double), hipMemcpyDeviceToHost, stream));
       POGS_HIP_CHECK(hipStreamSynchronize(stream));
       return S_host.p;
     }
     const unsigned long long want = ++fetch_seq;
     unsigned long long *seqp = reinterpret_cast<unsigned long long *>(S_host.p + kNumSlots);
-    launch_publish_scalars(S.p, kNumSlots, S_host_dev, reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots),
-                           want, stream);
+    if (npending) {
+      launch_sum_publish(pending, npending, S.p, kNumSlots, S_host_dev,
+                         reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots), want, pub_counter.p, stream);
+      npending = 0;
+    } else {
+      launch_publish_scalars(S.p, kNumSlots, S_host_dev, reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots),
+                             want, stream);
+    }
     unsigned spins = 0;
     while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != want) {
       if (++spins == (1u << 14)) {   // ~ every few hundred microseconds: surface a failed stream
@@ -193,9 +213,15 @@ struct Ctx {
     return S_host.p;
   }
   bool poll_fetch = true;
+  SumJob pending[kMaxSumJobs];
+  int npending = 0;
+  DevBuf<unsigned> pub_counter;
   unsigned long long fetch_seq = 0;
   double *S_host_dev = nullptr;   // device address of the host-mapped mirror
-  void sync() { POGS_HIP_CHECK(hipStreamSynchronize(stream)); }
+  void sync() {
+    flush_sums();
+    POGS_HIP_CHECK(hipStreamSynchronize(stream));
+  }
   // POGS_AMD_TRACE=1: host-side setup timeline on stderr (time to reach the mark on the host,
   // then the extra wait for the stream to drain) -- finds host stalls the kernel trace hides.
   void tmark(const char *label) {

@@ -92,6 +92,11 @@ struct SumJob {
   int stride = 0;   // doubles between consecutive partial records (0: ns)
   int offset = 0;   // first scalar of the record to sum
 };
+constexpr int kMaxSumJobs = 8;
+// launch_sum_jobs and launch_publish_scalars in one launch (see sum_publish_kernel); *counter is a
+// zero-initialised device word the kernel leaves at zero.
+void launch_sum_publish(const SumJob *jobs, int njobs, const double *S, int count, double *host_S,
+                        unsigned long long *host_seq, unsigned long long seq, unsigned *counter, hipStream_t s);
 // Copies the device scalar block to a host-mapped mirror and then raises *host_seq to `seq`
 // (system-scope release): the host reads the block after polling the sequence word, with no
 // copy-engine round trip and no stream-synchronize call.

@@ -116,14 +116,12 @@ __global__ void __launch_bounds__(kVecTpb) unscale_kernel(UnscaleArgs<T> a, int 
 }
 
 struct SumJobs {
-  SumJob j[4];
+  SumJob j[kMaxSumJobs];
 };
 
-__global__ void __launch_bounds__(256) sum_jobs_kernel(SumJobs jobs) {
-  // the whole workgroup strides over the partials of one scalar at a time (independent loads,
-  // four in flight per thread), then a fixed-order wave / workgroup reduction
-  __shared__ double s_w[4];
-  const SumJob job = jobs.j[blockIdx.x];
+// the whole workgroup strides over the partials of one scalar at a time (independent loads,
+// four in flight per thread), then a fixed-order wave / workgroup reduction
+__device__ __forceinline__ void run_sum_job(const SumJob &job, double (&s_w)[4]) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const size_t stride = job.stride > 0 ? job.stride : job.ns;
   for (int k = 0; k < job.ns; ++k) {
@@ -143,6 +141,35 @@ __global__ void __launch_bounds__(256) sum_jobs_kernel(SumJobs jobs) {
     if (t == 0) job.out[k] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
     __syncthreads();
   }
+}
+
+__global__ void __launch_bounds__(256) sum_jobs_kernel(SumJobs jobs) {
+  __shared__ double s_w[4];
+  run_sum_job(jobs.j[blockIdx.x], s_w);
+}
+
+// The iteration's closing launch: one workgroup per sum job, and the workgroup that finishes
+// last (a device counter) copies the scalar block to the host-mapped mirror and raises the
+// sequence word -- publish_scalars_kernel without a launch of its own.
+__global__ void __launch_bounds__(256) sum_publish_kernel(SumJobs jobs, int njobs, const double *S, int count,
+                                                          double *host_S, unsigned long long *host_seq,
+                                                          unsigned long long seq, unsigned *counter) {
+  __shared__ double s_w[4];
+  __shared__ unsigned s_last;
+  run_sum_job(jobs.j[blockIdx.x], s_w);
+  if (threadIdx.x == 0) {
+    __threadfence();   // this job's sums before the count
+    s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(njobs - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();     // the other workgroups' sums before the copy
+  const int t = threadIdx.x;
+  if (t == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t < count) host_S[t] = __hip_atomic_load(S + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <typename T>
@@ -246,10 +273,19 @@ void launch_max_partials(const double *partials, int n, double *out, hipStream_t
 }
 
 void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s) {
-  POGS_CHECK(njobs >= 1 && njobs <= 4, "sum jobs");
+  POGS_CHECK(njobs >= 1 && njobs <= kMaxSumJobs, "sum jobs");
   SumJobs j;
-  for (int i = 0; i < 4; ++i) j.j[i] = jobs[i < njobs ? i : 0];
+  for (int i = 0; i < kMaxSumJobs; ++i) j.j[i] = jobs[i < njobs ? i : 0];
   hipLaunchKernelGGL(sum_jobs_kernel, dim3(njobs), dim3(256), 0, s, j);
+}
+
+void launch_sum_publish(const SumJob *jobs, int njobs, const double *S, int count, double *host_S,
+                        unsigned long long *host_seq, unsigned long long seq, unsigned *counter, hipStream_t s) {
+  POGS_CHECK(njobs >= 1 && njobs <= kMaxSumJobs && count <= 256, "sum jobs");
+  SumJobs j;
+  for (int i = 0; i < kMaxSumJobs; ++i) j.j[i] = jobs[i < njobs ? i : 0];
+  hipLaunchKernelGGL(sum_publish_kernel, dim3(njobs), dim3(256), 0, s, j, njobs, S, count, host_S, host_seq, seq,
+                     counter);
 }
 
 namespace {
