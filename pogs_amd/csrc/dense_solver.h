@@ -784,13 +784,31 @@ class DenseSolver final : public SolverBase {
       if (split16) {
         constexpr int kRows = 1024;
         const int nchunks = (kdim + kRows - 1) / kRows;
-        GramF16Args gb{reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, reinterpret_cast<float *>(G), ld, 4, kRows,
-                       0, slab, 0, g.tile_map, scale16};
-        for (int c0 = 0; c0 < nchunks; c0 += 4) {
-          gb.ks0 = c0;
-          gb.nslabs = std::min(4, nchunks - c0);
-          gb.accumulate = c0 > 0 ? 1 : 0;
-          launch_gram_f16(gb, s);
+        const bool presplit = !(gsel && gsel[0] == 's');   // POGS_AMD_GRAM=s: split inside the product kernel
+        if (presplit) {
+          // four K ranges at a time are split into two fp16 images in operand order (168 MB at C2,
+          // 60 us), which the product kernel copies straight into LDS (gemm.h)
+          const int npad = static_cast<int>(round_up(k_, 128));
+          DevBuf<unsigned char> img(static_cast<size_t>(2) * (4 * kRows) * npad * 2);
+          unsigned char *H = img.p, *L = img.p + static_cast<size_t>(4 * kRows) * npad * 2;
+          GramF16PArgs gp{H, L, npad, k_, reinterpret_cast<float *>(G), ld, 4, kRows, slab, 0, g.tile_map, scale16};
+          for (int c0 = 0; c0 < nchunks; c0 += 4) {
+            gp.nslabs = std::min(4, nchunks - c0);
+            gp.accumulate = c0 > 0 ? 1 : 0;
+            launch_split_f16(reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, c0 * kRows, gp.nslabs * kRows, npad,
+                             scale16, H, L, s);
+            launch_gram_f16p(gp, s);
+          }
+          ctx_.sync();   // img is freed at scope exit
+        } else {
+          GramF16Args gb{reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, reinterpret_cast<float *>(G), ld, 4,
+                         kRows, 0, slab, 0, g.tile_map, scale16};
+          for (int c0 = 0; c0 < nchunks; c0 += 4) {
+            gb.ks0 = c0;
+            gb.nslabs = std::min(4, nchunks - c0);
+            gb.accumulate = c0 > 0 ? 1 : 0;
+            launch_gram_f16(gb, s);
+          }
         }
         launch_sum_slabs<T>(G, slab, std::min(4, nchunks), G, ld, k_, s);
         ksplit = 0;   // skip the fp32 rounds below

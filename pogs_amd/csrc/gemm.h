@@ -62,6 +62,26 @@ struct GramF16Args {
 };
 void launch_gram_f16(const GramF16Args &g, hipStream_t s);
 
+// The same product from operands split ahead of time.  launch_split_f16 writes rows
+// [k0, k0 + krows) of P (zeros past K, zeros in columns [N, npad)) as two fp16 images H and L in
+// MFMA-operand order: [k / 8][npad][8], i.e. 16 bytes = eight consecutive k of one column, columns
+// contiguous -- a wavefront's async global->LDS copy of 64 columns is one 1 KB line and lands in
+// LDS exactly as the matrix cores read it.  launch_gram_f16p then only copies (no staging
+// registers, no LDS stores, no conversion) and multiplies.  npad: a multiple of 128; krows: a
+// multiple of 32; unit u of the launch covers image rows [u kchunk, (u + 1) kchunk), kchunk a
+// multiple of 32, and goes to slab u.
+void launch_split_f16(const float *P, size_t ld, int K, int N, int k0, int krows, int npad, float scale,
+                      void *H, void *L, hipStream_t s);
+struct GramF16PArgs {
+  const void *H, *L; int npad, N;
+  float *C; size_t ldc;
+  int nslabs, kchunk; size_t slab_stride;
+  int accumulate;
+  const int *tile_map;
+  float scale;
+};
+void launch_gram_f16p(const GramF16PArgs &g, hipStream_t s);
+
 // Lower-triangular tile order in 8 x 8 super-tiles for an n x n Gram product: the ~64
 // workgroups an XCD runs at a time then touch 16 operand panels instead of 65.
 std::vector<int> gram_tile_order(int n);

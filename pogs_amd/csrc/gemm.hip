@@ -445,7 +445,7 @@ constexpr int GBK = 16;   // rows per k-tile: one 32x32x16 MFMA step
 // registers, two 16-byte LDS stores in operand order [part][k / 8][column].  Four workgroups
 // per CU (128 VGPRs, 32 KB of LDS each): the loop is not software-pipelined beyond one
 // register stage, the resident waves hide the rest.
-__global__ void __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) gram_f16_kernel(GramF16Args g) {
+__global__ void __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2))) gram_f16_kernel(GramF16Args g) {
   __shared__ __attribute__((aligned(16))) f16x8 sh[2][2][2][2][BM];
   const int tm = (g.N + BM - 1) / BM;
   const int ntiles = tm * (tm + 1) / 2;
@@ -484,27 +484,37 @@ __global__ void __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) gr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float va[8], vb[8];
-  auto gload = [&](int k0) {
-    const int gi = i0 + li, gj = j0 + li;
+  // Two register stages, both in flight: a step first splits and stores the panel of k-tile
+  // i + 1 (requested two steps ago), re-issues the freed registers for tile i + 3, and then
+  // multiplies tile i -- so every load has two full steps to land.  Loads are unconditional
+  // (clamped addresses, no branches around them): columns past N only feed outputs that are never
+  // stored, and rows past kend exist in the last tile only.
+  float ra[2][8], rb[2][8];
+  // Buffer loads: one descriptor over this unit's K range (base and size are scalars), the
+  // column as the 32-bit lane offset, the row as a scalar offset -- no 64-bit lane addresses, and
+  // rows past kend fall outside the descriptor and read as zero.
+  const int voff_a = min(i0 + li, g.N - 1) * 4, voff_b = min(j0 + li, g.N - 1) * 4;
+  const int lk8u = __builtin_amdgcn_readfirstlane(lk8);   // wave-uniform: row offsets stay scalar
+  const unsigned row_bytes = static_cast<unsigned>(g.ld) * 4u;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(g.P + static_cast<size_t>(kbeg) * g.ld), 0,
+      static_cast<int>(static_cast<unsigned>(kend - kbeg) * row_bytes), 0x00020000);
+  auto gload = [&](float (&va)[8], float (&vb)[8], int k0) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int k = k0 + lk8 * 8 + q;
-      const bool kok = k < kend;
-      va[q] = (kok && gi < g.N) ? g.P[static_cast<size_t>(k) * g.ld + gi] : 0.f;
-      if (!diag) vb[q] = (kok && gj < g.N) ? g.P[static_cast<size_t>(k) * g.ld + gj] : 0.f;
+      const int soff = static_cast<int>(static_cast<unsigned>(k0 - kbeg + lk8u * 8 + q) * row_bytes);
+      va[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_a, soff, 0));
+      vb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_b, soff, 0));
     }
   };
-  auto lstore = [&](int st) {
+  auto lstore = [&](int st, const float (&va)[8], const float (&vb)[8]) {
     f16x8 h, l;
     split8_f16(va, g.scale, h, l);
     sh[st][0][0][lk8][li] = h; sh[st][0][1][lk8][li] = l;
-    if (!diag) {
-      split8_f16(vb, g.scale, h, l);
-      sh[st][1][0][lk8][li] = h; sh[st][1][1][lk8][li] = l;
-    }
+    split8_f16(vb, g.scale, h, l);   // diagonal tiles stage the same panel twice: 1 tile in 40, no branch
+    sh[st][1][0][lk8][li] = h; sh[st][1][1][lk8][li] = l;
   };
-  const int bop = diag ? 0 : 1;
+  constexpr int bop = 1;
   auto compute = [&](int st) {
     f16x8 A[2][2], B[2][2];
 #pragma unroll
@@ -525,21 +535,25 @@ __global__ void __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) gr
         acc[a][b] = c;
       }
   };
-  const int nk = ((kend - kbeg + GBK - 1) / GBK + 1) & ~1;   // even; rows past kend load as zero
-  if (kend > kbeg) {
-    gload(kbeg);
-    lstore(0);
+  const int nk = (kend - kbeg + GBK - 1) / GBK;
+  if (nk > 0) {
+    // tiles past the end load as zero (k >= kend in the masked branch)
+    gload(ra[0], rb[0], kbeg);
+    lstore(0, ra[0], rb[0]);
+    gload(ra[0], rb[0], kbeg + GBK);
+    gload(ra[1], rb[1], kbeg + 2 * GBK);
+    __syncthreads();
+#define POGS_GRAM_STEP(J)                                          \
+    if (kt + (J) >= nk) break;                                     \
+    lstore(((J) + 1) & 1, ra[(J) & 1], rb[(J) & 1]);               \
+    gload(ra[(J) & 1], rb[(J) & 1], kbeg + (kt + (J) + 3) * GBK);  \
+    compute((J) & 1);                                              \
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
-      gload(kbeg + (kt + 1) * GBK);
-      compute(0);
-      lstore(1);
-      __syncthreads();
-      gload(kbeg + (kt + 2) * GBK);
-      compute(1);
-      lstore(0);
-      __syncthreads();
+      POGS_GRAM_STEP(0)
+      POGS_GRAM_STEP(1)
     }
+#undef POGS_GRAM_STEP
   }
   const float inv2 = 1.0f / (g.scale * g.scale);
 #pragma unroll
@@ -559,6 +573,159 @@ __global__ void __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(3))) gr
 }
 
 }  // namespace
+
+namespace {
+
+constexpr int PBK = 32;   // image rows per step of the pre-split kernel: four 8-row groups, two MFMA k-steps
+
+__global__ void __launch_bounds__(256) split_f16_kernel(const float *P, size_t ld, int K, int N, int k0, int npad,
+                                                        float scale, f16x8 *H, f16x8 *L) {
+  // one thread: eight consecutive rows of one column -> one 16-byte group of each image
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int kg = blockIdx.y;
+  if (col >= npad) return;
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int k = k0 + kg * 8 + q;
+    v[q] = (k < K && col < N) ? P[static_cast<size_t>(k) * ld + col] : 0.f;
+  }
+  f16x8 h, l;
+  split8_f16(v, scale, h, l);
+  const size_t o = static_cast<size_t>(kg) * npad + col;
+  H[o] = h;
+  L[o] = l;
+}
+
+// 4 waves as 2 x 2, each 64 x 64 (2 x 2 MFMA tiles), one step = 32 image rows.  LDS stage:
+// [operand A/B][part h/l][8-row group 0..3][128 columns] x 16 B = 32 KB, two stages.  A step's 32
+// one-KB lines are copied by the four waves (eight each) with global_load_lds; the copy of step
+// i + 1 is in flight while step i is multiplied.
+__global__ void __launch_bounds__(GT) gram_f16p_kernel(GramF16PArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gram_lds[];
+  typedef f16x8 Stage[2][2][4][BM];
+  Stage *sh = reinterpret_cast<Stage *>(gram_lds);
+  const int tm = (g.N + BM - 1) / BM;
+  const int ntiles = tm * (tm + 1) / 2;
+  const int nunits = ntiles * g.nslabs;
+  const int per_xcd = (nunits + kNumXcd - 1) / kNumXcd;
+  const int unit = static_cast<int>(blockIdx.x % kNumXcd) * per_xcd + static_cast<int>(blockIdx.x / kNumXcd);
+  if (unit >= nunits || static_cast<int>(blockIdx.x / kNumXcd) >= per_xcd) return;
+  const int ks = unit / ntiles, tile = unit % ntiles;
+  int ti, tj;
+  if (g.tile_map) {
+    const int e = g.tile_map[tile];
+    ti = e >> 16;
+    tj = e & 0xffff;
+  } else {
+    ti = static_cast<int>((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > tile) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    tj = tile - ti * (ti + 1) / 2;
+  }
+  const int i0 = ti * BM, j0 = tj * BM;
+  float *Cout = g.C + static_cast<size_t>(ks) * g.slab_stride;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int r32 = lane & 31, kh = lane >> 5;
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nsteps = g.kchunk / PBK;
+  const size_t kg0 = static_cast<size_t>(ks) * (g.kchunk / 8);
+  // line q = wave * 8 + j of a step: operand q >> 4, part (q >> 3) & 1, row group (q >> 1) & 3, column half q & 1
+  auto issue = [&](int st, int step) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int q = wave * 8 + j;
+      const int op = q >> 4, part = (q >> 3) & 1, kg = (q >> 1) & 3, half = q & 1;
+      const f16x8 *img = reinterpret_cast<const f16x8 *>(part ? g.L : g.H);
+      const f16x8 *src = img + (kg0 + static_cast<size_t>(step) * 4 + kg) * g.npad + (op ? j0 : i0) + half * 64 + lane;
+      f16x8 *dst = &sh[st][op][part][kg][half * 64];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
+                                       (__attribute__((address_space(3))) void *)(dst), 16, 0, 0);
+    }
+  };
+  auto compute = [&](int st) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      f16x8 A[2][2], B[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          A[a][p] = sh[st][0][p][kk * 2 + kh][wm + a * 32 + r32];
+          B[a][p] = sh[st][1][p][kk * 2 + kh][wn + a * 32 + r32];
+        }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          floatx16 c = acc[a][b];   // small products first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][0], B[b][1], c, 0, 0, 0);   // h l
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][1], B[b][0], c, 0, 0, 0);   // l h
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][0], B[b][0], c, 0, 0, 0);   // h h
+          acc[a][b] = c;
+        }
+    }
+  };
+  if (nsteps > 0) issue(0, 0);
+  for (int i = 0; i < nsteps; ++i) {
+    // each wave waits for its own lines, the barrier then covers everybody's -- and says that
+    // the stage about to be refilled has been read by all
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (i + 1 < nsteps) issue((i + 1) & 1, i + 1);
+    compute(i & 1);
+  }
+  const float inv2 = 1.0f / (g.scale * g.scale);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm + a * 32 + (r / 4) * 8 + kh * 4 + (r % 4);
+        const int col = j0 + wn + b * 32 + r32;
+        if (row < g.N && col < g.N) {
+          float *c = Cout + static_cast<size_t>(row) * g.ldc + col;
+          const float v = acc[a][b][r] * inv2;
+          *c = g.accumulate ? *c + v : v;
+        }
+      }
+}
+
+}  // namespace
+
+void launch_split_f16(const float *P, size_t ld, int K, int N, int k0, int krows, int npad, float scale, void *H,
+                      void *L, hipStream_t s) {
+  if (krows <= 0) return;
+  hipLaunchKernelGGL(split_f16_kernel, dim3((npad + 255) / 256, krows / 8), dim3(256), 0, s, P, ld, K, N, k0, npad,
+                     scale, static_cast<f16x8 *>(H), static_cast<f16x8 *>(L));
+}
+
+void launch_gram_f16p(const GramF16PArgs &g, hipStream_t s) {
+  const int tm = (g.N + BM - 1) / BM;
+  const int nunits = tm * (tm + 1) / 2 * g.nslabs;
+  if (nunits <= 0) return;
+  constexpr int kLds = 2 * 2 * 2 * 4 * BM * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    POGS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_f16p_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    attr_set = true;
+  }
+  const int grid = (nunits + kNumXcd - 1) / kNumXcd * kNumXcd;
+  hipLaunchKernelGGL(gram_f16p_kernel, dim3(grid), dim3(GT), kLds, s, g);
+}
 
 void launch_gram_f16(const GramF16Args &g, hipStream_t s) {
   const int tm = (g.N + BM - 1) / BM;
