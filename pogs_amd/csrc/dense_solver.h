@@ -785,20 +785,45 @@ class DenseSolver final : public SolverBase {
         constexpr int kRows = 1024;
         const int nchunks = (kdim + kRows - 1) / kRows;
         const bool presplit = !(gsel && gsel[0] == 's');   // POGS_AMD_GRAM=s: split inside the product kernel
+        int nslabs_used = std::min(4, nchunks);
         if (presplit) {
           // four K ranges at a time are split into two fp16 images in operand order (168 MB at C2,
           // 60 us), which the product kernel copies straight into LDS (gemm.h)
-          const int npad = static_cast<int>(round_up(k_, 128));
-          DevBuf<unsigned char> img(static_cast<size_t>(2) * (4 * kRows) * npad * 2);
-          unsigned char *H = img.p, *L = img.p + static_cast<size_t>(4 * kRows) * npad * 2;
-          GramF16PArgs gp{H, L, npad, k_, reinterpret_cast<float *>(G), ld, 4, kRows, slab, 0, g.tile_map, scale16};
-          for (int c0 = 0; c0 < nchunks; c0 += 4) {
-            gp.nslabs = std::min(4, nchunks - c0);
-            gp.accumulate = c0 > 0 ? 1 : 0;
-            launch_split_f16(reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, c0 * kRows, gp.nslabs * kRows, npad,
+          // units of up to four 1024-row chains (summed in registers), four units per tile and
+          // launch into the four slabs: 16384 rows per round where the K dimension is that long
+          int chains = 1;
+          while (chains < 4 && kdim >= 4 * kRows * chains * 2) chains *= 2;
+          int tile = 128;
+          if (const char *ev = std::getenv("POGS_AMD_GRAM_TILE")) tile = std::atoi(ev) == 256 ? 256 : 128;   // tuning aid
+          if (const char *ev = std::getenv("POGS_AMD_GRAM_CHAINS")) chains = std::max(1, std::min(16, std::atoi(ev)));
+          if (tile == 256) chains = 1;
+          const int urows = kRows * chains;
+          const int nunits = (kdim + urows - 1) / urows;
+          const int npad = static_cast<int>(round_up(k_, tile));
+          DevBuf<unsigned char> img(static_cast<size_t>(2) * (4 * urows) * npad * 2);
+          unsigned char *H = img.p, *L = img.p + static_cast<size_t>(4 * urows) * npad * 2;
+          GramF16PArgs gp{H, L, npad, k_, reinterpret_cast<float *>(G), ld, 4, urows, slab, 0, g.tile_map, scale16};
+          gp.tile = tile;
+          gp.flush_rows = kRows;
+          DevBuf<int> tmap256;
+          if (tile == 256) {
+            gp.tile_map = nullptr;
+            if (k_ > 16 * 256) {
+              const std::vector<int> order = gram_tile_order(k_, 256);
+              tmap256.alloc(order.size());
+              POGS_HIP_CHECK(hipMemcpyAsync(tmap256.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, s));
+              ctx_.sync();   // order is a host temporary
+              gp.tile_map = tmap256.p;
+            }
+          }
+          for (int u0 = 0; u0 < nunits; u0 += 4) {
+            gp.nslabs = std::min(4, nunits - u0);
+            gp.accumulate = u0 > 0 ? 1 : 0;
+            launch_split_f16(reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, u0 * urows, gp.nslabs * urows, npad,
                              scale16, H, L, s);
             launch_gram_f16p(gp, s);
           }
+          nslabs_used = std::min(4, nunits);
           ctx_.sync();   // img is freed at scope exit
         } else {
           GramF16Args gb{reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, reinterpret_cast<float *>(G), ld, 4,
@@ -810,7 +835,7 @@ class DenseSolver final : public SolverBase {
             launch_gram_f16(gb, s);
           }
         }
-        launch_sum_slabs<T>(G, slab, std::min(4, nchunks), G, ld, k_, s);
+        launch_sum_slabs<T>(G, slab, nslabs_used, G, ld, k_, s);
         ksplit = 0;   // skip the fp32 rounds below
         POGS_HIP_CHECK(hipMemsetAsync(G + slab, 0, 3 * slab * sizeof(T), s));
       }

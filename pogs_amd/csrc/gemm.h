@@ -69,7 +69,7 @@ void launch_gram_f16(const GramF16Args &g, hipStream_t s);
 // LDS exactly as the matrix cores read it.  launch_gram_f16p then only copies (no staging
 // registers, no LDS stores, no conversion) and multiplies.  npad: a multiple of 128; krows: a
 // multiple of 32; unit u of the launch covers image rows [u kchunk, (u + 1) kchunk), kchunk a
-// multiple of 32, and goes to slab u.
+// multiple of 32 (and of flush_rows), and goes to slab u.
 void launch_split_f16(const float *P, size_t ld, int K, int N, int k0, int krows, int npad, float scale,
                       void *H, void *L, hipStream_t s);
 struct GramF16PArgs {
@@ -79,12 +79,14 @@ struct GramF16PArgs {
   int accumulate;
   const int *tile_map;
   float scale;
+  int tile = 128;                 // workgroup tile: 128 (4 waves) or 256 (8 waves); tile_map must match
+  int flush_rows = 0;             // 128 tile: rows per MFMA chain inside a unit (0: the whole kchunk)
 };
 void launch_gram_f16p(const GramF16PArgs &g, hipStream_t s);
 
 // Lower-triangular tile order in 8 x 8 super-tiles for an n x n Gram product: the ~64
 // workgroups an XCD runs at a time then touch 16 operand panels instead of 65.
-std::vector<int> gram_tile_order(int n);
+std::vector<int> gram_tile_order(int n, int tile = 128);
 
 // A_KMAJ: op(A)(i,k) = A[k*lda + i], else A[i*lda + k].
 // B_KMAJ: op(B)(k,j) = B[k*ldb + j], else B[j*ldb + k].

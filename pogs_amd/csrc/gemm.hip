@@ -597,15 +597,21 @@ __global__ void __launch_bounds__(256) split_f16_kernel(const float *P, size_t l
   L[o] = l;
 }
 
-// 4 waves as 2 x 2, each 64 x 64 (2 x 2 MFMA tiles), one step = 32 image rows.  LDS stage:
-// [operand A/B][part h/l][8-row group 0..3][128 columns] x 16 B = 32 KB, two stages.  A step's 32
-// one-KB lines are copied by the four waves (eight each) with global_load_lds; the copy of step
-// i + 1 is in flight while step i is multiplied.
-__global__ void __launch_bounds__(GT) gram_f16p_kernel(GramF16PArgs g) {
+// WM x WN waves, each TA x TB MFMA tiles of 32 x 32; the workgroup tile is square (TILE = WM TA 32
+// = WN TB 32): 2 x 2 waves of 2 x 2 -> 128, 2 x 4 waves of 4 x 2 -> 256.  One step = 32 image
+// rows.  LDS stage: [operand A/B][part h/l][8-row group 0..3][TILE columns] x 16 B, two stages
+// (64 KB at 128, 128 KB at 256).  A step's one-KB lines are copied by the waves (eight each) with
+// global_load_lds; the copy of step i + 1 is in flight while step i is multiplied.
+template <int WM, int WN, int TA, int TB>
+__global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) gram_f16p_kernel(GramF16PArgs g) {
+  constexpr int TILE = WM * TA * 32;
+  static_assert(TILE == WN * TB * 32, "square workgroup tile");
+  constexpr int QC = TILE / 64;                       // 64-column lines per row group
+  static_assert(2 * 2 * 4 * QC == WM * WN * 8, "eight lines per wave and step");
   extern __shared__ __attribute__((aligned(16))) unsigned char gram_lds[];
-  typedef f16x8 Stage[2][2][4][BM];
+  typedef f16x8 Stage[2][2][4][TILE];
   Stage *sh = reinterpret_cast<Stage *>(gram_lds);
-  const int tm = (g.N + BM - 1) / BM;
+  const int tm = (g.N + TILE - 1) / TILE;
   const int ntiles = tm * (tm + 1) / 2;
   const int nunits = ntiles * g.nslabs;
   const int per_xcd = (nunits + kNumXcd - 1) / kNumXcd;
@@ -623,60 +629,80 @@ __global__ void __launch_bounds__(GT) gram_f16p_kernel(GramF16PArgs g) {
     while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
     tj = tile - ti * (ti + 1) / 2;
   }
-  const int i0 = ti * BM, j0 = tj * BM;
+  const int i0 = ti * TILE, j0 = tj * TILE;
   float *Cout = g.C + static_cast<size_t>(ks) * g.slab_stride;
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave / WN) * (TA * 32), wn = (wave % WN) * (TB * 32);
   const int r32 = lane & 31, kh = lane >> 5;
 
-  floatx16 acc[2][2];
+  floatx16 acc[TA][TB];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int nsteps = g.kchunk / PBK;
   const size_t kg0 = static_cast<size_t>(ks) * (g.kchunk / 8);
-  // line q = wave * 8 + j of a step: operand q >> 4, part (q >> 3) & 1, row group (q >> 1) & 3, column half q & 1
   auto issue = [&](int st, int step) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int q = wave * 8 + j;
-      const int op = q >> 4, part = (q >> 3) & 1, kg = (q >> 1) & 3, half = q & 1;
+      const int cq = q % QC, kg = (q / QC) % 4, part = (q / (QC * 4)) % 2, op = q / (QC * 8);
       const f16x8 *img = reinterpret_cast<const f16x8 *>(part ? g.L : g.H);
-      const f16x8 *src = img + (kg0 + static_cast<size_t>(step) * 4 + kg) * g.npad + (op ? j0 : i0) + half * 64 + lane;
-      f16x8 *dst = &sh[st][op][part][kg][half * 64];
+      const f16x8 *src = img + (kg0 + static_cast<size_t>(step) * 4 + kg) * g.npad + (op ? j0 : i0) + cq * 64 + lane;
+      f16x8 *dst = &sh[st][op][part][kg][cq * 64];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
                                        (__attribute__((address_space(3))) void *)(dst), 16, 0, 0);
     }
   };
   auto compute = [&](int st) {
+    // both k-halves' fragments are requested up front: the second half's reads land while the
+    // first half's products run
+    f16x8 A[2][TA][2], B[2][TB][2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      f16x8 A[2][2], B[2][2];
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          A[a][p] = sh[st][0][p][kk * 2 + kh][wm + a * 32 + r32];
-          B[a][p] = sh[st][1][p][kk * 2 + kh][wn + a * 32 + r32];
-        }
+        for (int a = 0; a < TA; ++a) A[kk][a][p] = sh[st][0][p][kk * 2 + kh][wm + a * 32 + r32];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < TB; ++b) B[kk][b][p] = sh[st][1][p][kk * 2 + kh][wn + b * 32 + r32];
+      }
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
           floatx16 c = acc[a][b];   // small products first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][0], B[b][1], c, 0, 0, 0);   // h l
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][1], B[b][0], c, 0, 0, 0);   // l h
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][0], B[b][0], c, 0, 0, 0);   // h h
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[kk][a][0], B[kk][b][1], c, 0, 0, 0);   // h l
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[kk][a][1], B[kk][b][0], c, 0, 0, 0);   // l h
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[kk][a][0], B[kk][b][0], c, 0, 0, 0);   // h h
           acc[a][b] = c;
         }
-    }
+    __builtin_amdgcn_s_setprio(0);
   };
+  // The MFMA accumulate truncates, so a chain is kept to flush_rows (1024) rows: after that many
+  // the chain's sum is added (IEEE) to a second set of registers and the chain restarts.  Units
+  // can then span several chains and pay their prologue, first-copy latency and the
+  // read-add-write of the C tile once per kchunk rather than once per chain.
+  constexpr bool TWO = TA * TB <= 4;   // the 256 tile has no registers left for a second set
+  floatx16 sum[TWO ? TA : 1][TWO ? TB : 1];
+  if (TWO) {
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int b = 0; b < TB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum[TWO ? a : 0][TWO ? b : 0][r] = 0.f;
+  }
+  const int fsteps = TWO && g.flush_rows > 0 ? g.flush_rows / PBK : nsteps + 1;
+  int until_flush = fsteps;
   if (nsteps > 0) issue(0, 0);
   for (int i = 0; i < nsteps; ++i) {
     // each wave waits for its own lines, the barrier then covers everybody's -- and says that
@@ -685,12 +711,32 @@ __global__ void __launch_bounds__(GT) gram_f16p_kernel(GramF16PArgs g) {
     __syncthreads();
     if (i + 1 < nsteps) issue((i + 1) & 1, i + 1);
     compute(i & 1);
+    if (TWO && --until_flush == 0) {
+      until_flush = fsteps;
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            sum[TWO ? a : 0][TWO ? b : 0][r] += acc[a][b][r];
+            acc[a][b][r] = 0.f;
+          }
+    }
+  }
+  if (TWO) {
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int b = 0; b < TB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] += sum[TWO ? a : 0][TWO ? b : 0][r];
   }
   const float inv2 = 1.0f / (g.scale * g.scale);
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = i0 + wm + a * 32 + (r / 4) * 8 + kh * 4 + (r % 4);
@@ -712,19 +758,26 @@ void launch_split_f16(const float *P, size_t ld, int K, int N, int k0, int krows
                      scale, static_cast<f16x8 *>(H), static_cast<f16x8 *>(L));
 }
 
-void launch_gram_f16p(const GramF16PArgs &g, hipStream_t s) {
-  const int tm = (g.N + BM - 1) / BM;
+template <int WM, int WN, int TA, int TB>
+static void launch_gram_f16p_cfg(const GramF16PArgs &g, hipStream_t s) {
+  constexpr int TILE = WM * TA * 32;
+  const int tm = (g.N + TILE - 1) / TILE;
   const int nunits = tm * (tm + 1) / 2 * g.nslabs;
   if (nunits <= 0) return;
-  constexpr int kLds = 2 * 2 * 2 * 4 * BM * 16;
+  constexpr int kLds = 2 * 2 * 2 * 4 * TILE * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    POGS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_f16p_kernel),
+    POGS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_f16p_kernel<WM, WN, TA, TB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     attr_set = true;
   }
   const int grid = (nunits + kNumXcd - 1) / kNumXcd * kNumXcd;
-  hipLaunchKernelGGL(gram_f16p_kernel, dim3(grid), dim3(GT), kLds, s, g);
+  hipLaunchKernelGGL((gram_f16p_kernel<WM, WN, TA, TB>), dim3(grid), dim3(WM * WN * 64), kLds, s, g);
+}
+
+void launch_gram_f16p(const GramF16PArgs &g, hipStream_t s) {
+  if (g.tile == 256) launch_gram_f16p_cfg<2, 4, 4, 2>(g, s);
+  else launch_gram_f16p_cfg<2, 2, 2, 2>(g, s);
 }
 
 void launch_gram_f16(const GramF16Args &g, hipStream_t s) {
@@ -735,9 +788,9 @@ void launch_gram_f16(const GramF16Args &g, hipStream_t s) {
   hipLaunchKernelGGL(gram_f16_kernel, dim3(grid), dim3(GT), 0, s, g);
 }
 
-std::vector<int> gram_tile_order(int n) {
+std::vector<int> gram_tile_order(int n, int tile) {
   constexpr int G = 8;
-  const int tm = (n + BM - 1) / BM;
+  const int tm = (n + tile - 1) / tile;
   std::vector<int> order;
   order.reserve(static_cast<size_t>(tm) * (tm + 1) / 2);
   const int sm = (tm + G - 1) / G;
