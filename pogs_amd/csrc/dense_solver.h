@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <thread>
 
 #include "cg_kernels.h"
 #include "engine.h"
@@ -95,6 +96,25 @@ class DenseSolver final : public SolverBase {
   DenseSolver(int ord, size_t m, size_t n, const void *A, int mem, const PogsAmdOptions *opt,
               const PogsAmdDist *dist) {
     const double t0 = wall_s();
+    // The first launch of a kernel of this translation unit makes the runtime load its code
+    // object (~4 MB, ~13 ms, once per process).  A helper thread asks for a kernel's attributes
+    // right away, so that load overlaps the stream creation and the upload of A instead of
+    // sitting in front of the first pass.  (POGS_AMD_PRELOAD=0: off.)
+    struct Joiner {
+      std::thread t;
+      ~Joiner() { if (t.joinable()) t.join(); }
+    } preload;
+    {
+      const char *pe = std::getenv("POGS_AMD_PRELOAD");
+      int dev = opt ? opt->device : -1;
+      if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = -1;
+      if (!(pe && pe[0] == '0') && dev >= 0)
+        preload.t = std::thread([dev] {
+          hipFuncAttributes fa;
+          if (hipSetDevice(dev) == hipSuccess)
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(scale_all_kernel<T>));
+        });
+    }
     ctx_.init(opt ? opt->device : -1, opt ? opt->profile != 0 : false);
     m_ = static_cast<int>(m);
     n_ = static_cast<int>(n);
