@@ -483,6 +483,10 @@ class DenseSolver final : public SolverBase {
     }
   }
 
+  static bool w_onepass() {   // POGS_AMD_WPASS=2: the two triangular products W, U of the reference's two trsv
+    static const bool on = [] { const char *e = std::getenv("POGS_AMD_WPASS"); return !(e && e[0] == '2'); }();
+    return on;
+  }
   static bool defer_allowed() {   // POGS_AMD_DEFER=0: one launch per sum, as on row shards
     static const bool on = [] { const char *e = std::getenv("POGS_AMD_DEFER"); return !(e && e[0] == '0'); }();
     return on;
@@ -917,6 +921,28 @@ class DenseSolver final : public SolverBase {
     }
   }
 
+  // The same solve for the x update of the one-pass iteration, as ONE sweep over W = L^-1:
+  // x = W^T (W (rhs + add)) -- the row dot t_i = W_i . r is handed back as the coefficient of row
+  // i in the column sums of the very pass that computed it (DOT + ACC on the lower triangle, like
+  // the symmetric product of the norm estimate), and the projection tail runs as the column
+  // functor of the second stage.  200 MB instead of 400 MB per iteration at C2; U is not read.
+  void solve_gram_onepass(const T *rhs, const T *add, const ProjTailSumColOp<T> &tail, double *tail_scalars) {
+    hipStream_t s = ctx_.stream;
+    StreamArgs<T> a;
+    a.A = Wp_; a.lda = k_pad_; a.m = k_; a.n_pad = k_pad_;
+    a.xin = rhs; a.xin_add = add; a.xin_nrm2 = nullptr;
+    a.col_partials = colpart_.p;   // free here: its sums were reduced into rhs before the solve
+    a.scalar_partials = ctx_.spart.p;
+    a.xl_scratch = xl_buf_.p;
+    launch_stream<T, true, true, false, kLower>(planW_, a, IdentRowOp<T>{}, s);
+    double *sp = ctx_.spart.p + sp_tail_off_;
+    launch_reduce_cols<T, ProjTailSumColOp<T>>(colpart_.p, stream_grid<true, true>(planW_, k_), k_pad_, tail, sp, s);
+    if (tail_scalars) {
+      SumJob j{sp, reduce_cols_grid(k_pad_, Vec16<T>::N), 2, tail_scalars};
+      sum_now_or_later(j);
+    }
+  }
+
   // ProjectorCgls::Project on the dense operator up to (not including) the final y = A x
   // (projector_cgls.cpp:59-75, cgls.h:200-323).  x: warm start in, projected x out.
   // Ax_warm: A times the warm start if the caller has it (inside the ADMM loop it is the
@@ -1106,7 +1132,11 @@ class DenseSolver final : public SolverBase {
       // (2) projection: x = (G + I)^{-1} (xtemp + A^T ytemp), y = A x   (projector_direct_dense.cpp:122-127)
       gemv_t_partials(ytemp_.p);
       finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, kGapY, 3);   // with shards: gap/norm sums ride along
-      solve_gram(rhs_.p, xtemp_.p, ProjTailOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p}, ctx_.S.p + kDXprev2);
+      if (w_onepass())
+        solve_gram_onepass(rhs_.p, xtemp_.p, ProjTailSumColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_},
+                           ctx_.S.p + kDXprev2);
+      else
+        solve_gram(rhs_.p, xtemp_.p, ProjTailOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p}, ctx_.S.p + kDXprev2);
       StreamArgs<T> a = argsA();
       a.xin = x_[nw].p;
       ctx_.stream_timer.begin(s);
@@ -1250,7 +1280,11 @@ class DenseSolver final : public SolverBase {
       SumJob j{sp, reduce_cols_grid(n_pad_, Vec16<T>::N), 1, ctx_.S.p + kExactS2};
       launch_sum_jobs(&j, 1, s);
     }
-    solve_gram(rhs_.p, xtemp_.p, ProjTailOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p}, ctx_.S.p + kDXprev2);
+    if (w_onepass())
+      solve_gram_onepass(rhs_.p, xtemp_.p, ProjTailSumColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_},
+                         ctx_.S.p + kDXprev2);
+    else
+      solve_gram(rhs_.p, xtemp_.p, ProjTailOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p}, ctx_.S.p + kDXprev2);
     // (D) the pass over A
     {
       StreamArgs2<T> a2{A_.p, lda_, m_, n_pad_, x_[nw].p, x12_.p, colpart_.p, colpart2_.p, ctx_.spart.p};

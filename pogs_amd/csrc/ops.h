@@ -182,6 +182,35 @@ struct ProjTailOp {
   __device__ __forceinline__ T u(int) const { return 0; }
 };
 
+// t_i = dot, handed straight back as the coefficient of row i for the column sums of the same
+// pass: x = W^T (W r) in one sweep over the triangular factor inverse.
+template <typename T>
+struct IdentRowOp {
+  static constexpr int NS = 0;
+  template <int N>
+  __device__ __forceinline__ T row(int, T dot, double (&)[N]) const { return dot; }
+  __device__ __forceinline__ T u(int) const { return 0; }
+};
+
+// ProjTailOp as the second stage of a column-sum pass (znew_j = total).
+template <typename T>
+struct ProjTailSumColOp {
+  static constexpr int NS = 2;
+  T *znew;
+  const T *zprev, *z12;
+  T *ztemp;
+  int n;
+  template <int N>
+  __device__ __forceinline__ void col(int j, T total, double (&s)[N]) const {
+    if (j >= n) return;
+    znew[j] = total;
+    const T a = zprev[j] - total, b = z12[j] - total;
+    s[0] += static_cast<double>(a) * a;
+    s[1] += static_cast<double>(b) * b;
+    ztemp[j] -= total;
+  }
+};
+
 // Exact residuals in one pass (pogs.cpp:352-376):
 //   r_i = (A x12)_i - y12_i, s0 += r_i^2;  returns y12_i + c yt_i - yprev_i, whose
 //   A^T-image the pass accumulates.
