@@ -926,7 +926,8 @@ class DenseSolver final : public SolverBase {
   // i in the column sums of the very pass that computed it (DOT + ACC on the lower triangle, like
   // the symmetric product of the norm estimate), and the projection tail runs as the column
   // functor of the second stage.  200 MB instead of 400 MB per iteration at C2; U is not read.
-  void solve_gram_onepass(const T *rhs, const T *add, const ProjTailSumColOp<T> &tail, double *tail_scalars) {
+  template <typename TailColOp>
+  void solve_gram_onepass(const T *rhs, const T *add, const TailColOp &tail, double *tail_scalars) {
     hipStream_t s = ctx_.stream;
     StreamArgs<T> a;
     a.A = Wp_; a.lda = k_pad_; a.m = k_; a.n_pad = k_pad_;
@@ -936,9 +937,9 @@ class DenseSolver final : public SolverBase {
     a.xl_scratch = xl_buf_.p;
     launch_stream<T, true, true, false, kLower>(planW_, a, IdentRowOp<T>{}, s);
     double *sp = ctx_.spart.p + sp_tail_off_;
-    launch_reduce_cols<T, ProjTailSumColOp<T>>(colpart_.p, stream_grid<true, true>(planW_, k_), k_pad_, tail, sp, s);
-    if (tail_scalars) {
-      SumJob j{sp, reduce_cols_grid(k_pad_, Vec16<T>::N), 2, tail_scalars};
+    launch_reduce_cols<T, TailColOp>(colpart_.p, stream_grid<true, true>(planW_, k_), k_pad_, tail, sp, s);
+    if (TailColOp::NS > 0 && tail_scalars) {
+      SumJob j{sp, reduce_cols_grid(k_pad_, Vec16<T>::N), TailColOp::NS, tail_scalars};
       sum_now_or_later(j);
     }
   }
@@ -1148,8 +1149,13 @@ class DenseSolver final : public SolverBase {
     } else {
       // (2') m <= n: t = (A A^T + I)^{-1} (A xtemp - ytemp); x = xtemp - A^T t; y = ytemp + t   (:128-135)
       t_mul_n(xtemp_.p, nullptr, ResidOp<T>{ytemp_.p, rhs_.p}, nullptr);
-      solve_gram(rhs_.p, static_cast<const T *>(nullptr),
-                 ProjTailAddOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p}, ctx_.S.p + kDYprev2);
+      if (w_onepass())
+        solve_gram_onepass(rhs_.p, static_cast<const T *>(nullptr),
+                           ProjTailAddColOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p, m_},
+                           ctx_.S.p + kDYprev2);
+      else
+        solve_gram(rhs_.p, static_cast<const T *>(nullptr),
+                   ProjTailAddOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p}, ctx_.S.p + kDYprev2);
       t_mul_t(tmpn_.p, ProjTailColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_}, ctx_.S.p + kDXprev2);
     }
     if (!use_cgls_) ctx_.stats.matvecs += 2;
@@ -1413,8 +1419,12 @@ class DenseSolver final : public SolverBase {
       SumJob j{sp, reduce_cols_grid(scols_pad_, Vec16<T>::N), 1, ctx_.S.p + kExactR2};
       launch_sum_jobs(&j, 1, s);
     }
-    solve_gram(rhs_.p, static_cast<const T *>(nullptr),
-               ProjTailAddOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p}, ctx_.S.p + kDYprev2);
+    if (w_onepass())
+      solve_gram_onepass(rhs_.p, static_cast<const T *>(nullptr),
+                         ProjTailAddColOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p, m_}, ctx_.S.p + kDYprev2);
+    else
+      solve_gram(rhs_.p, static_cast<const T *>(nullptr),
+                 ProjTailAddOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p}, ctx_.S.p + kDYprev2);
     // (D) the pass over T
     {
       StreamArgs2<T> a2{A_.p, lda_, srows_, scols_pad_, tmpn_.p, uvec_.p, colpart_.p, colpart2_.p, ctx_.spart.p};

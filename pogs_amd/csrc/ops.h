@@ -267,6 +267,28 @@ struct ProjTailAddOp {
   __device__ __forceinline__ T u(int) const { return 0; }
 };
 
+// ProjTailAddOp as the second stage of a column-sum pass.
+template <typename T>
+struct ProjTailAddColOp {
+  static constexpr int NS = 2;
+  T *znew;
+  const T *zprev, *z12;
+  T *ztemp;
+  T *tout;
+  int n;
+  template <int N>
+  __device__ __forceinline__ void col(int j, T total, double (&s)[N]) const {
+    if (j >= n) return;
+    const T zn = ztemp[j] + total;
+    tout[j] = total;
+    znew[j] = zn;
+    const T a = zprev[j] - zn, b = z12[j] - zn;
+    s[0] += static_cast<double>(a) * a;
+    s[1] += static_cast<double>(b) * b;
+    ztemp[j] -= zn;
+  }
+};
+
 // Power iteration on the Gram matrix stored as its lower triangle (strict upper part
 // zero): one DOT+ACC pass gives L x (dot) and L^T x (column sums); G x = L x + L^T x - D x.
 // x is held un-normalised; sc = 1/|x| comes from the device scalar written by the
