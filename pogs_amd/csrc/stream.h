@@ -204,7 +204,9 @@ __global__ void __launch_bounds__(TPB) stream_rows_kernel(StreamArgs<T> a, Op op
         if (TRI == kLower) ok = ok && (col <= row);
         if (TRI == kUpper) ok = ok && (col + VEC - 1 >= row);
         V val = dev::vzero<V>();
-        if (ok) val = stream_load<V>(rp + col);
+        // the pass over A is read once per iteration (non-temporal); a triangular factor is 1/20
+        // of that and comes back every iteration: plain loads, so it may stay in the Infinity Cache
+        if (ok) val = (TRI == kFull) ? stream_load<V>(rp + col) : *reinterpret_cast<const V *>(rp + col);
         av[r][v] = SQ ? dev::vsq(val) : val;
       }
     }
