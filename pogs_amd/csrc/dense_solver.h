@@ -523,49 +523,77 @@ class DenseSolver final : public SolverBase {
     const int gridBOTH = stream_grid<true, true>(planA_, srows_);
     StreamArgs<T> a = argsA();
     ctx_.tmark("  eq: start");
-    // The reference runs a fixed 50 iterations (equil_helper.h:147).  Once a whole iteration moves
-    // no entry of the scaling vector by more than 8 ulp the remaining ones reproduce the same
-    // numbers, so they are skipped (POGS_AMD_SK_FULL=1 keeps all 50); matrices on which the
-    // iteration keeps drifting simply run the full count.
+    // The reference runs a fixed 50 iterations (equil_helper.h:147).  After a few of them the only
+    // thing that still moves is the common factor (d * a, e / a) -- the unregularised iteration
+    // does not fix it, and the two regularisers pull it towards its fixed point at a rate of
+    // ~1e-8 per iteration -- so every entry of the scaling vector changes by the same ratio
+    // 1 + gamma (~1e-6).  The column functor measures that ratio (mean over the entries, in double)
+    // and stamps the pass if any entry deviates from the previous pass's mean by more than 16 ulp;
+    // the first pass without a stamp ends the loop, and the remaining iterations are applied in
+    // closed form: the newer vector times (1 + gamma)^r, the other one divided by it.  fp32 only
+    // (in fp64 the change of gamma itself over 50 iterations would show); POGS_AMD_SK_FULL=1 runs
+    // all 50 passes.
     const char *sk_env = std::getenv("POGS_AMD_SK_FULL");
-    const bool sk_full = sk_env && sk_env[0] == '1';
-    double *mark = sk_full ? nullptr : ctx_.S.p + kSkMark;
-    const T sk_tol = 8 * std::numeric_limits<T>::epsilon();
-    auto sk_stationary = [&](int k) {
-      if (!mark || k < 2) return false;
-      return ctx_.fetch_scalars()[kSkMark] < k + 1.0;
+    const bool sk_probe = std::is_same<T, float>::value && !(sk_env && sk_env[0] == '1');
+    double *mark = sk_probe ? ctx_.S.p + kSkMark : nullptr;
+    const T sk_tol = 16 * std::numeric_limits<T>::epsilon();
+    double r_ref = 0, gamma = 0;
+    bool extrapolate = false;
+    // after pass k (0-based): true if it was a pure common-factor pass; keeps r_ref current
+    auto sk_uniform = [&](int k, int count) {
+      if (!mark || k < 1) return false;
+      const double *S = ctx_.fetch_scalars();
+      const double r_mean = S[kSkRatio] / count;
+      const bool uniform = k >= 2 && S[kSkMark] < k + 1.0 && r_mean > 0.5 && r_mean < 2.0;
+      r_ref = r_mean;
+      gamma = r_mean - 1.0;
+      return uniform;
     };
+    int k = 0;
     if (tmode_) {
       // stored rows are the columns of A: one fused pass per iteration, the row dot (with d) gives
       // e_j, the column sums (weighted by e_j) give d   (equil_helper.h:149-163, d = 1 to start)
       double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
       launch_fill<T>(d_.p, static_cast<T>(1), m_, s);
-      int k = 0;
       for (; k < 50; ++k) {
         a.xin = d_.p;
         launch_stream<T, true, true, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(mg), ce, e_.p}, s);
-        launch_reduce_cols<T, SkColOp<T>>(colpart_.p, gridBOTH, scols_pad_,
-                                          SkColOp<T>{static_cast<T>(nn), cd, d_.p, m_, mark, k + 1.0, sk_tol}, sp, s);
-        if (sk_stationary(k)) { ++k; break; }
+        launch_reduce_cols<T, SkColOp<T>>(
+            colpart_.p, gridBOTH, scols_pad_,
+            SkColOp<T>{static_cast<T>(nn), cd, d_.p, m_, mark, k + 1.0, sk_tol, static_cast<T>(r_ref)}, sp, s);
+        SumJob j{sp, reduce_cols_grid(scols_pad_, Vec16<T>::N), 1, ctx_.S.p + kSkRatio};
+        launch_sum_jobs(&j, 1, s);
+        if (sk_uniform(k, m_)) { extrapolate = true; ++k; break; }
       }
       ctx_.stats.matvecs_init += k;
+      if (extrapolate) {
+        // state (e_{k-1}, d_k) after k passes; the reference ends with (e_49, d_50)
+        const double f = std::pow(1.0 + gamma, 50 - k);
+        launch_scal<T>(d_.p, static_cast<T>(f), m_, s);
+        launch_scal<T>(e_.p, static_cast<T>(1.0 / f), n_, s);
+      }
     } else {
       launch_stream<T, false, true, true, kFull>(planA_, a, OnesOp<T>{}, s);
       ctx_.tmark("  eq: first pass");
       finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_}, nullptr, 0, 0, gridACC);
       ctx_.tmark("  eq: first cols");
-      int k = 0;
       for (; k < 50; ++k) {
         a.xin = e_.p;
         if (k < 49) {
           launch_stream<T, true, true, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
-          finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_, mark, k + 1.0, sk_tol}, nullptr, 0, 0, gridBOTH);
-          if (sk_stationary(k)) { ++k; break; }
+          finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_, mark, k + 1.0, sk_tol, static_cast<T>(r_ref)},
+                      ctx_.S.p + kSkRatio, 0, 0, gridBOTH);
+          if (sk_uniform(k, n_)) { extrapolate = true; ++k; break; }
         } else {
           launch_stream<T, true, false, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
         }
       }
       ctx_.stats.matvecs_init += k + 1;
+      if (extrapolate) {
+        // state (d_k, e_k) after k loop passes; the reference ends with (d_50, e_49)
+        launch_scal<T>(d_.p, static_cast<T>(std::pow(1.0 + gamma, -(50 - k))), m_, s);
+        launch_scal<T>(e_.p, static_cast<T>(std::pow(1.0 + gamma, 49 - k)), n_, s);
+      }
     }
     ctx_.tmark("  eq: sk loop");
     launch_sqrt_inplace<T>(d_.p, m_, s);                                  // matrix_dense.cpp:176-177

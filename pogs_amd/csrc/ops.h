@@ -482,24 +482,28 @@ struct StoreColOp {
 };
 
 // Sinkhorn-Knopp column step: e_j = m / ((A.^2)^T d)_j + c)  (equil_helper.h:149-155)
+// Probe: the ratio new / old of every entry is summed (s[0], its mean is the common growth factor
+// of this iteration), and an entry whose ratio is further than tol (relative) from r_ref -- the
+// mean of the previous iteration -- stamps *mark with the number of the pass (every writer stores
+// the same value).  A pass that leaves no stamp moved the whole vector by one common factor.
 template <typename T>
 struct SkColOp {
-  static constexpr int NS = 0;
+  static constexpr int NS = 1;
   T mm, c;
   T *e;
   int n;
-  // stationarity probe: an entry that moved by more than tol (relative) stamps *mark with the
-  // number of the pass (every writer stores the same value); the host stops the iteration once
-  // a pass leaves no stamp
   double *mark = nullptr;
   double stamp = 0;
   T tol = 0;
+  T r_ref = 0;
   template <int N>
-  __device__ __forceinline__ void col(int j, T total, double (&)[N]) const {
+  __device__ __forceinline__ void col(int j, T total, double (&s)[N]) const {
     const T v = (j < n) ? mm / (total + c) : static_cast<T>(0);
-    if (mark) {
+    if (j < n) {
       const T old = e[j];
-      if (!(fabs(v - old) <= tol * fabs(v))) *mark = stamp;
+      const T r = old > static_cast<T>(0) ? v / old : static_cast<T>(0);
+      s[0] += static_cast<double>(r);
+      if (mark && !(fabs(r - r_ref) <= tol * r_ref)) *mark = stamp;
     }
     e[j] = v;
   }

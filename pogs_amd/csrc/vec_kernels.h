@@ -16,11 +16,12 @@ namespace pogs_amd {
 enum Slot : int {
   kGapY = 0, kWY2, kHY2, kDYprev2, kDY12, kExactR2, kPowSx2, kFro2, kFvalF, kCgQ2,
   kAmax = 10,   // max |entry| of the scaled matrix before the Frobenius normalisation (local shard)
-  kSkMark = 11, // last Sinkhorn-Knopp pass that still moved an entry of the scaling vector
+  kSkMark = 11, // last Sinkhorn-Knopp pass in which an entry left the common growth factor
   kGapX = 12, kWX2, kHX2, kDXprev2, kDX12, kExactS2, kPowX2, kPowXGx, kFvalG, kCgP2, kCgS2, kCgX2,
   kSpecGapY = 26, kSpecWY2, kSpecHY2,   // next iteration's y-half sums from the one-pass kernel
   kSpecGapX = 29, kSpecWX2, kSpecHX2,   // ... x-half sums (m <= n, transposed storage)
-  kNumSlots = 32
+  kSkRatio = 32,   // sum over the entries of (new / old) of a Sinkhorn-Knopp pass
+  kNumSlots = 40
 };
 
 template <typename T>

@@ -176,9 +176,10 @@ def test_c3_dense_logistic_200000x5000_kkt():
 
 
 def test_c2_sinkhorn_knopp_early_exit_matches_full_count(monkeypatch):
-    """configs[1] shape: the stationarity probe ends the Sinkhorn-Knopp loop after a few passes; the
-    47 skipped iterations of the reference would only have moved the common factor (d * a, e / a) by
-    a few 1e-6, which D A E does not see.  Same iteration count and solution as the full count."""
+    """configs[1] shape: the Sinkhorn-Knopp loop ends after a few passes, once a pass changes every
+    entry by one common ratio; the iterations the reference would still run only move the common
+    factor (d * a, e / a) and are applied in closed form.  Same d, e, iteration count and solution
+    as the full 50 passes."""
     torch = _torch()
     pogs = _pogs()
     m, n = 100000, 10000
@@ -202,7 +203,7 @@ def test_c2_sinkhorn_knopp_early_exit_matches_full_count(monkeypatch):
     d1, e1, n1, r1, p1 = got["full"]
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
     assert p0 < p1 and p0 <= 12
-    assert rel(d0, d1) < 2e-5 and rel(e0, e1) < 2e-5
+    assert rel(d0, d1) < 3e-6 and rel(e0, e1) < 3e-6
     assert rel(np.outer(d0[:100], e0[:100]), np.outer(d1[:100], e1[:100])) < 1e-6
     assert n0 == pytest.approx(n1, rel=1e-5)
     assert r0["status"] == r1["status"] == 0
