@@ -738,6 +738,45 @@ def test_degenerate_inputs_behave_like_the_reference_algorithm():
             assert relerr(got["x"], want["x"]) < 1e-6, tag
 
 
+def test_degenerate_inputs_fp32_with_equilibration_shortcut():
+    """The same kind of inputs in fp32, where the Sinkhorn-Knopp loop ends at the common-factor stage
+    (zero rows / columns keep their ratio at exactly 1, a NaN never lets the probe fire, a huge
+    dynamic range delays it): status and iteration count of the oracle, same finite pattern."""
+    pogs = _pogs()
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((600, 300))
+    An = A.copy()
+    An[3, 4] = np.nan
+    Az = A.copy()
+    Az[:, 7] = 0
+    Az[11, :] = 0
+    Wz = rng.standard_normal((200, 900))
+    Wz[:, 5] = 0
+    Wz[3, :] = 0
+    cases = [
+        ("zero tall", np.zeros((50, 20)), 2500, None),
+        ("zero wide", np.zeros((20, 50)), 2500, None),
+        ("nan entry", An, 50, None),
+        ("zero row and column, tall", Az, 2500, 1e-4),
+        ("zero row and column, wide", Wz, 2500, 1e-4),
+        ("rank one", np.outer(rng.standard_normal(800), rng.standard_normal(250)), 2500, 1e-2),
+        ("duplicate columns", np.hstack([A, A]), 2500, 1e-4),
+        ("sixteen decades of row / column scales",
+         A * np.exp(rng.uniform(-8, 8, (600, 1))) * np.exp(rng.uniform(-8, 8, (1, 300))), 2500, 1e-3),
+    ]
+    for tag, M, max_iter, tol in cases:
+        m, n = M.shape
+        b = rng.standard_normal(m)
+        f, g = pogs.graph.lasso_functions(b, 0.1, n)
+        got = pogs.graph._solve_graph_form(M, f, g, 1e-4, 1e-4, max_iter, 0, 1.0, dtype=np.float32)
+        want = ob.oracle_solve(M, soa(f), soa(g), dtype=np.float32, max_iter=max_iter)
+        assert got["status"] == want["status"], tag
+        assert abs(int(got["iterations"]) - int(want["iterations"])) <= max(1, int(want["iterations"]) // 50), tag
+        assert np.array_equal(np.isfinite(got["x"]), np.isfinite(want["x"])), tag
+        if tol is not None:
+            assert relerr(got["x"], want["x"]) < tol, tag
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(16700, 16500), (16450, 16900)])
 def test_rows_wider_than_one_register_tile_fp64(shape):
