@@ -84,20 +84,22 @@ struct SpAxpbyNormOp {  // y[i] = alpha * dot + beta * yin[i]; s0 += y[i]^2
 
 template <typename T>
 struct SpSkOp {  // out[i] = num / (dot + c)   (equil_helper.h:149-162)
-  static constexpr int NS = 0;
+  static constexpr int NS = 1;
   T num, c;
   T *out;
-  // stationarity probe, see SkColOp in ops.h
+  // common-factor probe, see SkColOp in ops.h: sums new / old, stamps *mark when an entry's ratio
+  // leaves r_ref by more than tol
   double *mark = nullptr;
   double stamp = 0;
   T tol = 0;
+  T r_ref = 0;
   template <int N>
-  __device__ __forceinline__ void row(int i, T dot, double (&)[N]) const {
+  __device__ __forceinline__ void row(int i, T dot, double (&s)[N]) const {
     const T v = num / (dot + c);
-    if (mark) {
-      const T old = out[i];
-      if (!(fabs(v - old) <= tol * fabs(v))) *mark = stamp;
-    }
+    const T old = out[i];
+    const T r = old > static_cast<T>(0) ? v / old : static_cast<T>(0);
+    s[0] += static_cast<double>(r);
+    if (mark && !(fabs(r - r_ref) <= tol * r_ref)) *mark = stamp;
     out[i] = v;
   }
 };
@@ -1057,19 +1059,37 @@ class SparseSolver final : public SolverBase {
     const T cd = static_cast<T>(1e-4) * static_cast<T>(mg + nn) / static_cast<T>(nn);
     launch_fill<T>(d_.p, static_cast<T>(1), m_, s);
     launch_fill<T>(e_.p, static_cast<T>(1), n_, s);
-    // 50 iterations in the reference (equil_helper.h:147); an iteration that moves no entry of e
-    // (replicated, so every rank of a sharded solve sees the same stamp) by more than 8 ulp ends
-    // the loop after its d update -- see DenseSolver::equilibrate.  POGS_AMD_SK_FULL=1: all 50.
+    // 50 iterations in the reference (equil_helper.h:147).  As in DenseSolver::equilibrate (fp32):
+    // once an iteration changes every entry of e (replicated, so the ranks of a sharded solve
+    // agree) by one common ratio 1 + gamma -- the slow drift of the common factor (d * a, e / a)
+    // -- the loop ends after its d update and the remaining iterations are applied in closed
+    // form.  POGS_AMD_SK_FULL=1: all 50.
     const char *sk_env = std::getenv("POGS_AMD_SK_FULL");
-    const bool sk_full = sk_env && sk_env[0] == '1';
-    double *mark = sk_full ? nullptr : ctx_.S.p + kSkMark;
-    const T sk_tol = 8 * std::numeric_limits<T>::epsilon();
+    const bool sk_probe = std::is_same<T, float>::value && !(sk_env && sk_env[0] == '1');
+    double *mark = sk_probe ? ctx_.S.p + kSkMark : nullptr;
+    const T sk_tol = 16 * std::numeric_limits<T>::epsilon();
+    double r_ref = 0, gamma = 0;
+    bool extrapolate = false;
     int k = 0;
     while (k < 50) {
-      spmv_t<true>(d_.p, SpSkOp<T>{static_cast<T>(mg), ce, e_.p, mark, k + 1.0, sk_tol}, nullptr);
+      spmv_t<true>(d_.p, SpSkOp<T>{static_cast<T>(mg), ce, e_.p, mark, k + 1.0, sk_tol, static_cast<T>(r_ref)},
+                   ctx_.S.p + kSkRatio);
       spmv<true>(A_, e_.p, nullptr, SpSkOp<T>{static_cast<T>(nn), cd, d_.p}, nullptr, 0);
       ++k;
-      if (mark && k >= 3 && ctx_.fetch_scalars()[kSkMark] < static_cast<double>(k)) break;
+      if (mark && k >= 2) {
+        const double *S = ctx_.fetch_scalars();
+        const double r_mean = S[kSkRatio] / n_;
+        const bool uniform = k >= 3 && S[kSkMark] < static_cast<double>(k) && r_mean > 0.5 && r_mean < 2.0;
+        r_ref = r_mean;
+        gamma = r_mean - 1.0;
+        if (uniform) { extrapolate = true; break; }
+      }
+    }
+    if (extrapolate) {
+      // state (e_{k-1}, d_k) after k iterations; the reference ends with (e_49, d_50)
+      const double f = std::pow(1.0 + gamma, 50 - k);
+      launch_scal<T>(e_.p, static_cast<T>(f), n_, s);
+      launch_scal<T>(d_.p, static_cast<T>(1.0 / f), m_, s);
     }
     ctx_.stats.matvecs_init += 2 * k;
     launch_sqrt_inplace<T>(d_.p, m_, s);
