@@ -528,17 +528,19 @@ class DenseSolver final : public SolverBase {
     // does not fix it, and the two regularisers pull it towards its fixed point at a rate of
     // ~1e-8 per iteration -- so every entry of the scaling vector changes by the same ratio
     // 1 + gamma (~1e-6).  The column functor measures that ratio (mean over the entries, in double)
-    // and stamps the pass if any entry deviates from the previous pass's mean by more than 16 ulp;
-    // the first pass without a stamp ends the loop, and the remaining iterations are applied in
-    // closed form: the newer vector times (1 + gamma)^r, the other one divided by it.  fp32 only
-    // (in fp64 the change of gamma itself over 50 iterations would show); POGS_AMD_SK_FULL=1 runs
-    // all 50 passes.
+    // and stamps the pass if any entry deviates from the previous pass's mean by more than 16 ulp
+    // (fp64: 64 ulp = 1.4e-14, where the entries' own drift rates differ by a few 1e-15);
+    // the first pass without a stamp (fp64: the second in a row) ends the loop, and the remaining
+    // iterations are applied in closed form: the newer vector times the product of the growth
+    // factors still to come, the other one divided by the matching product.
+    // POGS_AMD_SK_FULL=1 runs all 50 passes.
     const char *sk_env = std::getenv("POGS_AMD_SK_FULL");
-    const bool sk_probe = std::is_same<T, float>::value && !(sk_env && sk_env[0] == '1');
+    const bool sk_probe = !(sk_env && sk_env[0] == '1');
     double *mark = sk_probe ? ctx_.S.p + kSkMark : nullptr;
-    const T sk_tol = 16 * std::numeric_limits<T>::epsilon();
-    double r_ref = 0, gamma = 0;
-    bool extrapolate = false;
+    const char *sk_ulps = std::getenv("POGS_AMD_SK_ULPS");   // tuning aid
+    const T sk_tol = (sk_ulps ? std::atoi(sk_ulps) : (std::is_same<T, float>::value ? 16 : 64)) * std::numeric_limits<T>::epsilon();
+    double r_ref = 0, gamma = 0, gamma_prev = 0;
+    bool extrapolate = false, was_uniform = false;
     // after pass k (0-based): true if it was a pure common-factor pass; keeps r_ref current
     auto sk_uniform = [&](int k, int count) {
       if (!mark || k < 1) return false;
@@ -546,8 +548,29 @@ class DenseSolver final : public SolverBase {
       const double r_mean = S[kSkRatio] / count;
       const bool uniform = k >= 2 && S[kSkMark] < k + 1.0 && r_mean > 0.5 && r_mean < 2.0;
       r_ref = r_mean;
+      gamma_prev = gamma;
       gamma = r_mean - 1.0;
-      return uniform;
+      // fp64 also uses the previous pass's gamma (below), so that one has to be clean as well
+      if (std::getenv("POGS_AMD_TRACE"))
+        std::fprintf(stderr, "[pogs_amd trace]   sk pass %d: gamma %.6e, %s\n", k, r_mean - 1.0, uniform ? "uniform" : "stamped");
+      const bool fire = uniform && (std::is_same<T, float>::value || was_uniform);
+      was_uniform = uniform;
+      return fire;
+    };
+    // log of the product of the next `count` growth factors, the first of which is
+    // (1 + gamma q^first).  In fp32 gamma is taken as constant (its own change over 50 iterations,
+    // ~1e-6 relative, is far below fp32 resolution); in fp64 it is not: the drift slows down
+    // geometrically as the common factor approaches its fixed point, and the ratio q of two
+    // consecutive measurements carries that (second-order terms are ~1e-14).
+    auto sk_log_growth = [&](int first, int count) {
+      double q = 1.0;
+      if (std::is_same<T, double>::value && gamma != 0 && gamma_prev != 0) {
+        q = gamma / gamma_prev;
+        if (!(q > 0.999 && q < 1.001)) q = 1.0;
+      }
+      double L = 0, gi = gamma * std::pow(q, first);
+      for (int i = 0; i < count; ++i, gi *= q) L += std::log1p(gi);
+      return L;
     };
     int k = 0;
     if (tmode_) {
@@ -567,10 +590,12 @@ class DenseSolver final : public SolverBase {
       }
       ctx_.stats.matvecs_init += k;
       if (extrapolate) {
-        // state (e_{k-1}, d_k) after k passes; the reference ends with (e_49, d_50)
-        const double f = std::pow(1.0 + gamma, 50 - k);
-        launch_scal<T>(d_.p, static_cast<T>(f), m_, s);
-        launch_scal<T>(e_.p, static_cast<T>(1.0 / f), n_, s);
+        // state (e_{k-1}, d_k) after k passes, gamma measured on d_k / d_{k-1}; the reference ends
+        // with (e_49, d_50): d_50 = d_k prod_{i=1..50-k} (1 + gamma_i), e_49 = f(d_49) = e_{k-1} d_{k-1} / d_49
+        const double Ld = sk_log_growth(1, 50 - k);
+        const double Le = -sk_log_growth(0, 50 - k);
+        launch_scal<T>(d_.p, static_cast<T>(std::exp(Ld)), m_, s);
+        launch_scal<T>(e_.p, static_cast<T>(std::exp(Le)), n_, s);
       }
     } else {
       launch_stream<T, false, true, true, kFull>(planA_, a, OnesOp<T>{}, s);
@@ -590,9 +615,12 @@ class DenseSolver final : public SolverBase {
       }
       ctx_.stats.matvecs_init += k + 1;
       if (extrapolate) {
-        // state (d_k, e_k) after k loop passes; the reference ends with (d_50, e_49)
-        launch_scal<T>(d_.p, static_cast<T>(std::pow(1.0 + gamma, -(50 - k))), m_, s);
-        launch_scal<T>(e_.p, static_cast<T>(std::pow(1.0 + gamma, 49 - k)), n_, s);
+        // state (d_k, e_k) after k loop passes, gamma measured on e_k / e_{k-1}; the reference ends
+        // with (d_50, e_49): e_49 = e_k prod_{i=1..49-k} (1 + gamma_i), d_50 = g(e_49) = d_k e_{k-1} / e_49
+        const double Le = sk_log_growth(1, 49 - k);
+        const double Ld = -sk_log_growth(0, 50 - k);
+        launch_scal<T>(d_.p, static_cast<T>(std::exp(Ld)), m_, s);
+        launch_scal<T>(e_.p, static_cast<T>(std::exp(Le)), n_, s);
       }
     }
     ctx_.tmark("  eq: sk loop");

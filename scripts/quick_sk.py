@@ -8,13 +8,16 @@ from pogs_amd import graph as G
 import bench
 
 m, n = 100000, 10000
+DT = np.float64 if (len(sys.argv) > 1 and sys.argv[1] == "f64") else np.float32
+TDT = torch.float64 if DT == np.float64 else torch.float32
 dev = torch.device("cuda:0")
 A, b = bench.make_problem(m, n, 0, dev)
+A = A.to(TDT)
 out = {}
 for mode in ("early", "full"):
     if mode == "full":
         os.environ["POGS_AMD_SK_FULL"] = "1"
-    s = pogs_amd.Solver(A.data_ptr(), dtype=np.float32, shape=(m, n), device_ptr=True, profile=True)
+    s = pogs_amd.Solver(A.data_ptr(), dtype=DT, shape=(m, n), device_ptr=True, profile=True)
     f, g = G.lasso_functions(b, 0.1, n)
     r = s.solve(f, g)
     st = s.stats()
