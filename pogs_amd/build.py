@@ -6,6 +6,7 @@ not gpurun-ignored).  Usage: python pogs_amd/build.py [--force]
 """
 import concurrent.futures
 import os
+import re
 import subprocess
 import sys
 
@@ -13,7 +14,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(_HERE, "libpogs_amd.so")
-SOURCES = ["abi.hip", "dense_f32.hip", "dense_f64.hip", "sparse.hip", "gemm.hip", "vec_kernels.hip", "dist.hip"]
+SOURCES = ["abi.hip", "sparse.hip", "gemm.hip", "vec_kernels.hip", "dist.hip"]
+# dense_plan.hip is compiled once per arithmetic type and streaming shape (csrc/stream.h:
+# POGS_STREAM_PLANS) plus the windowed form -- one small code object per shape, see dense_plan.hip
+PLAN_SOURCE = "dense_plan.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -34,12 +38,32 @@ def _newest_dep():
     return t
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+def _plan_jobs():
+    """(object name, extra -D flags) for every build of dense_plan.hip."""
+    text = open(os.path.join(CSRC, "stream.h")).read()
+    body = text[text.index("#define POGS_STREAM_PLANS(X)"):]
+    body = body[:body.index("\n//")]
+    shapes = [(int(a), int(b)) for a, b in re.findall(r"X\((\d+),\s*(\d+)\)", body)]
+    if not shapes:
+        raise RuntimeError("POGS_STREAM_PLANS not found in stream.h")
+    jobs = []
+    for tname, ctype in (("f32", "float"), ("f64", "double")):
+        for tpb, nv in shapes:
+            name = "%s_p%d_%d" % (tname, tpb, nv)
+            jobs.append(("dense_%s.o" % name, ["-DPOGS_PLAN_T=%s" % ctype, "-DPOGS_PLAN_NAME=%s" % name,
+                                                "-DPOGS_PLAN_TPB=%d" % tpb, "-DPOGS_PLAN_NV=%d" % nv]))
+        name = "%s_xl" % tname
+        jobs.append(("dense_%s.o" % name, ["-DPOGS_PLAN_T=%s" % ctype, "-DPOGS_PLAN_NAME=%s" % name, "-DPOGS_PLAN_XL=1"]))
+    return jobs
+
+
+def _compile(job):
+    src, objname, defs = job
+    obj = os.path.join(OBJ, objname)
+    cmd = [_hipcc()] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        raise RuntimeError("hipcc failed for %s (%s):\n%s\n%s" % (src, objname, r.stdout, r.stderr))
     return obj
 
 
@@ -54,15 +78,18 @@ def build(force=False, verbose=False):
     headers_newer = max((os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h")),
                         default=0.0)
     headers_newer = max(headers_newer, os.path.getmtime(os.path.join(_HERE, "..", "include", "pogs_amd.h")))
-    for src in SOURCES:
-        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    jobs = [(src, src.replace(".hip", ".o"), []) for src in SOURCES]
+    jobs += [(PLAN_SOURCE, objname, defs) for objname, defs in _plan_jobs()]
+    for job in jobs:
+        src, objname, _ = job
+        obj = os.path.join(OBJ, objname)
         objs.append(obj)
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
             os.path.getmtime(os.path.join(CSRC, src)), headers_newer)
         if stale:
-            todo.append(src)
+            todo.append(job)
     if verbose:
-        print("pogs_amd.build: compiling", todo, file=sys.stderr)
+        print("pogs_amd.build: compiling", [j[1] for j in todo], file=sys.stderr)
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as ex:
         list(ex.map(_compile, todo))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]

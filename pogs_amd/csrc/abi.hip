@@ -6,19 +6,49 @@
 
 #include "engine.h"
 #include "prox.h"
+#include "stream.h"
 #include "vec_kernels.h"
 
 namespace pogs_amd {
 
-SolverBase *make_dense_solver_f32(int ord, size_t m, size_t n, const void *A, int mem, const PogsAmdOptions *opt,
-                                  const PogsAmdDist *dist);
-SolverBase *make_dense_solver_f64(int ord, size_t m, size_t n, const void *A, int mem, const PogsAmdOptions *opt,
-                                  const PogsAmdDist *dist);
+// One factory per streaming shape and arithmetic type (dense_plan.hip, built once per entry of
+// POGS_STREAM_PLANS plus the windowed form): the shape follows from the stored row length alone,
+// so it is chosen here and only that translation unit's code object is ever loaded.
+#define POGS_DECLARE_PLAN(TPB_, NV_)                                                                               \
+  SolverBase *make_dense_solver_f32_p##TPB_##_##NV_(int, size_t, size_t, const void *, int, const PogsAmdOptions *, \
+                                                    const PogsAmdDist *);                                          \
+  SolverBase *make_dense_solver_f64_p##TPB_##_##NV_(int, size_t, size_t, const void *, int, const PogsAmdOptions *, \
+                                                    const PogsAmdDist *);
+POGS_STREAM_PLANS(POGS_DECLARE_PLAN)
+#undef POGS_DECLARE_PLAN
+SolverBase *make_dense_solver_f32_xl(int, size_t, size_t, const void *, int, const PogsAmdOptions *, const PogsAmdDist *);
+SolverBase *make_dense_solver_f64_xl(int, size_t, size_t, const void *, int, const PogsAmdOptions *, const PogsAmdDist *);
+
+template <typename T>
+inline StreamPlan dense_plan_for(size_t m, size_t n, const PogsAmdOptions *opt, const PogsAmdDist *dist) {
+  // the stored row length, as DenseSolver's constructor derives it
+  const size_t m_global = (dist && dist->world >= 1) ? dist->m_global : m;
+  const bool tall = m_global > n;
+  const bool cgls = opt && opt->projector == POGS_AMD_PROJ_CGLS;
+  const size_t stored_cols = (!tall && !cgls) ? m : n;
+  return make_stream_plan<T>(static_cast<int>(round_up(stored_cols, Vec16<T>::N)), 256);
+}
+
 inline SolverBase *make_dense_solver(int dtype, int ord, size_t m, size_t n, const void *A, int mem,
                                      const PogsAmdOptions *opt, const PogsAmdDist *dist) {
-  if (dtype == POGS_AMD_F32) return make_dense_solver_f32(ord, m, n, A, mem, opt, dist);
-  if (dtype == POGS_AMD_F64) return make_dense_solver_f64(ord, m, n, A, mem, opt, dist);
-  throw Error("unknown dtype");
+  POGS_CHECK(dtype == POGS_AMD_F32 || dtype == POGS_AMD_F64, "unknown dtype");
+  POGS_CHECK(m > 0 && n > 0 && m < (1u << 31) && n < (1u << 31), "bad dimensions");
+  const bool f32 = dtype == POGS_AMD_F32;
+  const StreamPlan p = f32 ? dense_plan_for<float>(m, n, opt, dist) : dense_plan_for<double>(m, n, opt, dist);
+  POGS_CHECK(p.ok, "no streaming shape for this matrix");
+  if (p.xl) return f32 ? make_dense_solver_f32_xl(ord, m, n, A, mem, opt, dist) : make_dense_solver_f64_xl(ord, m, n, A, mem, opt, dist);
+#define POGS_PICK_PLAN(TPB_, NV_)                                                          \
+  if (p.tpb == TPB_ && p.nv == NV_)                                                        \
+    return f32 ? make_dense_solver_f32_p##TPB_##_##NV_(ord, m, n, A, mem, opt, dist)       \
+               : make_dense_solver_f64_p##TPB_##_##NV_(ord, m, n, A, mem, opt, dist);
+  POGS_STREAM_PLANS(POGS_PICK_PLAN)
+#undef POGS_PICK_PLAN
+  throw Error("no dense solver for this streaming shape");
 }
 SolverBase *make_sparse_solver(int dtype, int ord, size_t m, size_t n, size_t nnz, const void *data,
                                const int *ptr, const int *ind, int mem, const PogsAmdOptions *opt,

@@ -90,7 +90,9 @@ __global__ void __launch_bounds__(256) scale_all_kernel(T *A, size_t count_vec, 
   }
 }
 
-template <typename T>
+// Tag: the streaming shapes this instantiation carries (stream.h: OnePlan / WindowPlans /
+// AllPlans); dense_plan.hip builds one solver class per shape.
+template <typename T, typename Tag = AllPlans>
 class DenseSolver final : public SolverBase {
  public:
   DenseSolver(int ord, size_t m, size_t n, const void *A, int mem, const PogsAmdOptions *opt,
@@ -147,6 +149,8 @@ class DenseSolver final : public SolverBase {
     planA_ = make_stream_plan<T>(scols_pad_, ctx_.num_cu);
     POGS_CHECK(planA_.ok, tmode_ || tall_ ? "min(m, n) too large for the register-tiled streaming kernel"
                                           : "n too large for the register-tiled streaming kernel (CGLS projector)");
+    POGS_CHECK(planA_.xl ? Tag::windows : Tag::has(planA_.tpb, planA_.nv),
+               "dense solver built for another streaming shape (abi.hip: make_dense_solver)");
     ctx_.tmark_last = t0;
     ctx_.tmark("ctx init");
     upload(ord, A, mem);
@@ -253,14 +257,14 @@ class DenseSolver final : public SolverBase {
       cgls_project(xtemp_.p, ytemp_.p, x_[0].p, static_cast<T>(tol), nullptr);
       StreamArgs<T> a = argsA();
       a.xin = x_[0].p;
-      launch_stream<T, true, false, false, kFull>(planA_, a, GemvNOp<T>{1, 0, y_[0].p}, s);
+      launch_stream<T, true, false, false, kFull, Tag>(planA_, a, GemvNOp<T>{1, 0, y_[0].p}, s);
     } else if (tall_) {
       gemv_t_partials(ytemp_.p);
       finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, 0, 0);
       solve_gram(rhs_.p, xtemp_.p, GemvNOp<T>{1, 0, x_[0].p}, nullptr);
       StreamArgs<T> a = argsA();
       a.xin = x_[0].p;
-      launch_stream<T, true, false, false, kFull>(planA_, a, GemvNOp<T>{1, 0, y_[0].p}, s);
+      launch_stream<T, true, false, false, kFull, Tag>(planA_, a, GemvNOp<T>{1, 0, y_[0].p}, s);
     } else {
       // projector_direct_dense.cpp:128-135: t = (A A^T + I)^{-1} (A x0 - y0); x = x0 - A^T t; y = y0 + t
       t_mul_n(xtemp_.p, nullptr, ResidOp<T>{ytemp_.p, rhs_.p}, nullptr);
@@ -298,7 +302,7 @@ class DenseSolver final : public SolverBase {
       POGS_HIP_CHECK(hipMemcpyAsync(ytemp_.p, y, m_ * sizeof(T), hipMemcpyHostToDevice, s));
       StreamArgs<T> a = argsA();
       a.xin = xtemp_.p;
-      launch_stream<T, true, false, false, kFull>(planA_, a,
+      launch_stream<T, true, false, false, kFull, Tag>(planA_, a,
                                                   GemvNOp<T>{static_cast<T>(alpha), static_cast<T>(beta), ytemp_.p}, s);
       POGS_HIP_CHECK(hipMemcpyAsync(y, ytemp_.p, m_ * sizeof(T), hipMemcpyDeviceToHost, s));
     } else {
@@ -426,14 +430,14 @@ class DenseSolver final : public SolverBase {
       StreamArgs<T> a = argsA();
       a.xin = xin; a.xin_add = xin_add; a.xin_nrm2 = x_nrm2;
       ctx_.stream_timer.begin(s);
-      launch_stream<T, true, false, false, kFull>(planA_, a, op, s);
+      launch_stream<T, true, false, false, kFull, Tag>(planA_, a, op, s);
       ctx_.stream_timer.end(s);
       if (RowOp::NS > 0 && scalar_out) sum_row_scalars(stream_grid<true, false>(planA_, srows_), RowOp::NS, scalar_out);
       return;
     }
     StreamArgs<T> a = argsA();
     ctx_.stream_timer.begin(s);
-    launch_stream<T, false, true, false, kFull>(planA_, a, VecCoefOp<T>{xin, xin_add, x_nrm2}, s);
+    launch_stream<T, false, true, false, kFull, Tag>(planA_, a, VecCoefOp<T>{xin, xin_add, x_nrm2}, s);
     ctx_.stream_timer.end(s);
     double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
     launch_reduce_cols<T, RowAsColOp<T, RowOp>>(colpart_.p, stream_grid<false, true>(planA_, srows_), scols_pad_,
@@ -454,7 +458,7 @@ class DenseSolver final : public SolverBase {
     StreamArgs<T> a = argsA();
     a.xin = u;   // length m, zero-padded to the vector width
     ctx_.stream_timer.begin(s);
-    launch_stream<T, true, false, false, kFull>(planA_, a, ColAsRowOp<T, ColOp>{op}, s);
+    launch_stream<T, true, false, false, kFull, Tag>(planA_, a, ColAsRowOp<T, ColOp>{op}, s);
     ctx_.stream_timer.end(s);
     if (ColOp::NS > 0 && scalar_out) sum_row_scalars(stream_grid<true, false>(planA_, srows_), ColOp::NS, scalar_out);
   }
@@ -502,7 +506,7 @@ class DenseSolver final : public SolverBase {
   void gemv_t_partials(const T *u) {
     StreamArgs<T> a = argsA();
     ctx_.stream_timer.begin(ctx_.stream);
-    launch_stream<T, false, true, false, kFull>(planA_, a, GemvTOp<T>{1, u}, ctx_.stream);
+    launch_stream<T, false, true, false, kFull, Tag>(planA_, a, GemvTOp<T>{1, u}, ctx_.stream);
     ctx_.stream_timer.end(ctx_.stream);
   }
 
@@ -580,7 +584,7 @@ class DenseSolver final : public SolverBase {
       launch_fill<T>(d_.p, static_cast<T>(1), m_, s);
       for (; k < 50; ++k) {
         a.xin = d_.p;
-        launch_stream<T, true, true, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(mg), ce, e_.p}, s);
+        launch_stream<T, true, true, true, kFull, Tag>(planA_, a, SkRowOp<T>{static_cast<T>(mg), ce, e_.p}, s);
         launch_reduce_cols<T, SkColOp<T>>(
             colpart_.p, gridBOTH, scols_pad_,
             SkColOp<T>{static_cast<T>(nn), cd, d_.p, m_, mark, k + 1.0, sk_tol, static_cast<T>(r_ref)}, sp, s);
@@ -598,19 +602,19 @@ class DenseSolver final : public SolverBase {
         launch_scal<T>(e_.p, static_cast<T>(std::exp(Le)), n_, s);
       }
     } else {
-      launch_stream<T, false, true, true, kFull>(planA_, a, OnesOp<T>{}, s);
+      launch_stream<T, false, true, true, kFull, Tag>(planA_, a, OnesOp<T>{}, s);
       ctx_.tmark("  eq: first pass");
       finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_}, nullptr, 0, 0, gridACC);
       ctx_.tmark("  eq: first cols");
       for (; k < 50; ++k) {
         a.xin = e_.p;
         if (k < 49) {
-          launch_stream<T, true, true, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
+          launch_stream<T, true, true, true, kFull, Tag>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
           finish_cols(SkColOp<T>{static_cast<T>(mg), ce, e_.p, n_, mark, k + 1.0, sk_tol, static_cast<T>(r_ref)},
                       ctx_.S.p + kSkRatio, 0, 0, gridBOTH);
           if (sk_uniform(k, n_)) { extrapolate = true; ++k; break; }
         } else {
-          launch_stream<T, true, false, true, kFull>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
+          launch_stream<T, true, false, true, kFull, Tag>(planA_, a, SkRowOp<T>{static_cast<T>(nn), cd, d_.p}, s);
         }
       }
       ctx_.stats.matvecs_init += k + 1;
@@ -675,7 +679,7 @@ class DenseSolver final : public SolverBase {
       StreamArgs<T> a = argsA();
       a.xin = xa;
       a.xin_nrm2 = (i == 0) ? nullptr : ctx_.S.p + kPowX2;
-      launch_stream<T, true, true, false, kFull>(planA_, a, PowerRowOp<T>{}, s);
+      launch_stream<T, true, true, false, kFull, Tag>(planA_, a, PowerRowOp<T>{}, s);
       sum_row_scalars(grid, 1, ctx_.S.p + kPowSx2);
       // kPowX2 is read by the pass above (x normalisation) and rewritten here.
       // with shards |Sx|^2 travels in the same RCCL group as the column totals
@@ -727,7 +731,7 @@ class DenseSolver final : public SolverBase {
       a.xin = xa; a.xin_add = nullptr; a.xin_nrm2 = nrm;
       a.col_partials = colpart_.p; a.scalar_partials = ctx_.spart.p;
       a.xl_scratch = xl_buf_.p;
-      launch_stream<T, true, true, false, kLower>(planW_, a, SymRowOp<T>{G, ld, xa, nrm, tvec_.p}, s);
+      launch_stream<T, true, true, false, kLower, Tag>(planW_, a, SymRowOp<T>{G, ld, xa, nrm, tvec_.p}, s);
       launch_reduce_cols<T, SymColOp<T>>(colpart_.p, grid, n_pad_, SymColOp<T>{tvec_.p, xa, nrm, xb, n_}, sp, s);
       SumJob j{sp, reduce_cols_grid(n_pad_, Vec16<T>::N), 2, ctx_.S.p + kPowX2};   // -> kPowX2, kPowXGx
       launch_sum_jobs(&j, 1, s);
@@ -778,7 +782,7 @@ class DenseSolver final : public SolverBase {
       a.xin = ya; a.xin_add = nullptr; a.xin_nrm2 = nrm;
       a.col_partials = colpart_.p; a.scalar_partials = ctx_.spart.p;
       a.xl_scratch = xl_buf_.p;
-      launch_stream<T, true, true, false, kLower>(planW_, a, SymRowOp<T>{G, ld, ya, nrm, tvec_.p}, s);
+      launch_stream<T, true, true, false, kLower, Tag>(planW_, a, SymRowOp<T>{G, ld, ya, nrm, tvec_.p}, s);
       launch_reduce_cols<T, SymColOp<T>>(colpart_.p, grid, k_pad_, SymColOp<T>{tvec_.p, ya, nrm, yb, k_}, sp, s);
       double *tmp2 = ctx_.S.p + kPowX2;   // -> kPowX2 = |G y^|^2, kPowXGx = y^^T G y^ = |x'|^2
       const double prev_xgx = (i == 0) ? 1.0 : ctx_.S_host.p[kPowXGx];
@@ -967,10 +971,10 @@ class DenseSolver final : public SolverBase {
     double *part = defer_sums_ ? ctx_.spart.p + sp_tail_off_ : ctx_.spart.p;
     a.col_partials = nullptr; a.scalar_partials = part;
     a.xl_scratch = xl_buf_.p;
-    launch_stream<T, true, false, false, kLower>(planW_, a, GemvNOp<T>{1, 0, tvec_.p}, s);
+    launch_stream<T, true, false, false, kLower, Tag>(planW_, a, GemvNOp<T>{1, 0, tvec_.p}, s);
     a.A = Up_;
     a.xin = tvec_.p; a.xin_add = nullptr;
-    launch_stream<T, true, false, false, kUpper>(planW_, a, tail, s);
+    launch_stream<T, true, false, false, kUpper, Tag>(planW_, a, tail, s);
     if (TailOp::NS > 0 && tail_scalars) {
       SumJob j{part, stream_grid<true, false>(planW_, k_), TailOp::NS, tail_scalars};
       sum_now_or_later(j);
@@ -991,7 +995,7 @@ class DenseSolver final : public SolverBase {
     a.col_partials = colpart_.p;   // free here: its sums were reduced into rhs before the solve
     a.scalar_partials = ctx_.spart.p;
     a.xl_scratch = xl_buf_.p;
-    launch_stream<T, true, true, false, kLower>(planW_, a, IdentRowOp<T>{}, s);
+    launch_stream<T, true, true, false, kLower, Tag>(planW_, a, IdentRowOp<T>{}, s);
     double *sp = ctx_.spart.p + sp_tail_off_;
     launch_reduce_cols<T, TailColOp>(colpart_.p, stream_grid<true, true>(planW_, k_), k_pad_, tail, sp, s);
     if (TailColOp::NS > 0 && tail_scalars) {
@@ -1018,7 +1022,7 @@ class DenseSolver final : public SolverBase {
       StreamArgs<T> a = argsA();
       a.xin = xin;
       ctx_.stream_timer.begin(s);
-      launch_stream<T, true, false, false, kFull>(planA_, a, op, s);
+      launch_stream<T, true, false, false, kFull, Tag>(planA_, a, op, s);
       ctx_.stream_timer.end(s);
       if (ns > 0) sum_row_scalars(stream_grid<true, false>(planA_, m_), ns, out);
       ctx_.stats.matvecs += 1;
@@ -1135,7 +1139,7 @@ class DenseSolver final : public SolverBase {
     } else {
       StreamArgs<T> a = argsA();
       a.xin = x_[cur_].p;
-      launch_stream<T, true, false, false, kFull>(planA_, a, GemvNOp<T>{1, 0, y_[cur_].p}, s);   // y = A x
+      launch_stream<T, true, false, false, kFull, Tag>(planA_, a, GemvNOp<T>{1, 0, y_[cur_].p}, s);   // y = A x
       gemv_t_partials(yt_.p);
       finish_cols(StoreColOp<T>{static_cast<T>(1) / rho, 0, xt_.p, n_}, nullptr, 0, 0);         // xt = A^T (l0/d) / rho
     }
@@ -1176,7 +1180,7 @@ class DenseSolver final : public SolverBase {
       StreamArgs<T> a = argsA();
       a.xin = x_[nw].p;
       ctx_.stream_timer.begin(s);
-      launch_stream<T, true, false, false, kFull>(planA_, a,
+      launch_stream<T, true, false, false, kFull, Tag>(planA_, a,
                                                   ProjTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p}, s);
       ctx_.stream_timer.end(s);
       sum_row_scalars(stream_grid<true, false>(planA_, m_), 2, ctx_.S.p + kDYprev2);
@@ -1197,7 +1201,7 @@ class DenseSolver final : public SolverBase {
       StreamArgs<T> a = argsA();
       a.xin = x_[nw].p;
       ctx_.stream_timer.begin(s);
-      launch_stream<T, true, false, false, kFull>(planA_, a,
+      launch_stream<T, true, false, false, kFull, Tag>(planA_, a,
                                                   ProjTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p}, s);
       ctx_.stream_timer.end(s);
       sum_row_scalars(stream_grid<true, false>(planA_, m_), 2, ctx_.S.p + kDYprev2);
@@ -1228,7 +1232,7 @@ class DenseSolver final : public SolverBase {
         launch_exact_u<T>(m_, y12_.p, yt_.p, y_[cur_].p, zt_scale_, uvec_.p, s);
         a.xin = uvec_.p;
         ctx_.stream_timer.begin(s);
-        launch_stream<T, true, true, false, kFull>(planA_, a, ExactTRowOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_}, s);
+        launch_stream<T, true, true, false, kFull, Tag>(planA_, a, ExactTRowOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_}, s);
         ctx_.stream_timer.end(s);
         sum_row_scalars(grid, 1, ctx_.S.p + kExactS2);
         double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
@@ -1238,7 +1242,7 @@ class DenseSolver final : public SolverBase {
       } else {
         a.xin = x12_.p;
         ctx_.stream_timer.begin(s);
-        launch_stream<T, true, true, false, kFull>(planA_, a,
+        launch_stream<T, true, true, false, kFull, Tag>(planA_, a,
                                                    ExactRowOp<T>{y12_.p, yt_.p, y_[cur_].p, zt_scale_}, s);
         ctx_.stream_timer.end(s);
         sum_row_scalars(grid, 1, ctx_.S.p + kExactR2);
@@ -1314,7 +1318,7 @@ class DenseSolver final : public SolverBase {
       // (B) column sums A^T yhat_k and A^T (y12 + c yt - yprev)
       StreamArgs2<T> a2{A_.p, lda_, m_, n_pad_, nullptr, nullptr, colpart_.p, colpart2_.p, ctx_.spart.p};
       ctx_.stream_timer.begin(s);
-      launch_stream2<T, 0, 2>(planA_, a2, PreAccOp<T>{ytemp_.p, y12_.p, yt_.p, y_[cur_].p, zt_scale_}, s);
+      launch_stream2<T, 0, 2, Tag>(planA_, a2, PreAccOp<T>{ytemp_.p, y12_.p, yt_.p, y_[cur_].p, zt_scale_}, s);
       ctx_.stream_timer.end(s);
       nparts = stream2_grid<0>(planA_, m_);
       ctx_.stats.matvecs += 1;
@@ -1357,11 +1361,11 @@ class DenseSolver final : public SolverBase {
       if (fused_logistic_) {
         FusedIterOp<T, true> op{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, fview(), rho_pred_, ctl_.alpha(), zs_pred_,
                                 y12s_.p, ytemps_.p};
-        launch_stream2<T, 2, 2>(planA_, a2, op, s);
+        launch_stream2<T, 2, 2, Tag>(planA_, a2, op, s);
       } else {
         FusedIterOp<T, false> op{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, fview(), rho_pred_, ctl_.alpha(), zs_pred_,
                                  y12s_.p, ytemps_.p};
-        launch_stream2<T, 2, 2>(planA_, a2, op, s);
+        launch_stream2<T, 2, 2, Tag>(planA_, a2, op, s);
       }
       ctx_.stream_timer.end(s);
       const int grid = stream2_grid<2>(planA_, m_);
@@ -1462,7 +1466,7 @@ class DenseSolver final : public SolverBase {
       // (B) column sums A xhat_k and A x12_k
       StreamArgs2<T> a2{A_.p, lda_, srows_, scols_pad_, nullptr, nullptr, colpart_.p, colpart2_.p, ctx_.spart.p};
       ctx_.stream_timer.begin(s);
-      launch_stream2<T, 0, 2>(planA_, a2, PreAcc2Op<T>{xtemp_.p, x12_.p}, s);
+      launch_stream2<T, 0, 2, Tag>(planA_, a2, PreAcc2Op<T>{xtemp_.p, x12_.p}, s);
       ctx_.stream_timer.end(s);
       nparts = stream2_grid<0>(planA_, srows_);
       ctx_.stats.matvecs += 1;
@@ -1488,7 +1492,7 @@ class DenseSolver final : public SolverBase {
       ctx_.stream_timer.begin(s);
       FusedIterOp<T, false, true> op{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, gview(), rho_pred_, ctl_.alpha(), zs_pred_,
                                      x12s_.p, xtemps_.p, xt_.p, zt_scale_};
-      launch_stream2<T, 2, 2>(planA_, a2, op, s);
+      launch_stream2<T, 2, 2, Tag>(planA_, a2, op, s);
       ctx_.stream_timer.end(s);
       const int grid = stream2_grid<2>(planA_, srows_);
       SumJob j[2] = {{ctx_.spart.p, grid, 3, ctx_.S.p + kDXprev2, 6, 0},
@@ -1595,10 +1599,10 @@ class DenseSolver final : public SolverBase {
 // One translation unit per arithmetic type (dense_f32.hip, dense_f64.hip): the HIP runtime loads a
 // code object as a whole at its first kernel launch, and the row kernels come in ~700 variants
 // per type (plan x mode x functor), so a float solve should not pay for the double kernels.
-template <typename T>
+template <typename T, typename Tag>
 SolverBase *make_dense_solver_t(int ord, size_t m, size_t n, const void *A, int mem, const PogsAmdOptions *opt,
                                 const PogsAmdDist *dist) {
-  return new DenseSolver<T>(ord, m, n, A, mem, opt, dist);
+  return new DenseSolver<T, Tag>(ord, m, n, A, mem, opt, dist);
 }
 
 }  // namespace pogs_amd

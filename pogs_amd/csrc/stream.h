@@ -83,6 +83,30 @@ template <typename T> inline size_t stream_xl_scratch(const StreamPlan &p, int r
   return p.xl ? static_cast<size_t>(stream_windows<T>(p, n_pad) + 1) * rows : 0;
 }
 
+// The workgroup shapes (threads, 16-byte vectors per thread and row) the streaming kernels are
+// built for.  A dense solver uses exactly one of them (or the two window shapes) for all its
+// passes, so pogs_amd/build.py compiles dense_plan.hip once per entry of this list and
+// arithmetic type -- one small code object each instead of one 4 MB object per type, which is
+// what the first launch of a process has to load (~3 ms per MB).  Keep the list in one line per
+// the X(tpb, nv) form: build.py reads it.
+#define POGS_STREAM_PLANS(X) \
+  X(64, 1) X(64, 2) X(64, 4) X(256, 2) X(256, 3) X(256, 4) X(256, 5) X(256, 6) X(256, 8) X(256, 10) \
+  X(512, 6) X(512, 8) X(512, 10) X(1024, 6) X(1024, 8)
+// Which shapes a translation unit instantiates.
+struct AllPlans {
+  static constexpr bool has(int, int) { return true; }
+  static constexpr bool windows = true;
+};
+template <int TPB, int NV>
+struct OnePlan {
+  static constexpr bool has(int t, int v) { return t == TPB && v == NV; }
+  static constexpr bool windows = false;
+};
+struct WindowPlans {   // StreamPlan::xl: the two window shapes only
+  static constexpr bool has(int, int) { return false; }
+  static constexpr bool windows = true;
+};
+
 // Chooses the workgroup shape for rows of n_pad elements.
 template <typename T>
 inline StreamPlan make_stream_plan(int n_pad, int num_cu) {
@@ -329,54 +353,46 @@ __global__ void __launch_bounds__(256) xl_apply_rows_kernel(const T *part, int m
   }
 }
 
-template <typename T, bool DOT, bool ACC, bool SQ, int TRI, typename Op>
+template <typename T, bool DOT, bool ACC, bool SQ, int TRI, typename Tag, typename Op>
 void launch_stream_plain(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hipStream_t s, int grid) {
 #define POGS_STREAM_CASE(TPB_, NV_)                                                             \
-  if (p.tpb == TPB_ && p.nv == NV_) {                                                           \
-    constexpr int R_ = RowsPerStep<DOT, ACC, TPB_>::value;                                      \
-    hipLaunchKernelGGL((stream_rows_kernel<T, TPB_, NV_, R_, DOT, ACC, SQ, TRI, Op>),           \
-                       dim3(grid), dim3(TPB_), 0, s, a, op);                                    \
-    return;                                                                                     \
+  if constexpr (Tag::has(TPB_, NV_)) {                                                          \
+    if (p.tpb == TPB_ && p.nv == NV_) {                                                         \
+      constexpr int R_ = RowsPerStep<DOT, ACC, TPB_>::value;                                    \
+      hipLaunchKernelGGL((stream_rows_kernel<T, TPB_, NV_, R_, DOT, ACC, SQ, TRI, Op>),         \
+                         dim3(grid), dim3(TPB_), 0, s, a, op);                                  \
+      return;                                                                                   \
+    }                                                                                           \
   }
-  POGS_STREAM_CASE(64, 1)
-  POGS_STREAM_CASE(64, 2)
-  POGS_STREAM_CASE(64, 4)
-  POGS_STREAM_CASE(256, 2)
-  POGS_STREAM_CASE(256, 3)
-  POGS_STREAM_CASE(256, 4)
-  POGS_STREAM_CASE(256, 5)
-  POGS_STREAM_CASE(256, 6)
-  POGS_STREAM_CASE(256, 8)
-  POGS_STREAM_CASE(256, 10)
-  POGS_STREAM_CASE(512, 6)
-  POGS_STREAM_CASE(512, 8)
-  POGS_STREAM_CASE(512, 10)
-  POGS_STREAM_CASE(1024, 6)
-  POGS_STREAM_CASE(1024, 8)
+  POGS_STREAM_PLANS(POGS_STREAM_CASE)
 #undef POGS_STREAM_CASE
-  throw Error("no stream kernel instance for plan");
+  throw Error("no stream kernel instance for this plan in this translation unit");
 }
 
 // the two window shapes of a windowed plan only (keeps the number of kernel variants down)
-template <typename T, bool DOT, bool ACC, bool SQ, int TRI, typename Op>
+template <typename T, bool DOT, bool ACC, bool SQ, int TRI, typename Tag, typename Op>
 void launch_stream_window(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hipStream_t s, int grid) {
-  if (p.tpb == 256 && p.nv == 8) {
-    hipLaunchKernelGGL((stream_rows_kernel<T, 256, 8, RowsPerStep<DOT, ACC, 256>::value, DOT, ACC, SQ, TRI, Op>),
-                       dim3(grid), dim3(256), 0, s, a, op);
-  } else if (p.tpb == 64 && p.nv == 2) {
-    hipLaunchKernelGGL((stream_rows_kernel<T, 64, 2, RowsPerStep<DOT, ACC, 64>::value, DOT, ACC, SQ, TRI, Op>),
-                       dim3(grid), dim3(64), 0, s, a, op);
-  } else {
-    throw Error("no window kernel instance for plan");
+  if constexpr (Tag::windows) {
+    if (p.tpb == 256 && p.nv == 8) {
+      hipLaunchKernelGGL((stream_rows_kernel<T, 256, 8, RowsPerStep<DOT, ACC, 256>::value, DOT, ACC, SQ, TRI, Op>),
+                         dim3(grid), dim3(256), 0, s, a, op);
+      return;
+    }
+    if (p.tpb == 64 && p.nv == 2) {
+      hipLaunchKernelGGL((stream_rows_kernel<T, 64, 2, RowsPerStep<DOT, ACC, 64>::value, DOT, ACC, SQ, TRI, Op>),
+                         dim3(grid), dim3(64), 0, s, a, op);
+      return;
+    }
   }
+  throw Error("no window kernel instance for this plan in this translation unit");
 }
 
-template <typename T, bool DOT, bool ACC, bool SQ, int TRI, typename Op>
+template <typename T, bool DOT, bool ACC, bool SQ, int TRI, typename Tag = AllPlans, typename Op>
 void launch_stream(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hipStream_t s) {
   POGS_CHECK(p.ok, "matrix too wide for the row-streaming kernel");
   const int grid = stream_grid<DOT, ACC>(p, a.m);
   if (!p.xl) {
-    launch_stream_plain<T, DOT, ACC, SQ, TRI, Op>(p, a, op, s, grid);
+    launch_stream_plain<T, DOT, ACC, SQ, TRI, Tag, Op>(p, a, op, s, grid);
     return;
   }
   POGS_CHECK(a.xl_scratch != nullptr, "windowed pass without scratch");
@@ -388,7 +404,7 @@ void launch_stream(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hi
     const int gdot = stream_grid<true, false>(p, a.m);
     for (int c = 0; c < nwin; ++c) {
       aw.col0 = c * w;
-      launch_stream_window<T, true, false, SQ, TRI, XlStoreDotOp<T>>(p, aw, XlStoreDotOp<T>{part + static_cast<size_t>(c) * a.m},
+      launch_stream_window<T, true, false, SQ, TRI, Tag, XlStoreDotOp<T>>(p, aw, XlStoreDotOp<T>{part + static_cast<size_t>(c) * a.m},
                                                                      s, gdot);
     }
     hipLaunchKernelGGL((xl_apply_rows_kernel<T, Op, ACC>), dim3(grid), dim3(256), 0, s, part, a.m, nwin, op, uvec,
@@ -397,8 +413,8 @@ void launch_stream(const StreamPlan &p, const StreamArgs<T> &a, const Op &op, hi
   if (ACC) {
     for (int c = 0; c < nwin; ++c) {
       aw.col0 = c * w;
-      if (DOT) launch_stream_window<T, false, true, SQ, TRI, XlVecUOp<T>>(p, aw, XlVecUOp<T>{uvec}, s, grid);
-      else launch_stream_window<T, false, true, SQ, TRI, Op>(p, aw, op, s, grid);
+      if (DOT) launch_stream_window<T, false, true, SQ, TRI, Tag, XlVecUOp<T>>(p, aw, XlVecUOp<T>{uvec}, s, grid);
+      else launch_stream_window<T, false, true, SQ, TRI, Tag, Op>(p, aw, op, s, grid);
     }
   }
 }
@@ -577,11 +593,12 @@ inline int stream2_grid(const StreamPlan &p, int m) {
   return nblk < p.grid_max ? (nblk > 0 ? nblk : 1) : p.grid_max;
 }
 
-template <typename T, int ND, int NA, typename Op>
+template <typename T, int ND, int NA, typename Tag = AllPlans, typename Op>
 void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, hipStream_t s) {
   POGS_CHECK(stream2_supported(p), "plan not supported by the two-accumulator kernel");
   const int grid = stream2_grid<ND>(p, a.m);
 #define POGS_STREAM2_CASE(TPB_, NV_)                                                            \
+  if constexpr (Tag::has(TPB_, NV_) && TPB_ != 1024)                                            \
   if (p.tpb == TPB_ && p.nv == NV_) {                                                           \
     constexpr int R_ = stream2_rows_c(ND, NV_);                                                 \
     const size_t lds = (ND > 1) ? static_cast<size_t>(a.n_pad) * sizeof(T) : 0;                 \
@@ -597,21 +614,9 @@ void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, 
                        dim3(TPB_), lds, s, a, op);                                              \
     return;                                                                                     \
   }
-  POGS_STREAM2_CASE(64, 1)
-  POGS_STREAM2_CASE(64, 2)
-  POGS_STREAM2_CASE(64, 4)
-  POGS_STREAM2_CASE(256, 2)
-  POGS_STREAM2_CASE(256, 3)
-  POGS_STREAM2_CASE(256, 4)
-  POGS_STREAM2_CASE(256, 5)
-  POGS_STREAM2_CASE(256, 6)
-  POGS_STREAM2_CASE(256, 8)
-  POGS_STREAM2_CASE(256, 10)
-  POGS_STREAM2_CASE(512, 6)
-  POGS_STREAM2_CASE(512, 8)
-  POGS_STREAM2_CASE(512, 10)
+  POGS_STREAM_PLANS(POGS_STREAM2_CASE)
 #undef POGS_STREAM2_CASE
-  throw Error("no stream2 kernel instance for plan");
+  throw Error("no stream2 kernel instance for this plan in this translation unit");
 }
 
 // ---------------------------------------------------------------------------
