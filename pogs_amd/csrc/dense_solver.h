@@ -113,8 +113,10 @@ class DenseSolver final : public SolverBase {
       if (!(pe && pe[0] == '0') && dev >= 0)
         preload.t = std::thread([dev] {
           hipFuncAttributes fa;
-          if (hipSetDevice(dev) == hipSuccess)
-            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(scale_all_kernel<T>));
+          if (hipSetDevice(dev) != hipSuccess) return;
+          (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(scale_all_kernel<T>));
+          preload_vec_code();
+          preload_gemm_code();
         });
     }
     ctx_.init(opt ? opt->device : -1, opt ? opt->profile != 0 : false);

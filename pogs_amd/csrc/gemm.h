@@ -61,6 +61,9 @@ struct GramF16Args {
   float scale;                    // power of two; scale * max|P| must stay below 65504
 };
 void launch_gram_f16(const GramF16Args &g, hipStream_t s);
+// Asks the runtime for a kernel of gemm.hip, which makes it load that code object (helper thread
+// of DenseSolver's constructor).
+void preload_gemm_code();
 
 // The same product from operands split ahead of time.  launch_split_f16 writes rows
 // [k0, k0 + krows) of P (zeros past K, zeros in columns [N, npad)) as two fp16 images H and L in

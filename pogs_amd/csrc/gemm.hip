@@ -780,6 +780,11 @@ void launch_gram_f16p(const GramF16PArgs &g, hipStream_t s) {
   else launch_gram_f16p_cfg<2, 2, 2, 2>(g, s);
 }
 
+void preload_gemm_code() {
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(split_f16_kernel));
+}
+
 void launch_gram_f16(const GramF16Args &g, hipStream_t s) {
   const int tm = (g.N + BM - 1) / BM;
   const int nunits = tm * (tm + 1) / 2 * g.nslabs;

@@ -93,6 +93,8 @@ struct SumJob {
   int stride = 0;   // doubles between consecutive partial records (0: ns)
   int offset = 0;   // first scalar of the record to sum
 };
+// Makes the runtime load this translation unit's code object (see preload_gemm_code).
+void preload_vec_code();
 constexpr int kMaxSumJobs = 8;
 // launch_sum_jobs and launch_publish_scalars in one launch (see sum_publish_kernel); *counter is a
 // zero-initialised device word the kernel leaves at zero.

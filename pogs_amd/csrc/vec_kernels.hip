@@ -268,6 +268,11 @@ __global__ void __launch_bounds__(256) max_partials_kernel(const double *partial
 }
 }  // namespace
 
+void preload_vec_code() {
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(max_partials_kernel));
+}
+
 void launch_max_partials(const double *partials, int n, double *out, hipStream_t s) {
   hipLaunchKernelGGL(max_partials_kernel, dim3(1), dim3(256), 0, s, partials, n, out);
 }
