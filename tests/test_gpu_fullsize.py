@@ -209,3 +209,30 @@ def test_c2_sinkhorn_knopp_early_exit_matches_full_count(monkeypatch):
     assert r0["status"] == r1["status"] == 0
     assert abs(int(r0["iterations"]) - int(r1["iterations"])) <= 1
     assert rel(r0["x"].astype(np.float64), r1["x"].astype(np.float64)) < 1e-4
+
+
+def test_c2_through_the_reference_entry_point_with_host_buffers():
+    """configs[1] the way the reference's own Python layer calls it: `PogsS` with a host float32 A
+    (4 GB over PCIe) and host coefficient arrays, one shot.  Same iteration count and solution as
+    the handle on a device-resident copy of the same matrix."""
+    torch = _torch()
+    pogs = _pogs()
+    m, n = 100000, 10000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float32)
+    xt = torch.randn(n, generator=g, device=dev) * (torch.rand(n, generator=g, device=dev) < 0.1)
+    b = (A @ xt + 0.1 * torch.randn(m, generator=g, device=dev)).double().cpu().numpy()
+    torch.cuda.synchronize()
+    f, gg = pogs.graph.lasso_functions(b, LAM, n)
+    with pogs.Solver(A.data_ptr(), dtype=np.float32, shape=(m, n), device_ptr=True) as s:
+        want = s.solve(f, gg)
+    A_host = A.cpu().numpy()
+    del A
+    torch.cuda.empty_cache()
+    got = pogs.graph._solve_graph_form(A_host, f, gg, 1e-4, 1e-4, 2500, 0, 1.0, dtype=np.float32)
+    assert got["status"] == want["status"] == 0
+    assert got["iterations"] == want["iterations"]
+    assert np.array_equal(got["x"], want["x"])          # same engine, same data: bit for bit
+    assert got["optval"] == want["optval"]
