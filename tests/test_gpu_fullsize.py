@@ -236,3 +236,37 @@ def test_c2_through_the_reference_entry_point_with_host_buffers():
     assert got["iterations"] == want["iterations"]
     assert np.array_equal(got["x"], want["x"])          # same engine, same data: bit for bit
     assert got["optval"] == want["optval"]
+
+
+def test_every_streaming_shape_and_type_once():
+    """One dense solver class (and code object) is built per streaming shape and arithmetic type
+    (stream.h: POGS_STREAM_PLANS + the windowed form).  Row lengths that select each of them in
+    fp32 and in fp64; the two types run the same data on different shapes, so their agreement
+    (status, iteration count, solution) checks both."""
+    torch = _torch()
+    pogs = _pogs()
+    dev = torch.device("cuda:0")
+    vprs = [60, 120, 250, 500, 760, 1000, 1270, 1500, 2000, 2500, 3000, 4000, 5000, 6000, 8000, 9000]
+    for n in sorted(set([2 * v for v in vprs] + [4 * v for v in vprs])):
+        m = n + 64
+        g = torch.Generator(device=dev)
+        g.manual_seed(n)
+        A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float64)
+        xt = torch.randn(n, generator=g, device=dev, dtype=torch.float64) * (torch.rand(n, generator=g, device=dev) < 0.05)
+        b = A @ xt + 0.1 * torch.randn(m, generator=g, device=dev, dtype=torch.float64)
+        lam = 0.3 * float(torch.max(torch.abs(A.T @ b)))
+        f, gg = pogs.graph.lasso_functions(b.cpu().numpy(), lam, n)
+        res = {}
+        for dt, tdt in ((np.float64, torch.float64), (np.float32, torch.float32)):
+            At = A.to(tdt)
+            torch.cuda.synchronize()
+            with pogs.Solver(At.data_ptr(), dtype=dt, shape=(m, n), device_ptr=True) as s:
+                res[dt] = s.solve(f, gg)
+            del At
+        r64, r32 = res[np.float64], res[np.float32]
+        assert r64["status"] == 0 and r32["status"] == 0, n
+        assert abs(int(r64["iterations"]) - int(r32["iterations"])) <= 1 + int(r64["iterations"]) // 50, n
+        err = np.linalg.norm(r32["x"].astype(np.float64) - r64["x"]) / np.linalg.norm(r64["x"])
+        assert err < 1e-4, (n, err)
+        del A
+        torch.cuda.empty_cache()
