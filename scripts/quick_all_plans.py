@@ -11,11 +11,13 @@ from pogs_amd import graph as G
 dev = torch.device("cuda:0")
 vprs = [60, 120, 250, 500, 760, 1000, 1270, 1500, 2000, 2500, 3000, 4000, 5000, 6000, 8000, 9000]
 sizes = sorted(set([2 * v for v in vprs] + [4 * v for v in vprs]))
-if len(sys.argv) > 1:
-    sizes = [int(a) for a in sys.argv[1:]]
-for n in sizes:
-    m = n + 64
-    g = torch.Generator(device=dev); g.manual_seed(n)
+wide = "--wide" in sys.argv     # m < n: transposed storage, the mirrored iteration
+args = [a for a in sys.argv[1:] if a != "--wide"]
+if args:
+    sizes = [int(a) for a in args]
+for k in sizes:
+    m, n = (k, k + 64) if wide else (k + 64, k)
+    g = torch.Generator(device=dev); g.manual_seed(k)
     A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float64)
     xt = torch.randn(n, generator=g, device=dev, dtype=torch.float64) * (torch.rand(n, generator=g, device=dev) < 0.05)
     b = A @ xt + 0.1 * torch.randn(m, generator=g, device=dev, dtype=torch.float64)
@@ -34,7 +36,7 @@ for n in sizes:
     r64, t64 = res[np.float64]; r32, t32 = res[np.float32]
     err = np.linalg.norm(r32["x"].astype(np.float64) - r64["x"]) / max(np.linalg.norm(r64["x"]), 1e-300)
     ok = r64["status"] == 0 and r32["status"] == 0 and err < 5e-3
-    print("n %6d: fp64 status %d it %4d (%.2f s)   fp32 status %d it %4d (%.2f s)   x rel diff %.1e  %s" % (
-        n, r64["status"], r64["iterations"], t64, r32["status"], r32["iterations"], t32, err, "ok" if ok else "MISMATCH"), flush=True)
+    print("k %6d: fp64 status %d it %4d (%.2f s)   fp32 status %d it %4d (%.2f s)   x rel diff %.1e  %s" % (
+        k, r64["status"], r64["iterations"], t64, r32["status"], r32["iterations"], t32, err, "ok" if ok else "MISMATCH"), flush=True)
     del A
     torch.cuda.empty_cache()

@@ -238,8 +238,9 @@ def test_c2_through_the_reference_entry_point_with_host_buffers():
     assert got["optval"] == want["optval"]
 
 
-def test_every_streaming_shape_and_type_once():
-    """One dense solver class (and code object) is built per streaming shape and arithmetic type
+@pytest.mark.parametrize("wide", [False, True])
+def test_every_streaming_shape_and_type_once(wide):
+    """(wide: m < n, transposed storage and the mirrored iteration.)  One dense solver class (and code object) is built per streaming shape and arithmetic type
     (stream.h: POGS_STREAM_PLANS + the windowed form).  Row lengths that select each of them in
     fp32 and in fp64; the two types run the same data on different shapes, so their agreement
     (status, iteration count, solution) checks both."""
@@ -247,10 +248,10 @@ def test_every_streaming_shape_and_type_once():
     pogs = _pogs()
     dev = torch.device("cuda:0")
     vprs = [60, 120, 250, 500, 760, 1000, 1270, 1500, 2000, 2500, 3000, 4000, 5000, 6000, 8000, 9000]
-    for n in sorted(set([2 * v for v in vprs] + [4 * v for v in vprs])):
-        m = n + 64
+    for k in sorted(set([2 * v for v in vprs] + [4 * v for v in vprs])):
+        m, n = (k, k + 64) if wide else (k + 64, k)
         g = torch.Generator(device=dev)
-        g.manual_seed(n)
+        g.manual_seed(k)
         A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float64)
         xt = torch.randn(n, generator=g, device=dev, dtype=torch.float64) * (torch.rand(n, generator=g, device=dev) < 0.05)
         b = A @ xt + 0.1 * torch.randn(m, generator=g, device=dev, dtype=torch.float64)
