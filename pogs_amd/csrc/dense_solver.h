@@ -99,9 +99,10 @@ class DenseSolver final : public SolverBase {
               const PogsAmdDist *dist) {
     const double t0 = wall_s();
     // The first launch of a kernel of this translation unit makes the runtime load its code
-    // object (~4 MB, ~13 ms, once per process).  A helper thread asks for a kernel's attributes
-    // right away, so that load overlaps the stream creation and the upload of A instead of
-    // sitting in front of the first pass.  (POGS_AMD_PRELOAD=0: off.)
+    // object (once per process; ~2 ms now that there is one ~0.8 MB object per streaming shape).
+    // POGS_AMD_PRELOAD=1: a helper thread asks for a kernel's attributes right away, so that the
+    // load overlaps the stream creation and the upload of A.  Off by default: with the small
+    // objects it saves ~2 ms, not worth a second thread inside the runtime.
     struct Joiner {
       std::thread t;
       ~Joiner() { if (t.joinable()) t.join(); }
@@ -110,7 +111,7 @@ class DenseSolver final : public SolverBase {
       const char *pe = std::getenv("POGS_AMD_PRELOAD");
       int dev = opt ? opt->device : -1;
       if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = -1;
-      if (!(pe && pe[0] == '0') && dev >= 0)
+      if (pe && pe[0] == '1' && dev >= 0)
         preload.t = std::thread([dev] {
           hipFuncAttributes fa;
           if (hipSetDevice(dev) != hipSuccess) return;

@@ -249,6 +249,8 @@ def test_every_streaming_shape_and_type_once(wide):
     dev = torch.device("cuda:0")
     vprs = [60, 120, 250, 500, 760, 1000, 1270, 1500, 2000, 2500, 3000, 4000, 5000, 6000, 8000, 9000]
     for k in sorted(set([2 * v for v in vprs] + [4 * v for v in vprs])):
+        if wide and k > 24000:
+            continue   # the two largest only repeat the windowed form, which 18000+ covers in fp64
         m, n = (k, k + 64) if wide else (k + 64, k)
         g = torch.Generator(device=dev)
         g.manual_seed(k)
