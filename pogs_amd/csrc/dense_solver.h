@@ -889,6 +889,7 @@ class DenseSolver final : public SolverBase {
           const int npad = static_cast<int>(round_up(k_, tile));
           DevBuf<unsigned char> img(static_cast<size_t>(2) * (4 * urows) * npad * 2);
           unsigned char *H = img.p, *L = img.p + static_cast<size_t>(4 * urows) * npad * 2;
+          ctx_.tmark("  gram: images allocated");
           GramF16PArgs gp{H, L, npad, k_, reinterpret_cast<float *>(G), ld, 4, urows, slab, 0, g.tile_map, scale16};
           gp.tile = tile;
           gp.flush_rows = kRows;
