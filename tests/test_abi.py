@@ -67,3 +67,24 @@ def test_every_part1_entry_cites_the_reference_interface():
     for n in ("PogsD", "PogsS", "PogsSparseD", "PogsSparseS"):
         i = HEADER.index("int %s(" % n)
         assert "replaces: src/interface_c/pogs_c.h" in HEADER[max(0, i - 400):i]
+
+
+def test_one_dense_solver_factory_per_streaming_shape_and_type():
+    """csrc/stream.h lists the streaming shapes (POGS_STREAM_PLANS); pogs_amd/build.py compiles
+    dense_plan.hip once per shape and arithmetic type, plus the windowed form, and abi.hip picks
+    the factory from the shape.  Every one of them has to be in the library."""
+    import re
+    import subprocess
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    text = open(os.path.join(root, "pogs_amd", "csrc", "stream.h")).read()
+    body = text[text.index("#define POGS_STREAM_PLANS(X)"):]
+    body = body[:body.index("\n//")]
+    shapes = re.findall(r"X\((\d+),\s*(\d+)\)", body)
+    assert len(shapes) >= 10
+    lib = os.path.join(root, "pogs_amd", "libpogs_amd.so")
+    syms = subprocess.run(["nm", "-C", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    for t in ("f32", "f64"):
+        for tpb, nv in shapes:
+            assert "make_dense_solver_%s_p%s_%s(" % (t, tpb, nv) in syms, (t, tpb, nv)
+        assert "make_dense_solver_%s_xl(" % t in syms, t
