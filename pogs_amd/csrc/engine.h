@@ -195,13 +195,20 @@ struct Ctx {
       launch_publish_scalars(S.p, kNumSlots, S_host_dev, reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots),
                              want, stream);
     }
-    unsigned spins = 0;
+    unsigned spins = 0, idle_seen = 0;
     while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != want) {
       if (++spins == (1u << 14)) {   // ~ every few hundred microseconds: surface a failed stream
         spins = 0;
         const hipError_t q = hipStreamQuery(stream);
         if (q == hipSuccess) {
           if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == want) break;
+          // the stream is idle (so the block on the device is final) but the word has not
+          // shown up in the mirror: never spin on that -- copy the block and stop polling
+          if (++idle_seen >= 3) {
+            POGS_HIP_CHECK(hipMemcpy(S_host.p, S.p, kNumSlots * sizeof(double), hipMemcpyDeviceToHost));
+            poll_fetch = false;
+            return S_host.p;
+          }
         } else if (q != hipErrorNotReady) {
           POGS_HIP_CHECK(q);
         }
