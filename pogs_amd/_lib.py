@@ -60,6 +60,7 @@ class PogsAmdStats(ctypes.Structure):
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
         d["spec_hits"], d["spec_misses"] = self.reserved[0], self.reserved[1]
+        d["collectives"] = int(self.reserved[2])   # all-reduce calls issued by the handle so far
         return d
 
 

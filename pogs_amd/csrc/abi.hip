@@ -255,6 +255,7 @@ int PogsAmdCreateDense(PogsAmdSolver **out, int dtype, enum ORD ord, size_t m, s
                        const PogsAmdOptions *opt, const PogsAmdDist *dist) {
   return guarded([&]() {
     *out = nullptr;
+    DeviceGuard guard(opt ? opt->device : -1);   // the caller's current device is put back on exit
     std::unique_ptr<PogsAmdSolver> h(new PogsAmdSolver);
     h->impl.reset(make_dense_solver(dtype, ord, m, n, A, mem, opt, dist));
     *out = h.release();
@@ -267,6 +268,7 @@ int PogsAmdCreateSparse(PogsAmdSolver **out, int dtype, enum ORD ord, size_t m, 
                         const PogsAmdDist *dist) {
   return guarded([&]() {
     *out = nullptr;
+    DeviceGuard guard(opt ? opt->device : -1);
     std::unique_ptr<PogsAmdSolver> h(new PogsAmdSolver);
     h->impl.reset(make_sparse_solver(dtype, ord, m, n, nnz, data, ptr, ind, mem, opt, dist));
     *out = h.release();
@@ -281,6 +283,7 @@ int PogsAmdSolve(PogsAmdSolver *s, const void *f_a, const void *f_b, const void 
                  void *l, void *mu, double *optval, unsigned int *final_iter) {
   return guarded([&]() {
     POGS_CHECK(s && s->impl, "null solver");
+    DeviceGuard guard(s->impl->device());
     FnHost f{f_a, f_b, f_c, f_d, f_e, f_h};
     FnHost g{g_a, g_b, g_c, g_d, g_e, g_h};
     return s->impl->solve(f, g, make_params(rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop), x,
@@ -294,6 +297,7 @@ int PogsAmdBeginRun(PogsAmdSolver *s, const void *f_a, const void *f_b, const vo
                     unsigned int max_iter, int adaptive_rho, int gap_stop) {
   return guarded([&]() {
     POGS_CHECK(s && s->impl, "null solver");
+    DeviceGuard guard(s->impl->device());
     FnHost f{f_a, f_b, f_c, f_d, f_e, f_h};
     FnHost g{g_a, g_b, g_c, g_d, g_e, g_h};
     s->impl->begin_run(f, g, make_params(rho, abs_tol, rel_tol, max_iter, 0, adaptive_rho, gap_stop));
@@ -304,6 +308,7 @@ int PogsAmdBeginRun(PogsAmdSolver *s, const void *f_a, const void *f_b, const vo
 int PogsAmdIterate(PogsAmdSolver *s, unsigned int iters, double *seconds, unsigned int *solves_completed) {
   return guarded([&]() {
     POGS_CHECK(s && s->impl, "null solver");
+    DeviceGuard guard(s->impl->device());
     s->impl->iterate(iters, seconds, solves_completed);
     return 0;
   });
@@ -312,6 +317,7 @@ int PogsAmdIterate(PogsAmdSolver *s, unsigned int iters, double *seconds, unsign
 int PogsAmdSetWarmStart(PogsAmdSolver *s, const void *x0, const void *l0) {
   return guarded([&]() {
     POGS_CHECK(s && s->impl && x0 && l0, "warm start needs both x0 and l0 (pogs.cpp:159-179)");
+    DeviceGuard guard(s->impl->device());
     s->impl->set_warm_start(x0, l0);
     return 0;
   });
@@ -328,6 +334,7 @@ int PogsAmdGetStats(const PogsAmdSolver *s, PogsAmdStats *out) {
 int PogsAmdResetStats(PogsAmdSolver *s) {
   return guarded([&]() {
     POGS_CHECK(s && s->impl, "null solver");
+    DeviceGuard guard(s->impl->device());
     PogsAmdStats &st = s->impl->stats();
     st.t_loop_s = 0; st.iterations = 0; st.exact_iters = 0; st.rho_updates = 0;
     st.cg_iters = 0; st.matvecs = 0;
@@ -338,7 +345,11 @@ int PogsAmdResetStats(PogsAmdSolver *s) {
 }
 
 void PogsAmdDestroy(PogsAmdSolver *s) {
-  try { delete s; } catch (...) {}
+  try {
+    if (!s) return;
+    DeviceGuard guard(s->impl ? s->impl->device() : -1);   // buffers are freed on the handle's device
+    delete s;
+  } catch (...) {}
 }
 
 const char *PogsAmdLastError(void) { return g_last_error.c_str(); }
@@ -364,6 +375,7 @@ int PogsAmdFuncEval(int dtype, size_t n, const int *h, const void *a, const void
 int PogsAmdGetEquil(const PogsAmdSolver *s, void *A_eq, void *d, void *e, double *nrmA) {
   return guarded([&]() {
     POGS_CHECK(s && s->impl, "null solver");
+    DeviceGuard guard(s->impl->device());
     const_cast<PogsAmdSolver *>(s)->impl->get_equil(A_eq, d, e, nrmA);
     return 0;
   });
@@ -372,6 +384,7 @@ int PogsAmdGetEquil(const PogsAmdSolver *s, void *A_eq, void *d, void *e, double
 int PogsAmdProject(PogsAmdSolver *s, const void *x0, const void *y0, double tol, void *x, void *y) {
   return guarded([&]() {
     POGS_CHECK(s && s->impl, "null solver");
+    DeviceGuard guard(s->impl->device());
     s->impl->project(x0, y0, tol, x, y);
     return 0;
   });
@@ -380,6 +393,7 @@ int PogsAmdProject(PogsAmdSolver *s, const void *x0, const void *y0, double tol,
 int PogsAmdMul(PogsAmdSolver *s, char trans, double alpha, const void *x, double beta, void *y) {
   return guarded([&]() {
     POGS_CHECK(s && s->impl, "null solver");
+    DeviceGuard guard(s->impl->device());
     s->impl->mul(trans, alpha, x, beta, y);
     return 0;
   });

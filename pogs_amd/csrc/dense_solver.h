@@ -22,6 +22,7 @@
 
 #include "cg_kernels.h"
 #include "engine.h"
+#include "fused_cols.h"
 #include "gemm.h"
 #include "ops.h"
 #include "reduce.h"
@@ -170,6 +171,7 @@ class DenseSolver final : public SolverBase {
   }
 
   int dtype() const override { return sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64; }
+  int device() const override { return ctx_.device; }
   PogsAmdStats &stats() override { return ctx_.stats; }
 
   int solve(const FnHost &f, const FnHost &g, const SolveParams &p, void *x, void *y, void *l, void *mu,
@@ -180,8 +182,7 @@ class DenseSolver final : public SolverBase {
     apply_warm_start();
     ctx_.sync();
     const double t1 = wall_s();
-    if (p.verbose > 1 && ctx_.dist.rank() == 0)
-      std::printf(" Iter | pri res | pri tol | dua res | dua tol |   gap   | eps gap\n");
+    if (ctx_.dist.rank() == 0) print_banner(p.verbose);
     while (!iteration(p.verbose)) {}
     ctx_.sync();
     const double t2 = wall_s();
@@ -195,9 +196,11 @@ class DenseSolver final : public SolverBase {
     st.rho_updates = ctl_.rho_updates;
     st.rho_final = ctl_.rho;
     collect_stream_timer();
-    if (p.verbose > 0 && ctx_.dist.rank() == 0)
-      std::printf("POGS-AMD dense/direct: status %d, iter %u, init %.3e s, loop %.3e s\n", status, ctl_.k,
-                  st.t_init_s, st.t_loop_s);
+    if (p.verbose > 0 && ctx_.dist.rank() == 0) {
+      print_summary(status, st.t_total_s, st.t_init_s, ctl_);
+      std::printf("POGS-AMD dense/%s: status %d, iter %u, init %.3e s, loop %.3e s\n", use_cgls_ ? "cgls" : "direct",
+                  status, ctl_.k, st.t_init_s, st.t_loop_s);
+    }
     return status;
   }
 
@@ -215,6 +218,7 @@ class DenseSolver final : public SolverBase {
   }
 
   void iterate(unsigned iters, double *seconds, unsigned *solves) override {
+    POGS_CHECK(loaded_, "PogsAmdIterate before PogsAmdBeginRun / PogsAmdSolve: no problem is loaded");
     unsigned done = 0;
     ctx_.sync();
     const double t0 = wall_s();
@@ -392,8 +396,10 @@ class DenseSolver final : public SolverBase {
       x12s_.zero(s); xtemps_.zero(s);
     } else if (fused_ok_) {
       colpart2_.alloc(static_cast<size_t>(planA_.grid_max) * np);
-      pair_.alloc(2 * np);
-      pair_.zero(s);
+      if (multi_) {   // [A^T yhat | exact-dual-residual sums | 6 scalars] in fp64: one all-reduce per iteration
+        pack_.alloc(2 * np + 8);
+        pack_.zero(s);
+      }
       y12s_.alloc(m_); ytemps_.alloc(m_);
       y12s_.zero(s); ytemps_.zero(s);
     }
@@ -402,8 +408,8 @@ class DenseSolver final : public SolverBase {
     // their own because that iteration sums everything in its closing launch (Ctx::queue_sum)
     const size_t vb = vec_blocks(n_) + vec_blocks(m_);
     const size_t r01 = static_cast<size_t>(planA_.grid_max) * 6 + std::max<size_t>(4096, vb * 3 + 64);
-    sp_pre_off_ = r01;
-    sp_tail_off_ = r01 + vb * 3 + 64;
+    sp_pre_off_ = r01;   // [y-half prox sums: vec_blocks(m) x 3 | pre_cols sums: column blocks x 4]
+    sp_tail_off_ = r01 + vb * 3 + static_cast<size_t>(reduce_cols_grid(n_pad_, Vec16<T>::N)) * 4 + 64;
     ctx_.ensure_spart(sp_tail_off_ + static_cast<size_t>(ctx_.num_cu) * 32);
   }
 
@@ -1086,6 +1092,8 @@ class DenseSolver final : public SolverBase {
     };
     up(f_, f, m_);
     up(g_, g, n_);
+    warn_negative_coeffs<T>(f, m_);   // prox_lib.h:62-69 (the clamp is in scale_objective_kernel)
+    warn_negative_coeffs<T>(g, n_);
     // the one-pass kernel evaluates prox_f inline: only for the cheap base functions
     bool all_cheap = true, all_logistic = true;
     if (tmode_) {   // transposed storage: it is prox_g that runs inside the pass
@@ -1111,6 +1119,7 @@ class DenseSolver final : public SolverBase {
     ctl_.rho0 = static_cast<T>(p.rho);
     ctl_.m_glob = ctx_.m_global;
     ctl_.n = n_;
+    loaded_ = true;
     ctx_.sync();  // the host coefficient arrays may be freed by the caller afterwards
   }
   FnView<T> fview() const { return FnView<T>{f_.h.p, fs_.a.p, f_.b.p, fs_.c.p, fs_.d.p, fs_.e.p}; }
@@ -1258,10 +1267,7 @@ class DenseSolver final : public SolverBase {
       exact = true;
     }
     const bool stop = ctl_.check_stop(exact);
-    if (verbose > 1 && ctx_.dist.rank() == 0 &&
-        ((verbose > 2 && ctl_.k % 10 == 0) || ctl_.k % 100 == 0 || ctl_.converged))
-      std::printf("%5u : %.2e  %.2e  %.2e  %.2e  %.2e  %.2e\n", ctl_.k, (double)ctl_.nrm_r, (double)ctl_.eps_pri,
-                  (double)ctl_.nrm_s, (double)ctl_.eps_dua, (double)ctl_.gap, (double)ctl_.eps_gap);
+    log_iteration(verbose);
     if (stop) return true;
     // (4) dual update already sits in xtemp/ytemp (ProjTailOp): swap roles.
     std::swap(xt_, xtemp_);
@@ -1281,75 +1287,73 @@ class DenseSolver final : public SolverBase {
   bool iteration_fused(unsigned verbose) {
     hipStream_t s = ctx_.stream;
     const int nw = cur_ ^ 1;
-    const int bx = vec_blocks(n_), by = vec_blocks(m_);
-    // single GPU: every scalar sum of the iteration runs in the launch that publishes the scalar
-    // block (row shards need the sums on the device before their collectives)
+    const int by = vec_blocks(m_);
+    const int gridC = reduce_cols_grid(n_pad_, Vec16<T>::N);
+    // every scalar sum of the iteration that needs no exchange runs in the launch that publishes
+    // the scalar block; on row shards the y-side sums travel in the tail of the pack buffer
     struct DeferGuard {
       bool &flag;
       DeferGuard(bool &f, bool on) : flag(f) { flag = on; }
       ~DeferGuard() { flag = false; }
-    } defer_guard(defer_sums_, !multi_ && defer_allowed());
+    } defer_guard(defer_sums_, defer_allowed());
     const bool spec = spec_valid_;
-    // (A) prox / over-relaxation: x half always, y half unless already speculated
-    AdmmPreArgs<T> pa;
-    pa.n_x = n_; pa.n_y = spec_valid_ ? 0 : m_;
-    pa.g = gview(); pa.f = fview();
-    pa.x_cur = x_[cur_].p; pa.y_cur = y_[cur_].p;
-    pa.xt = xt_.p; pa.yt = yt_.p;
-    pa.zt_scale = zt_scale_;
-    pa.x12 = x12_.p; pa.y12 = y12_.p;
-    pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
-    pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
-    pa.partials = ctx_.spart.p + sp_pre_off_;
-    pa.blocks_x = bx;
-    launch_admm_pre<T>(pa, s);
-    {
-      SumJob j[2] = {{pa.partials, bx, 3, ctx_.S.p + kGapX},
-                     {pa.partials + static_cast<size_t>(bx) * 3, by, 3, ctx_.S.p + kGapY}};
-      if (defer_sums_) {
-        ctx_.queue_sum(j[0]);
-        if (!spec) ctx_.queue_sum(j[1]);
-      } else {
-        launch_sum_jobs(j, spec ? 1 : 2, s);
-      }
-    }
-    int nparts;
-    if (spec_valid_) {
-      // the y-half sums of this iteration came with the previous pass (kSpecGapY, already on the
-      // host -- and all-reduced on row shards): spec_gap_ stands in for kGapY after the fetch
-      nparts = stream2_grid<2>(planA_, m_);
-    } else {
-      // (B) column sums A^T yhat_k and A^T (y12 + c yt - yprev)
+    double *pre_part = ctx_.spart.p + sp_pre_off_;              // [by][3] y-half prox sums (non-speculated iterations)
+    double *pc_part = pre_part + static_cast<size_t>(by) * 3;    // [gridC][4] pre_cols sums
+    double *tail = pack_.p ? pack_.p + 2 * static_cast<size_t>(n_pad_) : nullptr;   // row shards: 6 scalars
+    const size_t pack_count = 2 * static_cast<size_t>(n_pad_) + 6;
+    int nparts = stream2_grid<2>(planA_, m_);
+    if (!spec) {
+      // (A') y half of the prox / over-relaxation, then (B) the column sums A^T yhat_k and
+      // A^T (y12 + c yt - yprev) in a pass of their own -- a speculated iteration has both from
+      // the previous pass (and its y-half sums on the host: spec_gap_ stands in for kGapY)
+      AdmmPreArgs<T> pa;
+      pa.n_x = 0; pa.n_y = m_;
+      pa.g = gview(); pa.f = fview();
+      pa.x_cur = x_[cur_].p; pa.y_cur = y_[cur_].p;
+      pa.xt = xt_.p; pa.yt = yt_.p;
+      pa.zt_scale = zt_scale_;
+      pa.x12 = x12_.p; pa.y12 = y12_.p;
+      pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
+      pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
+      pa.partials = pre_part;
+      pa.blocks_x = 0;
+      launch_admm_pre<T>(pa, s);
+      const SumJob jy{pre_part, by, 3, ctx_.S.p + kGapY};
       StreamArgs2<T> a2{A_.p, lda_, m_, n_pad_, nullptr, nullptr, colpart_.p, colpart2_.p, ctx_.spart.p};
       ctx_.stream_timer.begin(s);
       launch_stream2<T, 0, 2, Tag>(planA_, a2, PreAccOp<T>{ytemp_.p, y12_.p, yt_.p, y_[cur_].p, zt_scale_}, s);
       ctx_.stream_timer.end(s);
       nparts = stream2_grid<0>(planA_, m_);
       ctx_.stats.matvecs += 1;
-    }
-    // (C) x = (G + I)^{-1} (xtemp + A^T yhat); exact dual residual from the second sums
-    if (!multi_) {
-      finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, 0, 0, nparts, colpart_.p);
-      finish_cols(ExactColOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_, n_}, ctx_.S.p + kExactS2, 0, 0, nparts,
-                  colpart2_.p);
-    } else {
-      // row shards: both n-vectors and the three gap/norm sums travel in ONE RCCL group -- when
-      // the iteration was speculated they already crossed the links with the previous pass's
-      // residual sums (end of (D)), so a speculated iteration has a single collective
-      double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
-      T *both = pair_.p;
-      if (!spec_valid_) {
-        launch_reduce_cols<T, StoreColOp<T>>(colpart_.p, nparts, n_pad_, StoreColOp<T>{1, 0, both, n_}, sp, s);
-        launch_reduce_cols<T, StoreColOp<T>>(colpart2_.p, nparts, n_pad_, StoreColOp<T>{1, 0, both + n_pad_, n_}, sp,
-                                             s);
-        ctx_.dist.allreduce2<T>(both, 2 * static_cast<size_t>(n_pad_), ctx_.S.p + kGapY, 3, s);
+      if (!multi_) {
+        sum_now_or_later(jy);
+      } else {
+        PackJobs pj;
+        pj.j[0] = jy; pj.j[1] = jy; pj.njobs = 1;
+        launch_pack_cols<T>(colpart_.p, colpart2_.p, nparts, n_pad_, pack_.p, pj, s);
+        ctx_.dist.allreduce(pack_.p, pack_count, s);
+        ScalarOverlay ov;
+        ov.src = tail; ov.slot[0] = kGapY; ov.n[0] = 3;
+        launch_apply_overlay(ctx_.S.p, ov, s);   // the pack buffer is reused before this iteration's fetch
       }
-      launch_reduce_cols<T, StoreColOp<T>>(both, 1, n_pad_, StoreColOp<T>{1, 0, rhs_.p, n_}, sp, s);
-      launch_reduce_cols<T, ExactColOp<T>>(both + n_pad_, 1, n_pad_,
-                                           ExactColOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_, n_}, sp, s);
-      SumJob j{sp, reduce_cols_grid(n_pad_, Vec16<T>::N), 1, ctx_.S.p + kExactS2};
-      launch_sum_jobs(&j, 1, s);
     }
+    // (C) ONE launch for the column side: both second stages, the x half of the prox, the exact
+    // dual residual (fused_cols.h)
+    {
+      PreColsArgs<T> pc;
+      pc.part0 = colpart_.p; pc.part1 = colpart2_.p; pc.nparts = nparts;
+      pc.tot64 = pack_.p;
+      pc.n = n_; pc.n_pad = n_pad_;
+      pc.g = gview();
+      pc.x_cur = x_[cur_].p; pc.xt = xt_.p;
+      pc.zt_scale = zt_scale_; pc.rho = ctl_.rho; pc.alpha = ctl_.alpha();
+      pc.x12 = x12_.p; pc.xtemp = xtemp_.p; pc.rhs = rhs_.p;
+      pc.partials = pc_part;
+      launch_pre_cols<T>(pc, multi_, s);
+      sum_now_or_later(SumJob{pc_part, gridC, 3, ctx_.S.p + kGapX, 4, 0});
+      sum_now_or_later(SumJob{pc_part, gridC, 1, ctx_.S.p + kExactS2, 4, 3});
+    }
+    // x = (G + I)^{-1} (xtemp + A^T yhat)
     if (w_onepass())
       solve_gram_onepass(rhs_.p, xtemp_.p, ProjTailSumColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_},
                          ctx_.S.p + kDXprev2);
@@ -1373,23 +1377,24 @@ class DenseSolver final : public SolverBase {
       }
       ctx_.stream_timer.end(s);
       const int grid = stream2_grid<2>(planA_, m_);
-      SumJob j[2] = {{ctx_.spart.p, grid, 3, ctx_.S.p + kDYprev2, 6, 0},
-                     {ctx_.spart.p, grid, 3, ctx_.S.p + kSpecGapY, 6, 3}};
-      if (defer_sums_) {
-        ctx_.queue_sum(j[0]);
-        ctx_.queue_sum(j[1]);
+      const SumJob jd{ctx_.spart.p, grid, 3, ctx_.S.p + kDYprev2, 6, 0};
+      const SumJob js{ctx_.spart.p, grid, 3, ctx_.S.p + kSpecGapY, 6, 3};
+      if (!multi_) {
+        sum_now_or_later(jd);
+        sum_now_or_later(js);
       } else {
-        launch_sum_jobs(j, 2, s);
-      }
-      if (multi_) {
-        // this iteration's y-residual sums, and the speculative column sums / y-half sums of the
-        // next one, in one group
-        double *sp = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
-        T *both = pair_.p;
-        launch_reduce_cols<T, StoreColOp<T>>(colpart_.p, grid, n_pad_, StoreColOp<T>{1, 0, both, n_}, sp, s);
-        launch_reduce_cols<T, StoreColOp<T>>(colpart2_.p, grid, n_pad_, StoreColOp<T>{1, 0, both + n_pad_, n_}, sp, s);
-        ctx_.dist.allreduce3<T>(both, 2 * static_cast<size_t>(n_pad_), ctx_.S.p + kDYprev2, 3,
-                                ctx_.S.p + kSpecGapY, 3, s);
+        // ONE collective per iteration: this iteration's y-residual sums, the speculative column
+        // sums and y-half sums of the next one -- a single fp64 buffer, one ncclAllReduce; the
+        // scalars reach the host through the publishing launch (ScalarOverlay)
+        PackJobs pj;
+        pj.j[0] = jd; pj.j[1] = js; pj.njobs = 2;
+        launch_pack_cols<T>(colpart_.p, colpart2_.p, grid, n_pad_, pack_.p, pj, s);
+        ctx_.dist.allreduce(pack_.p, pack_count, s);
+        ScalarOverlay ov;
+        ov.src = tail;
+        ov.slot[0] = kDYprev2; ov.n[0] = 3;
+        ov.slot[1] = kSpecGapY; ov.n[1] = 3;
+        ctx_.set_overlay(ov);
       }
       ctx_.stats.matvecs += 1;
     }
@@ -1405,10 +1410,7 @@ class DenseSolver final : public SolverBase {
       exact = true;
     }
     const bool stop = ctl_.check_stop(exact);
-    if (verbose > 1 && ctx_.dist.rank() == 0 &&
-        ((verbose > 2 && ctl_.k % 10 == 0) || ctl_.k % 100 == 0 || ctl_.converged))
-      std::printf("%5u : %.2e  %.2e  %.2e  %.2e  %.2e  %.2e\n", ctl_.k, (double)ctl_.nrm_r, (double)ctl_.eps_pri,
-                  (double)ctl_.nrm_s, (double)ctl_.eps_dua, (double)ctl_.gap, (double)ctl_.eps_gap);
+    log_iteration(verbose);
     if (stop) return true;
     std::swap(xt_, xtemp_);
     std::swap(yt_, ytemp_);            // yt = ytilde_{k+1}
@@ -1513,9 +1515,7 @@ class DenseSolver final : public SolverBase {
       exact = true;
     }
     const bool stop = ctl_.check_stop(exact);
-    if (verbose > 1 && ((verbose > 2 && ctl_.k % 10 == 0) || ctl_.k % 100 == 0 || ctl_.converged))
-      std::printf("%5u : %.2e  %.2e  %.2e  %.2e  %.2e  %.2e\n", ctl_.k, (double)ctl_.nrm_r, (double)ctl_.eps_pri,
-                  (double)ctl_.nrm_s, (double)ctl_.eps_dua, (double)ctl_.gap, (double)ctl_.eps_gap);
+    log_iteration(verbose);
     if (stop) return true;
     std::swap(xt_, xtemp_);            // xt = xtilde_{k+1}
     std::swap(yt_, ytemp_);
@@ -1532,6 +1532,29 @@ class DenseSolver final : public SolverBase {
     }
     ++ctl_.k;
     return false;
+  }
+
+  // sum f(y12) + sum g(x12) at the current prox point (pogs.cpp:385, 473)
+  double eval_objective() {
+    hipStream_t s = ctx_.stream;
+    const int by = vec_blocks(m_), bx = vec_blocks(n_);
+    const bool was_deferring = defer_sums_;
+    defer_sums_ = false;
+    launch_func_eval<T>(m_, fview(), y12_.p, ctx_.spart.p, s);
+    launch_func_eval<T>(n_, gview(), x12_.p, ctx_.spart.p + by, s);
+    SumJob j[2] = {{ctx_.spart.p, by, 1, ctx_.S.p + kFvalF}, {ctx_.spart.p + by, bx, 1, ctx_.S.p + kFvalG}};
+    launch_sum_jobs(j, 2, s);
+    if (multi_) ctx_.dist.allreduce(ctx_.S.p + kFvalF, 1, s);
+    const double *S = ctx_.fetch_scalars();
+    defer_sums_ = was_deferring;
+    return static_cast<double>(static_cast<T>(S[kFvalF]) + static_cast<T>(S[kFvalG]));
+  }
+  // the reference's per-iteration line (pogs.cpp:382-388); every rank evaluates (the objective
+  // sum is a collective on row shards), rank 0 prints
+  void log_iteration(unsigned verbose) {
+    if (!wants_iter_line(verbose, ctl_)) return;
+    const double obj = eval_objective();
+    if (ctx_.dist.rank() == 0) print_iter_line(ctl_, obj);
   }
 
   // optval, status, un-scaling, copy out (pogs.cpp:473-482, 510-518, 567-570).
@@ -1556,10 +1579,14 @@ class DenseSolver final : public SolverBase {
     if (mu) POGS_HIP_CHECK(hipMemcpyAsync(mu, muout_.p, n_ * sizeof(T), hipMemcpyDeviceToHost, s));
     const double *S = ctx_.fetch_scalars();
     *optval = static_cast<double>(static_cast<T>(S[kFvalF]) + static_cast<T>(S[kFvalG]));
+    // the polled sequence word says the kernels are done; the D2H copies into the caller's
+    // (pageable) buffers are only guaranteed complete after a synchronizing call
+    POGS_HIP_CHECK(hipStreamSynchronize(s));
     return ctl_.status();
   }
 
   void collect_stream_timer() {
+    ctx_.stats.reserved[2] = static_cast<double>(ctx_.dist.collectives());   // all-reduce calls since creation
     if (!ctx_.stream_timer.enabled()) return;
     unsigned long long cnt = 0;
     ctx_.stats.stream_ms += ctx_.stream_timer.collect_ms(&cnt);
@@ -1584,7 +1611,8 @@ class DenseSolver final : public SolverBase {
   size_t lda_ = 0;
   StreamPlan planA_, planW_;
   T *Wp_ = nullptr, *Up_ = nullptr;   // views into fac_
-  DevBuf<T> A_, fac_, d_, e_, colpart_, colpart2_, pair_, y12s_, ytemps_;
+  DevBuf<T> A_, fac_, d_, e_, colpart_, colpart2_, y12s_, ytemps_;
+  DevBuf<double> pack_;         // row shards, one-pass iteration: the packed all-reduce buffer
   bool fused_ok_ = false, fused_now_ = false, fused_logistic_ = false, spec_valid_ = false;
   bool warm_pending_ = false;
   std::vector<T> warm_x_, warm_l_;
@@ -1593,6 +1621,7 @@ class DenseSolver final : public SolverBase {
   DevBuf<T> xout_, yout_, lout_, muout_;
   FnBuf<T> f_, g_, fs_, gs_;
   AdmmControl<T> ctl_;
+  bool loaded_ = false;   // load_problem has run: f, g and the control block are valid
   int cur_ = 0;
   T zt_scale_ = 1;
   T nrmA_ = 0;

@@ -9,12 +9,17 @@
 // (PyTorch ships its own copy) that instance is reused, so the library never
 // ends up with two RCCL / HIP runtimes in one address space.
 //
-// Test transport: a unique id that starts with "POGSLOCAL:" selects an in-process
-// communicator instead of RCCL -- the ranks are threads of one process (each with its
-// own solver, possibly on the same GPU), buffers are staged through the host and summed
-// in rank order.  It exists so that the row-sharded decomposition of the engine itself
-// can be verified on a single GPU (RCCL refuses two ranks on one device); it is not a
-// performance path.
+// One collective per exchange: a vector and the scalar sums that travel with it are packed
+// into one fp64 staging buffer (allreduce2 / allreduce3: pack kernel, ONE ncclAllReduce,
+// unpack kernel); the one-pass dense iteration fills its pack buffer straight from the producing
+// kernels and calls allreduce() on it (dense_solver.h).  No ncclGroupStart/End anywhere.
+//
+// Test transport (only with POGS_AMD_TEST_TRANSPORT=1 in the environment; otherwise such an id
+// is refused): a unique id that starts with "POGSLOCAL:" selects an in-process communicator
+// instead of RCCL -- the ranks are threads of one process (each with its own solver, possibly
+// on the same GPU), buffers are staged through the host and summed in rank order.  It exists
+// so that the row-sharded decomposition of the engine itself can be verified on a single GPU
+// (RCCL refuses two ranks on one device); it is not a performance path.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -40,12 +45,12 @@ class DistComm {
   // In-place sum all-reduce on `stream`.  No-ops when not initialised.
   void allreduce(float *buf, size_t count, hipStream_t stream) const;
   void allreduce(double *buf, size_t count, hipStream_t stream) const;
-  // Two buffers as one RCCL group (one launch).
+  // A vector and one / two scalar ranges as ONE all-reduce of a packed fp64 buffer.
   template <typename T>
-  void allreduce2(T *buf, size_t count, double *scalars, size_t nscalars, hipStream_t stream) const;
-  // One buffer and two scalar ranges as one group.
+  void allreduce2(T *buf, size_t count, double *scalars, size_t nscalars, hipStream_t stream);
   template <typename T>
-  void allreduce3(T *buf, size_t count, double *s1, size_t n1, double *s2, size_t n2, hipStream_t stream) const;
+  void allreduce3(T *buf, size_t count, double *s1, size_t n1, double *s2, size_t n2, hipStream_t stream);
+  unsigned long long collectives() const { return ncoll_; }   // all-reduce calls issued so far
 
   static void unique_id(char *out);  // fresh id (rank 0)
 
@@ -54,6 +59,9 @@ class DistComm {
   int rank_ = 0, world_ = 1;
   void *comm_ = nullptr;
   void *local_ = nullptr;   // std::shared_ptr<LocalGroup>* (test transport)
+  double *pack_ = nullptr;  // fp64 staging of allreduce2 / allreduce3 (device)
+  size_t pack_cap_ = 0;
+  mutable unsigned long long ncoll_ = 0;
 };
 
 }  // namespace pogs_amd

@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -29,8 +30,6 @@ struct RcclApi {
   int (*CommInitRank)(ncclComm_t *, int, UniqueId, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
 };
 
@@ -53,8 +52,6 @@ RcclApi &api() {
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
-    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
-    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
   });
   return a;
@@ -128,11 +125,36 @@ void local_allreduce(LocalGroup &g, int rank, T *buf, size_t count, hipStream_t 
 
 }  // namespace
 
+// pack: out[0..nv) = vec (as double), then the scalar ranges; unpack: the reverse
+template <typename T>
+__global__ void __launch_bounds__(256) pack_kernel(const T *vec, size_t nv, const double *s1, int n1, const double *s2,
+                                                   int n2, double *out) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < nv) out[i] = static_cast<double>(vec[i]);
+  if (blockIdx.x == 0) {
+    const int t = threadIdx.x;
+    if (t < n1) out[nv + t] = s1[t];
+    else if (t < n1 + n2) out[nv + t] = s2[t - n1];
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) unpack_kernel(const double *in, size_t nv, T *vec, double *s1, int n1, double *s2,
+                                                     int n2) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < nv) vec[i] = static_cast<T>(in[i]);
+  if (blockIdx.x == 0) {
+    const int t = threadIdx.x;
+    if (t < n1) s1[t] = in[nv + t];
+    else if (t < n1 + n2) s2[t - n1] = in[nv + t];
+  }
+}
+
 DistComm::~DistComm() {
   if (comm_) {
     try { api().CommDestroy(comm_); } catch (...) {}
   }
   delete static_cast<std::shared_ptr<LocalGroup> *>(local_);
+  if (pack_) (void)hipFree(pack_);
 }
 
 void DistComm::unique_id(char *out) {
@@ -146,6 +168,8 @@ void DistComm::init(int rank, int world, const char *unique_id) {
   rank_ = rank;
   world_ = world;
   if (std::strncmp(unique_id, kLocalTag, sizeof(kLocalTag) - 1) == 0) {
+    const char *tt = std::getenv("POGS_AMD_TEST_TRANSPORT");
+    POGS_CHECK(tt && tt[0] == '1', "the in-process test transport needs POGS_AMD_TEST_TRANSPORT=1");
     const std::string key(unique_id, strnlen(unique_id, kUniqueIdBytes));
     local_ = new std::shared_ptr<LocalGroup>(local_group(key, world));
     return;
@@ -156,13 +180,14 @@ void DistComm::init(int rank, int world, const char *unique_id) {
 }
 
 void DistComm::reduce_raw(void *buf, size_t count, int dtype, hipStream_t stream) const {
-  if (local_ && count > 0) {
+  if (count == 0 || !active()) return;
+  ++ncoll_;
+  if (local_) {
     LocalGroup &g = **static_cast<std::shared_ptr<LocalGroup> *>(local_);
     if (dtype == kNcclFloat) local_allreduce(g, rank_, static_cast<float *>(buf), count, stream);
     else local_allreduce(g, rank_, static_cast<double *>(buf), count, stream);
     return;
   }
-  if (!comm_ || count == 0) return;
   check(api().AllReduce(buf, buf, count, dtype, kNcclSum, comm_, stream), "ncclAllReduce");
 }
 
@@ -174,37 +199,31 @@ void DistComm::allreduce(double *buf, size_t count, hipStream_t stream) const {
 }
 
 template <typename T>
-void DistComm::allreduce2(T *buf, size_t count, double *scalars, size_t nscalars, hipStream_t stream) const {
-  if (local_) {
-    allreduce(buf, count, stream);
-    allreduce(scalars, nscalars, stream);
-    return;
+void DistComm::allreduce3(T *buf, size_t count, double *s1, size_t n1, double *s2, size_t n2, hipStream_t stream) {
+  if (!active()) return;
+  POGS_CHECK(n1 + n2 <= 256, "allreduce3: too many scalars");
+  const size_t total = count + n1 + n2;
+  if (total > pack_cap_) {
+    POGS_HIP_CHECK(hipStreamSynchronize(stream));
+    if (pack_) POGS_HIP_CHECK(hipFree(pack_));
+    pack_ = nullptr;
+    POGS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&pack_), total * sizeof(double)));
+    pack_cap_ = total;
   }
-  if (!comm_) return;
-  check(api().GroupStart(), "ncclGroupStart");
-  allreduce(buf, count, stream);
-  allreduce(scalars, nscalars, stream);
-  check(api().GroupEnd(), "ncclGroupEnd");
+  const unsigned grid = static_cast<unsigned>((count + 255) / 256) + (count == 0 ? 1u : 0u);
+  hipLaunchKernelGGL(pack_kernel<T>, dim3(grid), dim3(256), 0, stream, buf, count, s1, static_cast<int>(n1), s2,
+                     static_cast<int>(n2), pack_);
+  allreduce(pack_, total, stream);
+  hipLaunchKernelGGL(unpack_kernel<T>, dim3(grid), dim3(256), 0, stream, pack_, count, buf, s1, static_cast<int>(n1), s2,
+                     static_cast<int>(n2));
 }
 template <typename T>
-void DistComm::allreduce3(T *buf, size_t count, double *s1, size_t n1, double *s2, size_t n2,
-                          hipStream_t stream) const {
-  if (local_) {
-    allreduce(buf, count, stream);
-    allreduce(s1, n1, stream);
-    allreduce(s2, n2, stream);
-    return;
-  }
-  if (!comm_) return;
-  check(api().GroupStart(), "ncclGroupStart");
-  allreduce(buf, count, stream);
-  allreduce(s1, n1, stream);
-  allreduce(s2, n2, stream);
-  check(api().GroupEnd(), "ncclGroupEnd");
+void DistComm::allreduce2(T *buf, size_t count, double *scalars, size_t nscalars, hipStream_t stream) {
+  allreduce3<T>(buf, count, scalars, nscalars, nullptr, 0, stream);
 }
-template void DistComm::allreduce3<float>(float *, size_t, double *, size_t, double *, size_t, hipStream_t) const;
-template void DistComm::allreduce3<double>(double *, size_t, double *, size_t, double *, size_t, hipStream_t) const;
-template void DistComm::allreduce2<float>(float *, size_t, double *, size_t, hipStream_t) const;
-template void DistComm::allreduce2<double>(double *, size_t, double *, size_t, hipStream_t) const;
+template void DistComm::allreduce3<float>(float *, size_t, double *, size_t, double *, size_t, hipStream_t);
+template void DistComm::allreduce3<double>(double *, size_t, double *, size_t, double *, size_t, hipStream_t);
+template void DistComm::allreduce2<float>(float *, size_t, double *, size_t, hipStream_t);
+template void DistComm::allreduce2<double>(double *, size_t, double *, size_t, hipStream_t);
 
 }  // namespace pogs_amd

@@ -25,6 +25,29 @@ inline double wall_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// HIP's current device is per thread: every extern "C" entry that touches a handle selects the
+// handle's device for its duration and puts the caller's device back on exit (a handle may be
+// used from another thread, or after the caller -- e.g. torch -- switched devices).
+class DeviceGuard {
+ public:
+  explicit DeviceGuard(int dev) {
+    if (dev < 0) return;
+    if (hipGetDevice(&prev_) != hipSuccess) { prev_ = -1; }
+    if (prev_ != dev) {
+      POGS_HIP_CHECK(hipSetDevice(dev));
+      restore_ = prev_ >= 0;
+    }
+  }
+  ~DeviceGuard() {
+    if (restore_) (void)hipSetDevice(prev_);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+ private:
+  int prev_ = -1;
+  bool restore_ = false;
+};
+
 // HIP-event stopwatch for kernels launched on one stream (profile mode only).
 class EventTimer {
  public:
@@ -178,9 +201,14 @@ struct Ctx {
     if (npending) launch_sum_jobs(pending, npending, stream);
     npending = 0;
   }
+  // scalars that the next fetch takes from a packed all-reduce buffer (consumed by that fetch)
+  void set_overlay(const ScalarOverlay &ov) { overlay = ov; }
   const double *fetch_scalars() {
+    const ScalarOverlay ov = overlay;
+    overlay = ScalarOverlay();
     if (!poll_fetch) {
       flush_sums();
+      launch_apply_overlay(S.p, ov, stream);
       POGS_HIP_CHECK(hipMemcpyAsync(S_host.p, S.p, kNumSlots * sizeof(double), hipMemcpyDeviceToHost, stream));
       POGS_HIP_CHECK(hipStreamSynchronize(stream));
       return S_host.p;
@@ -189,11 +217,11 @@ struct Ctx {
     unsigned long long *seqp = reinterpret_cast<unsigned long long *>(S_host.p + kNumSlots);
     if (npending) {
       launch_sum_publish(pending, npending, S.p, kNumSlots, S_host_dev,
-                         reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots), want, pub_counter.p, stream);
+                         reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots), want, pub_counter.p, stream, ov);
       npending = 0;
     } else {
       launch_publish_scalars(S.p, kNumSlots, S_host_dev, reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots),
-                             want, stream);
+                             want, stream, ov);
     }
     unsigned spins = 0, idle_seen = 0;
     while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != want) {
@@ -220,6 +248,7 @@ struct Ctx {
     return S_host.p;
   }
   bool poll_fetch = true;
+  ScalarOverlay overlay;
   SumJob pending[kMaxSumJobs];
   int npending = 0;
   DevBuf<unsigned> pub_counter;
@@ -242,10 +271,14 @@ struct Ctx {
     tmark_last = wall_s();
   }
   double tmark_last = 0;
+  bool poisoned = false;   // set when an error left the stream / communicator in an unknown state
   ~Ctx() {
     if (!stream) return;
-    (void)hipStreamSynchronize(stream);
-    if (ctx_recycle()) {
+    DeviceGuard guard(device);
+    // a stream that faulted (or was left inside a failed collective) must not be handed to the
+    // next solver: recycle it only if it drains cleanly
+    const bool healthy = hipStreamSynchronize(stream) == hipSuccess && !poisoned;
+    if (ctx_recycle() && healthy) {
       std::lock_guard<std::mutex> lock(ctx_pool_mutex());
       CtxResources r;
       r.stream = stream;
@@ -398,6 +431,58 @@ struct AdmmControl {
   }
 };
 
+// ---- console output in the reference's format (src/cpu/pogs.cpp:26-27,185-196,382-388,485-500,
+// src/include/pogs.h:168-186), so that a caller parsing the reference's verbose output keeps working
+#define POGS_AMD_HBAR "----------------------------------------------------------------------------\n"
+inline const char *status_string(int st) {
+  switch (st) {
+    case POGS_SUCCESS: return "Solved";
+    case POGS_UNBOUNDED: return "Unbounded";
+    case POGS_INFEASIBLE: return "Infeasible";
+    case POGS_MAX_ITER: return "Reached max iter";
+    case POGS_NAN_FOUND: return "Encountered NaN";
+    case POGS_INVALID_CONE: return "Invalid cone found";
+    default: return "Error";
+  }
+}
+inline void print_banner(unsigned verbose) {
+  if (verbose > 0)
+    std::printf(POGS_AMD_HBAR
+                "           POGS v0.4.0 - Proximal Graph Solver (MI355X / HIP engine)\n"
+                "           graph-form ADMM of foges/pogs, rebuilt for gfx950\n");
+  if (verbose > 1)
+    std::printf(POGS_AMD_HBAR " Iter | pri res | pri tol | dua res | dua tol |   gap   | eps gap |"
+                " pri obj\n" POGS_AMD_HBAR);
+}
+template <typename T>
+inline bool wants_iter_line(unsigned verbose, const AdmmControl<T> &c) {
+  return (verbose > 2 && c.k % 10 == 0) || (verbose > 1 && c.k % 100 == 0) || (verbose > 1 && c.converged);
+}
+template <typename T>
+inline void print_iter_line(const AdmmControl<T> &c, double optval) {
+  std::printf("%5d : %.2e  %.2e  %.2e  %.2e  %.2e  %.2e % .2e\n", static_cast<int>(c.k), (double)c.nrm_r,
+              (double)c.eps_pri, (double)c.nrm_s, (double)c.eps_dua, (double)c.gap, (double)c.eps_gap, optval);
+}
+template <typename T>
+inline void print_summary(int status, double t_total, double t_init, const AdmmControl<T> &c) {
+  std::printf(POGS_AMD_HBAR
+              "Status: %s\n"
+              "Timing: Total = %3.2e s, Init = %3.2e s\n"
+              "Iter  : %u\n",
+              status_string(status), t_total, t_init, c.k);
+  std::printf(POGS_AMD_HBAR
+              "Error Metrics:\n"
+              "Pri: "
+              "|Ax - y|    / (abs_tol sqrt(m)     / rel_tol + |y|)          = %.2e\n"
+              "Dua: "
+              "|A'l + u|   / (abs_tol sqrt(n)     / rel_tol + |u|)          = %.2e\n"
+              "Gap: "
+              "|x'u + y'l| / (abs_tol sqrt(m + n) / rel_tol + |x,u| |y,l|)  = %.2e\n" POGS_AMD_HBAR,
+              (double)(c.rel_tol * c.nrm_r / c.eps_pri), (double)(c.rel_tol * c.nrm_s / c.eps_dua),
+              (double)(c.rel_tol * c.gap / c.eps_gap));
+  std::fflush(stdout);
+}
+
 struct SolveParams {
   double rho, abs_tol, rel_tol;
   unsigned max_iter, verbose;
@@ -409,10 +494,34 @@ struct FnHost {  // host SoA, element type = solver dtype
   const int *h;
 };
 
+// FunctionObj::CheckConsts (src/include/prox_lib.h:62-69): a negative c or e is not convex; the
+// reference prints a warning per offending object and uses 0.  The clamp itself happens on the
+// device (scale_objective_kernel); this prints the reference's messages, the first kMaxWarn per
+// coefficient array and then a count, so that a bad million-element vector stays readable.
+template <typename T>
+inline unsigned warn_negative_coeffs(const FnHost &f, size_t count) {
+  constexpr unsigned kMaxWarn = 8;
+  const T *c = static_cast<const T *>(f.c), *e = static_cast<const T *>(f.e);
+  unsigned nc = 0, ne = 0;
+  for (size_t i = 0; i < count; ++i) {
+    // (the reference's messages carry no newline: Printf at prox_lib.h:64,66)
+    if (c[i] < static_cast<T>(0) && nc++ < kMaxWarn) std::printf("WARNING c < 0. Function not convex. Using c = 0");
+    if (e[i] < static_cast<T>(0) && ne++ < kMaxWarn) std::printf("WARNING e < 0. Function not convex. Using e = 0");
+  }
+  if (nc > kMaxWarn) std::printf("\nWARNING c < 0 in %u more function objects", nc - kMaxWarn);
+  if (ne > kMaxWarn) std::printf("\nWARNING e < 0 in %u more function objects", ne - kMaxWarn);
+  if (nc + ne) {
+    std::printf("\n");
+    std::fflush(stdout);
+  }
+  return nc + ne;
+}
+
 // Type-erased solver behind the C handle.
 struct SolverBase {
   virtual ~SolverBase() {}
   virtual int dtype() const = 0;
+  virtual int device() const = 0;   // HIP device the handle lives on (DeviceGuard in abi.hip)
   virtual int solve(const FnHost &f, const FnHost &g, const SolveParams &p, void *x, void *y, void *l,
                     void *mu, double *optval, unsigned *final_iter) = 0;
   virtual void begin_run(const FnHost &f, const FnHost &g, const SolveParams &p) = 0;

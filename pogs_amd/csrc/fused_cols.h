@@ -1,0 +1,201 @@
+// Column-side kernels of the one-pass dense iteration (dense_solver.h: iteration_fused).
+//
+// pre_cols_kernel: ONE launch for everything that happens per column between two passes over A
+//   -- the second stage of both column-sum sets the pass left behind (A^T yhat, and the exact
+//   dual residual's A^T (y12 + c yt - yprev)), the x half of the prox step (pogs.cpp:257-278) and
+//   the exact dual residual itself (pogs.cpp:366-373).  It replaces three launches
+//   (admm_pre's x half + two reduce_cols), ~18 us + two kernel boundaries at C2.
+// pack_cols_kernel (row shards): the same second stage, written as fp64 into the pack buffer that
+//   ONE ncclAllReduce then sums over the ranks, plus -- in an extra workgroup -- the y-side scalar
+//   sums that ride in the tail of that buffer (one collective per iteration).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "prox.h"
+#include "reduce.h"
+#include "stream.h"
+#include "vec_kernels.h"
+
+namespace pogs_amd {
+
+// total[j] = sum_b partials[b][j] exactly as reduce_cols_kernel forms it (8 groups of every 8th
+// partial, then the groups in order), so that both second stages give the same bits.
+template <typename T>
+__device__ __forceinline__ typename Vec16<T>::type colsum_group(const T *partials, int nparts, int n_pad, int col, int g) {
+  using V = typename Vec16<T>::type;
+  V sum = dev::vzero<V>();
+  int b = g;
+  for (; b + 56 < nparts; b += 64) {
+    V v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const V *>(partials + static_cast<size_t>(b + 8 * q) * n_pad + col);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dev::vfma(sum, static_cast<T>(1), v[q]);
+  }
+  for (; b < nparts; b += 8) {
+    const V v = *reinterpret_cast<const V *>(partials + static_cast<size_t>(b) * n_pad + col);
+    dev::vfma(sum, static_cast<T>(1), v);
+  }
+  return sum;
+}
+
+template <typename T>
+struct PreColsArgs {
+  const T *part0, *part1;   // SRC64 = false: [nparts][n_pad] partial column sums of the two sets
+  int nparts;
+  const double *tot64;      // SRC64 = true: [2][n_pad] totals (summed over the ranks)
+  int n, n_pad;
+  FnView<T> g;              // scaled g
+  const T *x_cur, *xt;
+  T zt_scale, rho, alpha;
+  T *x12, *xtemp;           // out: prox point, over-relaxed point
+  T *rhs;                   // out: A^T yhat (padding columns zero)
+  double *partials;         // out: [grid][4] = sum w h, |w|^2, |h|^2, |exact dual residual|^2
+};
+
+template <typename T, bool SRC64>
+__global__ void __launch_bounds__(256) pre_cols_kernel(PreColsArgs<T> a) {
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = Vec16<T>::N;
+  __shared__ V s_v[2][8][32];
+  __shared__ double s_red[4 * 4];
+  const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + cx) * VEC;
+  if (!SRC64) {
+    V s0 = dev::vzero<V>(), s1 = dev::vzero<V>();
+    if (col < a.n_pad) {
+      s0 = colsum_group<T>(a.part0, a.nparts, a.n_pad, col, g);
+      s1 = colsum_group<T>(a.part1, a.nparts, a.n_pad, col, g);
+    }
+    s_v[0][g][cx] = s0;
+    s_v[1][g][cx] = s1;
+    __syncthreads();
+  }
+  double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (g == 0 && col < a.n_pad) {
+    T t0[VEC], t1[VEC];
+    if (SRC64) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        t0[i] = static_cast<T>(a.tot64[col + i]);
+        t1[i] = static_cast<T>(a.tot64[a.n_pad + col + i]);
+      }
+    } else {
+      V tot0 = s_v[0][0][cx], tot1 = s_v[1][0][cx];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) {
+        dev::vfma(tot0, static_cast<T>(1), s_v[0][q][cx]);
+        dev::vfma(tot1, static_cast<T>(1), s_v[1][q][cx]);
+      }
+      __builtin_memcpy(t0, &tot0, sizeof(V));
+      __builtin_memcpy(t1, &tot1, sizeof(V));
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int j = col + i;
+      if (j < a.n) {
+        const T prev = a.x_cur[j];
+        const T xtj = a.xt[j];
+        const T ztv = a.zt_scale * xtj;
+        const T v = prev - ztv;                                                          // pogs.cpp:257
+        const T h = dev::ProxEval(a.g.h[j], a.g.a[j], a.g.b[j], a.g.c[j], a.g.d[j], a.g.e[j], v, a.rho);   // :263
+        const T w = v - h;                                                               // :267
+        a.x12[j] = h;
+        a.xtemp[j] = ztv + a.alpha * h + (static_cast<T>(1) - a.alpha) * prev;           // :276-278
+        sacc[0] += static_cast<double>(w) * h;                                           // :268
+        sacc[1] += static_cast<double>(w) * w;
+        sacc[2] += static_cast<double>(h) * h;
+        a.rhs[j] = t0[i];
+        const T sd = t1[i] + h + a.zt_scale * xtj - prev;                                // :366-373
+        sacc[3] += static_cast<double>(sd) * sd;
+      } else {
+        a.rhs[j] = static_cast<T>(0);
+      }
+    }
+  }
+  __syncthreads();
+  dev::block_sum<4, 256>(sacc, s_red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.partials[static_cast<size_t>(blockIdx.x) * 4 + k] = sacc[k];
+  }
+}
+
+template <typename T>
+void launch_pre_cols(const PreColsArgs<T> &a, bool src64, hipStream_t s) {
+  const int grid = reduce_cols_grid(a.n_pad, Vec16<T>::N);
+  if (src64) hipLaunchKernelGGL((pre_cols_kernel<T, true>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((pre_cols_kernel<T, false>), dim3(grid), dim3(256), 0, s, a);
+}
+
+// Workgroups [0, ncb): pack[j] = total0[j], pack[n_pad + j] = total1[j] as doubles.
+// Workgroup ncb: the scalar sums of up to two jobs into pack[2 n_pad ...] (job order, k order).
+struct PackJobs {
+  SumJob j[2];
+  int njobs;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) pack_cols_kernel(const T *part0, const T *part1, int nparts, int n_pad,
+                                                        double *pack, PackJobs jobs) {
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = Vec16<T>::N;
+  __shared__ V s_v[2][8][32];
+  __shared__ double s_w[4];
+  const int ncb = (n_pad / VEC + 31) / 32;   // = reduce_cols_grid
+  if (static_cast<int>(blockIdx.x) == ncb) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double *out = pack + 2 * static_cast<size_t>(n_pad);
+    for (int q = 0; q < jobs.njobs; ++q) {
+      const SumJob job = jobs.j[q];
+      const size_t stride = job.stride > 0 ? job.stride : job.ns;
+      for (int k = 0; k < job.ns; ++k) {
+        const double *p = job.partials + job.offset + k;
+        double sum = 0;
+        for (int b = t; b < job.nparts; b += 256) sum += p[static_cast<size_t>(b) * stride];
+        sum = dev::wave_sum(sum);
+        if (lane == 0) s_w[wave] = sum;
+        __syncthreads();
+        if (t == 0) *out = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        ++out;
+        __syncthreads();
+      }
+    }
+    return;
+  }
+  const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + cx) * VEC;
+  V s0 = dev::vzero<V>(), s1 = dev::vzero<V>();
+  if (col < n_pad) {
+    s0 = colsum_group<T>(part0, nparts, n_pad, col, g);
+    s1 = colsum_group<T>(part1, nparts, n_pad, col, g);
+  }
+  s_v[0][g][cx] = s0;
+  s_v[1][g][cx] = s1;
+  __syncthreads();
+  if (g == 0 && col < n_pad) {
+    V tot0 = s_v[0][0][cx], tot1 = s_v[1][0][cx];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      dev::vfma(tot0, static_cast<T>(1), s_v[0][q][cx]);
+      dev::vfma(tot1, static_cast<T>(1), s_v[1][q][cx]);
+    }
+    T t0[VEC], t1[VEC];
+    __builtin_memcpy(t0, &tot0, sizeof(V));
+    __builtin_memcpy(t1, &tot1, sizeof(V));
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      pack[col + i] = static_cast<double>(t0[i]);
+      pack[n_pad + col + i] = static_cast<double>(t1[i]);
+    }
+  }
+}
+
+template <typename T>
+void launch_pack_cols(const T *part0, const T *part1, int nparts, int n_pad, double *pack, const PackJobs &jobs,
+                      hipStream_t s) {
+  const int grid = reduce_cols_grid(n_pad, Vec16<T>::N) + 1;
+  hipLaunchKernelGGL((pack_cols_kernel<T>), dim3(grid), dim3(256), 0, s, part0, part1, nparts, n_pad, pack, jobs);
+}
+
+}  // namespace pogs_amd

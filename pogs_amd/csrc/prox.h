@@ -47,84 +47,99 @@ template <typename T> __device__ __forceinline__ T BisectTol();   // prox_tools.
 template <> __device__ __forceinline__ float BisectTol<float>() { return 1e-5f; }
 template <> __device__ __forceinline__ double BisectTol<double>() { return 1e-10; }
 
-// W(exp(x)), principal branch, in double (prox_tools.h:98-129; callers cast to
-// double exactly as prox_lib.h:88-100 does).
-__device__ inline double LambertWExp(double x) {
+// ---- scalar root finders behind Exp / NegEntr / Recipr / Logistic ---------------------------
+// Behavioural spec only (the parity tests compare every one of them with the reference's values:
+// tests/golden/prox_table.npz is generated from the reference header): same start values, same
+// number of refinement steps and the same stopping thresholds as src/include/prox_tools.h:98-149
+// and prox_lib.h:131-170, so the iterates agree to rounding.
+
+// Start value for w e^w = e^x: the asymptotic series for large x, a series in sqrt(2 (e^(x+1) + 1))
+// around the branch point for negative x, x itself in between (less log x beyond x = log 3).
+struct LambertSeed {
   double w;
+  bool final;   // the asymptotic branch is returned as is
+};
+__device__ __forceinline__ LambertSeed lambert_seed(double x) {
   if (x > 100.0) {
-    const double log_x = log(x);
-    return -0.36962844 + x - 0.97284858 * log_x + 1.3437973 / log_x;
-  } else if (x < 0.0) {
-    const double p = sqrt(2.0 * (exp(x + 1.0) + 1.0));
-    w = -1.0 + p * (1.0 + p * (-1.0 / 3.0 + p * (11.0 / 72.0)));
-  } else {
-    w = x;
+    const double lx = log(x);
+    return {x - 0.36962844 - 0.97284858 * lx + 1.3437973 / lx, true};
   }
-  if (x > 1.098612288668110) w -= log(w);
-  for (int i = 0; i < 10; ++i) {
-    const double e = exp(w);
-    double t = w * e - exp(x);
-    const double p = w + 1.0;
-    t /= e * p - 0.5 * (p + 1.0) * t / p;
-    w -= t;
-    if (fabs(t) < 4e-16 * (1.0 + fabs(w))) break;
+  if (x < 0.0) {
+    const double q = sqrt(2.0 * (exp(x + 1.0) + 1.0));
+    const double series = 1.0 + q * (q * (11.0 / 72.0) - 1.0 / 3.0);   // Horner form of 1 - q/3 + 11 q^2 / 72
+    return {q * series - 1.0, false};
+  }
+  return {x > 1.098612288668110 ? x - log(x) : x, false};
+}
+// W(exp(x)), principal branch, evaluated in double (callers cast as prox_lib.h:88-100 does):
+// at most ten Halley steps on F(w) = w e^w - e^x.
+__device__ inline double LambertWExp(double x) {
+  const LambertSeed seed = lambert_seed(x);
+  if (seed.final) return seed.w;
+  const double target = exp(x);
+  double w = seed.w;
+  for (int step = 0; step < 10; ++step) {
+    const double ew = exp(w), w1 = w + 1.0;
+    const double F = w * ew - target;
+    const double delta = F / (ew * w1 - 0.5 * (w1 + 1.0) * F / w1);   // Halley: F / (F' - F F'' / (2 F'))
+    w -= delta;
+    if (fabs(delta) < 4e-16 * (1.0 + fabs(w))) break;
   }
   return w;
 }
 
-// Single positive root of x^3 + p x^2 + q x + r (prox_tools.h:134-149).
+// The positive root of x^3 + p x^2 + q x + r: substitute x = t - p/3 to get t^3 + 3 A t + 2 B = 0,
+// then Cardano (one real root) or the trigonometric form (three real roots, the largest).
 template <typename T>
 __device__ inline T CubicSolve(T p, T q, T r) {
-  const T s = p / 3, s2 = s * s, s3 = s2 * s;
-  const T a = -s2 + q / 3;
-  const T b = s3 - s * q / 2 + r / 2;
-  const T a3 = a * a * a;
-  const T b2 = b * b;
-  if (a3 + b2 >= 0) {
-    const T A = Pow(Sqrt(a3 + b2) - b, static_cast<T>(1) / 3);
-    return -s - a / A + A;
-  } else {
-    const T A = Sqrt(-a3);
-    const T B = Acos(-b / A);
-    const T C = Pow(A, static_cast<T>(1) / 3);
-    return -s + (C - a / C) * Cos(B / 3);
+  const T third = static_cast<T>(1) / 3;
+  const T shift = p / 3;
+  const T shift2 = shift * shift;
+  const T A = q / 3 - shift2;
+  const T B = shift2 * shift - shift * q / 2 + r / 2;
+  const T A3 = A * A * A;
+  const T disc = A3 + B * B;
+  if (disc >= 0) {
+    const T root = Pow(Sqrt(disc) - B, third);
+    return root - A / root - shift;
   }
+  const T mod = Sqrt(-A3);
+  const T angle = Acos(-B / mod);
+  const T rad = Pow(mod, third);
+  return (rad - A / rad) * Cos(angle / 3) - shift;
 }
 
-// Root of sigma(x) + rho (x - v) = 0: guarded Newton then interval halving
-// (prox_lib.h:131-170).
+// x with sigma(x) + rho (x - v) = 0 (the prox of log(1 + e^x)).  The root lies in [v - 1/rho, v]:
+// five Newton steps clipped to the bracket, then the bracket is shrunk with the fixed-point
+// residual until it is narrower than BisectTol (at most 100 rounds).
 template <typename T>
 __device__ inline T ProxLogistic(T v, T rho) {
-  const T inv_rho = 1 / rho;
-  T x;
-  if (v < static_cast<T>(-2.5))
-    x = v;
-  else if (v > static_cast<T>(2.5) + inv_rho)
-    x = v - inv_rho;
-  else
-    x = (rho * v - static_cast<T>(0.5)) / (static_cast<T>(0.2) + rho);
-  T l = v - inv_rho, u = v;
+  const T one = 1;
+  const T step = one / rho;
+  T lo = v - step, hi = v;
+  // start: the two asymptotes, or the tangent-line model sigma(x) ~ 0.5 + 0.2 x in between
+  T x = (v < static_cast<T>(-2.5)) ? v
+        : (v > static_cast<T>(2.5) + step) ? lo
+        : (rho * v - static_cast<T>(0.5)) / (static_cast<T>(0.2) + rho);
 #pragma unroll 1
-  for (int i = 0; i < 5; ++i) {
-    const T inv_ex = 1 / (1 + Exp(-x));
-    const T f = inv_ex + rho * (x - v);
-    const T g = inv_ex * (1 - inv_ex) + rho;
-    if (f < 0) l = x; else u = x;
-    x = x - f / g;
-    x = Min(x, u);
-    x = Max(x, l);
+  for (int it = 0; it < 5; ++it) {
+    const T sig = one / (one + Exp(-x));
+    const T resid = sig + rho * (x - v);
+    const T slope = sig * (one - sig) + rho;
+    if (resid < 0) lo = x; else hi = x;
+    x = Max(Min(x - resid / slope, hi), lo);
   }
 #pragma unroll 1
-  for (int i = 0; u - l > BisectTol<T>() && i < 100; ++i) {
-    const T g_rho = 1 / (rho * (1 + Exp(-x))) + (x - v);
-    if (g_rho > 0) {
-      l = Max(l, x - g_rho);
-      u = x;
+  for (int it = 0; it < 100 && hi - lo > BisectTol<T>(); ++it) {
+    const T gap = one / (rho * (one + Exp(-x))) + (x - v);   // residual / rho
+    if (gap > 0) {
+      lo = Max(lo, x - gap);
+      hi = x;
     } else {
-      u = Min(u, x - g_rho);
-      l = x;
+      hi = Min(hi, x - gap);
+      lo = x;
     }
-    x = (u + l) / 2;
+    x = (hi + lo) / 2;
   }
   return x;
 }

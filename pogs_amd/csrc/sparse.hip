@@ -9,20 +9,11 @@
 //       -> cgls::Solve (src/cpu/include/cgls.h:200-323)
 //     PogsImplementation::Solve (src/cpu/pogs.cpp:91-581)
 //
-// HBM layout: two CSR structures (A by rows, A^T by rows), int32 indices, plus
-// "row blocks": consecutive rows whose non-zeros fit one LDS tile.  A workgroup
-// streams a row block's values / indices with fully coalesced loads, stages the
-// products val * x[ind] in LDS, then reduces each row from LDS (CSR-stream);
-// rows longer than a tile are reduced by the whole workgroup.
-//
-// Column-blocked copy (the one the solver normally runs on): a random gather x[ind] is one
-// 64-byte L2 request per non-zero and that request rate, not HBM, bounds the plain kernel
-// (~1 TB/s at C4).  So each CSR is also stored split into column blocks of 28672 (fp32) or
-// 10240 (fp64) columns: non-zeros ordered by (column block, row), local column as uint16 (6 instead of 8
-// bytes per fp32 non-zero).  A workgroup keeps its block's slice of x in LDS (112 KB) and
-// gathers from there; per-(block, row) partial sums go to a buffer that a second kernel adds
-// in block order (deterministic) and hands to the row functor.  One block (n <= 28672 fp32
-// columns): no partials, the functor runs in the first kernel.
+// HBM layout: two CSR structures (A by rows, A^T by rows; int32 indices) -- kept for GetEquil,
+// as the source of the tiled copies and as the fallback (POGS_AMD_SPMV=plain): "row blocks" of
+// consecutive rows whose non-zeros fit one LDS tile, streamed with coalesced loads, products
+// staged in LDS, rows reduced from there.  The solver itself runs on a tiled sliced-ELL copy of
+// each (sell.h): x slices and row sums in LDS, uint16 local columns, no partial-sum traffic.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -32,6 +23,7 @@
 #include "cg_kernels.h"
 #include "engine.h"
 #include "reduce.h"
+#include "sell.h"
 #include "vec_kernels.h"
 
 namespace pogs_amd {
@@ -44,11 +36,6 @@ namespace {
 constexpr int kSpTpb = 256;
 constexpr int kSpCap = 4096;       // non-zeros staged in LDS per row block
 constexpr int kSpMaxRows = 2048;   // rows per block cap (balance when rows are empty)
-constexpr int kBlkTpb = 1024;      // column-blocked kernel: one workgroup per CU
-// LDS bytes for the x slice of one column block (+ 2 x kSpCap staged products <= 160 KB)
-template <typename T> struct BlkCfg { static constexpr int BYTES = sizeof(T) == 4 ? 112 * 1024 : 80 * 1024;
-                                      static constexpr int BW = BYTES / sizeof(T); };
-constexpr int kBlkU = kSpCap / kBlkTpb; // non-zeros per thread per row block
 
 // ---------------------------------------------------------------------------
 // Row functors (one thread per finished row; scalars accumulate in doubles)
@@ -239,166 +226,7 @@ __global__ void __launch_bounds__(kSpTpb) spmv_kernel(Csr<T> A, const T *__restr
   }
 }
 
-// ---------------------------------------------------------------------------
-// Column-blocked SpMV
-// ---------------------------------------------------------------------------
-// Pseudo-row q = cb * nrows + r holds the non-zeros of row r whose column lies in block cb;
-// (val, loc, bptr) is an ordinary CSR over the ncb * nrows pseudo-rows with block-local
-// uint16 columns, `blocks` its row blocks (none spans two column blocks).
-
-template <typename T>
-struct BlkRegs {
-  T v[kBlkU];
-  unsigned short l[kBlkU];
-  int bp[2];   // row offsets t and t + kBlkTpb of the row block
-};
-constexpr int kBlkMaxRows = 2 * kBlkTpb - 1;   // rows per row block: their offsets fit BlkRegs::bp
-
-// DIRECT (ncb == 1): the row functor runs here; otherwise part[q] receives the partial sums.
-// The structure arrays are separate __restrict__ arguments (not struct members) so that the
-// compiler may read the row-block descriptors through the scalar cache: as vector loads their
-// waits (vmcnt is in order) would drain the prefetched non-zeros of the next row blocks.
-struct BcsrDims {
-  int nrows, ncols, ncb, bw, nblocks;
-};
-
-template <typename T, bool SQ, bool DIRECT, typename Op>
-__global__ void __launch_bounds__(kBlkTpb) spmv_blocked_kernel(const T *__restrict__ a_val,
-                                                                const unsigned short *__restrict__ a_loc,
-                                                                const unsigned short *__restrict__ a_boff,
-                                                                const int2 *__restrict__ a_desc, BcsrDims A,
-                                                                const T *__restrict__ x, const double *x_nrm2, Op op,
-                                                                T *__restrict__ part, double *scalar_partials) {
-  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
-  extern __shared__ __attribute__((aligned(16))) unsigned char blk_smem[];
-  T *s_x = reinterpret_cast<T *>(blk_smem);                    // [bw]
-  T *s_prod = s_x + BlkCfg<T>::BW;                             // [2][kSpCap]
-  unsigned short *s_ptr = reinterpret_cast<unsigned short *>(s_prod + 2 * kSpCap);   // [2][2 kBlkTpb]
-  __shared__ T s_long[kBlkTpb / 64];
-  __shared__ double s_red[NS * (kBlkTpb / 64)];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  double sacc[NS];
-#pragma unroll
-  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
-  T xs = 1;
-  if (x_nrm2) xs = static_cast<T>(1.0 / sqrt(*x_nrm2));
-
-  // contiguous share of the row blocks: the column block changes at most a few times
-  const int d0 = static_cast<int>(static_cast<long long>(A.nblocks) * blockIdx.x / gridDim.x);
-  const int d1 = static_cast<int>(static_cast<long long>(A.nblocks) * (blockIdx.x + 1) / gridDim.x);
-  int cur_cb = -1, buf = 0;
-
-  // a_desc[d] = {first pseudo-row, first non-zero} of row block d (entry nblocks closes the
-  // last one).  The descriptors of the next four row blocks ride in scalar registers, loaded
-  // one row block ahead of their first use, so no load sits on the critical path.
-  auto desc_at = [&](int d) { return a_desc[min(d, A.nblocks)]; };
-  int2 Da = desc_at(d0), Db = desc_at(d0 + 1), Dc = desc_at(d0 + 2), Dd = desc_at(d0 + 3);
-
-  // values / local columns of row block d = [lo, hi) into registers (nothing for a long row)
-  auto fetch = [&](int d, int2 lo, int2 hi, BlkRegs<T> &R) {
-    if (d >= d1) return;
-    const int q0 = lo.x, nq = hi.x - lo.x;
-    const int p0 = lo.y, cnt = hi.y - lo.y;
-    if (cnt > kSpCap) return;
-    // streamed once per SpMV: non-temporal
-    // row offsets relative to the row block's first non-zero (uint16); slot nq holds the count
-    R.bp[0] = (t < nq) ? static_cast<int>(__builtin_nontemporal_load(a_boff + q0 + t)) : cnt;
-    R.bp[1] = (t + kBlkTpb < nq) ? static_cast<int>(__builtin_nontemporal_load(a_boff + q0 + kBlkTpb + t)) : cnt;
-#pragma unroll
-    for (int u = 0; u < kBlkU; ++u) {
-      const int k = u * kBlkTpb + t;
-      const bool ok = k < cnt;
-      R.v[u] = ok ? __builtin_nontemporal_load(a_val + p0 + k) : static_cast<T>(0);
-      R.l[u] = ok ? __builtin_nontemporal_load(a_loc + p0 + k) : static_cast<unsigned short>(0);
-    }
-  };
-  // consumes (Da, Db) = row block d, refills R with row block d + 2 = (Dc, Dd), then shifts
-  auto process = [&](int d, BlkRegs<T> &R) {
-    const int2 De = desc_at(d + 4);
-    const int q0 = Da.x, q1 = Db.x;
-    const int cb = q0 / A.nrows;
-    if (cb != cur_cb) {   // uniform
-      __syncthreads();
-      const int c0 = cb * A.bw, w = min(A.bw, A.ncols - c0);
-      for (int c = t; c < w; c += kBlkTpb) s_x[c] = x[c0 + c] * xs;
-      cur_cb = cb;
-      __syncthreads();
-    }
-    const int p0 = Da.y, cnt = Db.y - p0;
-    const int rbase = cb * A.nrows;
-    if (cnt > kSpCap) {
-      // one long pseudo-row: the whole workgroup strides over it
-      T sl = 0;
-      for (int k = t; k < cnt; k += kBlkTpb) {
-        T v = a_val[p0 + k];
-        if (SQ) v *= v;
-        sl += v * s_x[a_loc[p0 + k]];
-      }
-      sl = dev::wave_sum(sl);
-      if (lane == 0) s_long[wave] = sl;
-      __syncthreads();
-      if (t == 0) {
-        T tot = 0;
-#pragma unroll
-        for (int w = 0; w < kBlkTpb / 64; ++w) tot += s_long[w];
-        if (DIRECT) op.row(q0 - rbase, tot, sacc);
-        else part[q0] = tot;
-      }
-      __syncthreads();
-      fetch(d + 2, Dc, Dd, R);
-      Da = Db; Db = Dc; Dc = Dd; Dd = De;
-      return;
-    }
-    T *sp = s_prod + buf * kSpCap;
-    unsigned short *spt = s_ptr + buf * (2 * kBlkTpb);
-#pragma unroll
-    for (int u = 0; u < kBlkU; ++u) {
-      const int k = u * kBlkTpb + t;
-      if (k < cnt) sp[k] = (SQ ? R.v[u] * R.v[u] : R.v[u]) * s_x[R.l[u]];
-    }
-    spt[t] = static_cast<unsigned short>(R.bp[0]);   // entries past nq are never read
-    spt[kBlkTpb + t] = static_cast<unsigned short>(R.bp[1]);
-    fetch(d + 2, Dc, Dd, R);   // in flight during this and the next row block's reduction
-    __syncthreads();
-    const int nq = q1 - q0;
-    int tpr = 1;  // threads per row: a power of two <= 64, about a quarter of the mean row length
-    while (tpr < 64 && tpr * 4 < cnt / (nq > 0 ? nq : 1)) tpr <<= 1;
-    const int rpp = kBlkTpb / tpr, lir = t % tpr, slot = t / tpr;
-    for (int base = 0; base < nq; base += rpp) {
-      const int q = q0 + base + slot;
-      T sr = 0;
-      if (q < q1) {
-        const int a = spt[q - q0], e = spt[q - q0 + 1];
-        for (int k = a + lir; k < e; k += tpr) sr += sp[k];
-      }
-      for (int off = tpr >> 1; off > 0; off >>= 1) sr += __shfl_xor(sr, off, 64);
-      if (lir == 0 && q < q1) {
-        if (DIRECT) op.row(q - rbase, sr, sacc);
-        else part[q] = sr;
-      }
-    }
-    buf ^= 1;   // the next row block stages into the other half: one barrier per row block
-    Da = Db; Db = Dc; Dc = Dd; Dd = De;
-  };
-
-  BlkRegs<T> R0, R1;
-  fetch(d0, Da, Db, R0);
-  fetch(d0 + 1, Db, Dc, R1);
-  for (int d = d0; d < d1; d += 2) {
-    process(d, R0);
-    if (d + 1 < d1) process(d + 1, R1);
-  }
-  if (DIRECT && Op::NS > 0) {
-    __syncthreads();
-    dev::block_sum<NS, kBlkTpb>(sacc, s_red);
-    if (t == 0) {
-#pragma unroll
-      for (int k = 0; k < NS; ++k) scalar_partials[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
-    }
-  }
-}
-
-// row r: sum of its ncb partial sums in block order, then the row functor
+// row r: sum of its ncb partial sums (one per column group) in group order, then the row functor
 template <typename T, typename Op>
 __global__ void __launch_bounds__(256) reduce_parts_kernel(const T *__restrict__ part, int nrows, int ncb, Op op,
                                                            double *scalar_partials) {
@@ -441,29 +269,24 @@ __global__ void __launch_bounds__(256) apply_rows_kernel(const T *__restrict__ d
   }
 }
 
-// cnt[cb * nrows + r] = non-zeros of row r in column block cb (one thread per row)
-__global__ void bcsr_count_kernel(const int *ind, const int *ptr, int nrows, int bw, int *cnt) {
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x)
-    for (int k = ptr[r]; k < ptr[r + 1]; ++k) cnt[static_cast<size_t>(ind[k] / bw) * nrows + r] += 1;
-}
-
-// copies row r's non-zeros to their pseudo-rows, keeping their order (one thread per row);
-// cursor starts as a copy of bptr
-template <typename T>
-__global__ void bcsr_fill_kernel(const T *val, const int *ind, const int *ptr, int nrows, int bw, int *cursor,
-                                 T *bval, unsigned short *loc) {
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x)
-    for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
-      const int c = ind[k], cb = c / bw;
-      const int pos = cursor[static_cast<size_t>(cb) * nrows + r]++;
-      bval[pos] = val[k];
-      if (loc) loc[pos] = static_cast<unsigned short>(c - cb * bw);
-    }
-}
-
 // ---------------------------------------------------------------------------
 // One-time structure kernels
 // ---------------------------------------------------------------------------
+// *err |= 1 if ptr decreases somewhere, 2 if an index lies outside [0, ncols): checked before any
+// kernel scatters through these arrays (a malformed CSR / CSC is an error return, not a fault)
+__global__ void validate_csr_kernel(const int *ind, const int *ptr, int nrows, int ncols, size_t nnz, int *err) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  const size_t t0 = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  int bad = 0;
+  for (size_t r = t0; r < static_cast<size_t>(nrows); r += stride)
+    if (ptr[r + 1] < ptr[r]) bad |= 1;
+  for (size_t k = t0; k < nnz; k += stride) {
+    const int c = ind[k];
+    if (c < 0 || c >= ncols) bad |= 2;
+  }
+  if (bad) atomicOr(err, bad);
+}
+
 __global__ void count_cols_kernel(const int *ind, size_t nnz, int *cnt) {
   for (size_t k = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < nnz;
        k += static_cast<size_t>(gridDim.x) * blockDim.x)
@@ -536,54 +359,6 @@ __global__ void __launch_bounds__(1024) scan_add_kernel(int *out, int n, const i
   for (int k = 0; k < 8; ++k)
     if (base + k < n) out[base + k] += off;
   if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_off[ntiles];
-}
-
-// Row blocks of the column-blocked copy, found in parallel.  Window w holds the pseudo-rows
-// whose first non-zero lies in [w, w + 1) * kBlkSlot; win_start[w] is its first pseudo-row.
-// Pseudo-row q starts a row block when it is the first of its column block or of its window,
-// every kBlkMaxRows rows after the window start, and when it or its predecessor is longer than
-// kSpCap - kBlkSlot.  A row block therefore holds < kSpCap non-zeros unless it is one long row.
-constexpr int kBlkSlot = kSpCap - 512;
-
-__global__ void bcsr_windows_kernel(const int *bptr, int nq, int nwin, int *win_start) {
-  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nwin; w += gridDim.x * blockDim.x) {
-    const long long target = static_cast<long long>(w) * kBlkSlot;
-    int lo = 0, hi = nq;   // first q with bptr[q] >= target
-    while (lo < hi) {
-      const int mid = lo + (hi - lo) / 2;
-      if (bptr[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    win_start[w] = lo;
-  }
-}
-
-__global__ void bcsr_flag_kernel(const int *bptr, const int *win_start, int nq, int nrows, int *flag) {
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
-    bool f = (q % nrows == 0);
-    if (!f) {
-      const int a = bptr[q - 1], b = bptr[q], c = bptr[q + 1];
-      const int w = b / kBlkSlot;
-      f = (w != a / kBlkSlot) || ((q - win_start[w]) % kBlkMaxRows == 0) || (c - b > kSpCap - kBlkSlot) ||
-          (b - a > kSpCap - kBlkSlot);
-    }
-    flag[q] = f ? 1 : 0;
-  }
-}
-
-__global__ void bcsr_compact_kernel(const int *flag, const int *pos, const int *bptr, int nq, int2 *desc) {
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x)
-    if (flag[q]) desc[pos[q]] = make_int2(q, bptr[q]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) desc[pos[nq]] = make_int2(nq, bptr[nq]);
-}
-
-// boff[q] = bptr[q] - (first non-zero of the row block that holds pseudo-row q)
-__global__ void bcsr_offsets_kernel(const int *flag, const int *pos, const int *bptr, const int2 *desc, int nq,
-                                    unsigned short *boff) {
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
-    const int d = pos[q] + flag[q] - 1;
-    const int rel = bptr[q] - desc[d].y;
-    boff[q] = static_cast<unsigned short>(rel < 65535 ? rel : 65535);   // only a long row's own offset (0) matters
-  }
 }
 
 // scatter (row, val) of every non-zero into its column segment (order within a
@@ -682,13 +457,19 @@ struct DevCsr {
   int nrows = 0, ncols = 0, nblocks = 0;
   size_t nnz = 0;
   Csr<T> view() const { return Csr<T>{val.p, ind.p, ptr.p, blocks.p, nrows, nblocks}; }
-  // column-blocked copy (see the file header); ncb == 0: not built, the plain kernel runs
-  DevBuf<T> bval, part;
-  DevBuf<unsigned short> loc, boff;
-  DevBuf<int> bptr;
-  DevBuf<int2> bdesc;
-  int ncb = 0, nbblocks = 0;
-  BcsrDims bdims() const { return BcsrDims{nrows, ncols, ncb, BlkCfg<T>::BW, nbblocks}; }
+  // tiled sliced-ELL copy (sell.h); sell_ready == false: not built, the plain kernel runs
+  DevBuf<T> sval, part;
+  DevBuf<unsigned short> sloc, sperm;
+  DevBuf<unsigned> sdesc;
+  DevBuf<int> tile_ptr;
+  DevBuf<unsigned short> scnt, sslot;   // build temporaries kept until the values are final (refill_sell)
+  bool sell_ready = false;
+  int rr_rows = 0, nrr = 0, ncb = 0, ncg = 1, cb_per_group = 1;
+  size_t sell_elems = 0, sell_slices = 0;
+  SellDims sdims() const { return SellDims{nrows, ncols, rr_rows, nrr, ncb, SellCfg<T>::BW}; }
+  SellView<T> sview() const {
+    return SellView<T>{sval.p, sloc.p, sperm.p, sdesc.p, tile_ptr.p, nrows, ncols, rr_rows, nrr, ncb, ncg, cb_per_group};
+  }
 };
 
 std::vector<int> make_row_blocks(const std::vector<int> &ptr, int nrows) {
@@ -742,6 +523,7 @@ class SparseSolver final : public SolverBase {
   }
 
   int dtype() const override { return sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64; }
+  int device() const override { return ctx_.device; }
   PogsAmdStats &stats() override { return ctx_.stats; }
 
   int solve(const FnHost &f, const FnHost &g, const SolveParams &p, void *x, void *y, void *l, void *mu,
@@ -752,6 +534,7 @@ class SparseSolver final : public SolverBase {
     apply_warm_start();
     ctx_.sync();
     const double t1 = wall_s();
+    if (ctx_.dist.rank() == 0) print_banner(p.verbose);
     while (!iteration(p.verbose)) {}
     ctx_.sync();
     const double t2 = wall_s();
@@ -765,9 +548,11 @@ class SparseSolver final : public SolverBase {
     st.rho_updates = ctl_.rho_updates;
     st.rho_final = ctl_.rho;
     collect_timer();
-    if (p.verbose > 0)
+    if (p.verbose > 0 && ctx_.dist.rank() == 0) {
+      print_summary(status, st.t_total_s, st.t_init_s, ctl_);
       std::printf("POGS-AMD sparse/cgls: status %d, iter %u, init %.3e s, loop %.3e s, cg %llu, spmv %llu\n", status,
                   ctl_.k, st.t_init_s, st.t_loop_s, st.cg_iters, st.matvecs);
+    }
     return status;
   }
 
@@ -785,6 +570,7 @@ class SparseSolver final : public SolverBase {
   }
 
   void iterate(unsigned iters, double *seconds, unsigned *solves) override {
+    POGS_CHECK(loaded_, "PogsAmdIterate before PogsAmdBeginRun / PogsAmdSolve: no problem is loaded");
     unsigned done = 0;
     ctx_.sync();
     const double t0 = wall_s();
@@ -862,6 +648,16 @@ class SparseSolver final : public SolverBase {
       std::memcpy(hptr.data(), ptr, (r1 + 1) * sizeof(int));
     }
     POGS_CHECK(hptr[0] == 0 && static_cast<size_t>(hptr[r1]) == nnz_, "ptr does not match nnz");
+    {
+      DevBuf<int> err(1);
+      err.zero(s);
+      hipLaunchKernelGGL(validate_csr_kernel, dim3(2048), dim3(256), 0, s, first.ind.p, first.ptr.p, r1, c1, nnz_, err.p);
+      int herr = 0;
+      POGS_HIP_CHECK(hipMemcpyAsync(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      ctx_.sync();
+      POGS_CHECK((herr & 1) == 0, "sparse matrix: ptr is not non-decreasing");
+      POGS_CHECK((herr & 2) == 0, "sparse matrix: an index lies outside [0, columns)");
+    }
     // transpose on the device (gsl_spmat.h:32-55)
     second.val.alloc(nnz_); second.ind.alloc(nnz_); second.ptr.alloc(c1 + 1);
     DevBuf<int> cnt(c1 + 1), cursor(c1 + 1);
@@ -888,8 +684,8 @@ class SparseSolver final : public SolverBase {
     second.ncols = r1;
     const char *ev = std::getenv("POGS_AMD_SPMV");
     if (!(ev && ev[0] == 'p')) {   // POGS_AMD_SPMV=plain keeps the plain CSR kernel (testing aid)
-      build_blocked(first);
-      build_blocked(second);
+      build_sell(first);
+      build_sell(second);
     }
     if (ord == ROW_MAJ) { A_ = std::move(first); At_ = std::move(second); }
     else { At_ = std::move(first); A_ = std::move(second); }
@@ -911,59 +707,87 @@ class SparseSolver final : public SolverBase {
     ctx_.sync();   // temporaries are freed at scope exit
   }
 
-  // Column-blocked copy of M (structure now, values again after every rescaling).  Skipped
-  // when the per-(block, row) bookkeeping would outweigh the non-zeros themselves.
-  void build_blocked(DevCsr<T> &M) {
+  // Tiled sliced-ELL copy of M (sell.h): structure and values now, values again after the
+  // equilibration has rescaled the CSR copy (refill_sell).  Skipped (the plain CSR kernel then
+  // runs) when the per-(tile, row) bookkeeping could not be indexed with 32 bits.
+  void build_sell(DevCsr<T> &M) {
     hipStream_t s = ctx_.stream;
-    constexpr int BW = BlkCfg<T>::BW;
+    constexpr int BW = SellCfg<T>::BW, RRMAX = SellCfg<T>::RR;
+    if (M.nnz == 0) return;
     const int ncb = (M.ncols + BW - 1) / BW;
-    const long long nq = static_cast<long long>(ncb) * M.nrows;
-    if (M.nnz == 0 || nq >= (1LL << 30) || (ncb > 1 && nq > 2 * static_cast<long long>(M.nnz) + (1 << 20))) return;
-    DevBuf<int> cnt(nq + 1);
-    cnt.zero(s);
+    // rows per row range: as many as the LDS holds, fewer when the matrix would otherwise give
+    // the chip less than ~2 workgroups per CU (column groups can only multiply by ncb)
+    const long long want = static_cast<long long>(M.nrows) * ncb / (2LL * ctx_.num_cu);
+    int rr_rows = static_cast<int>(round_up(static_cast<size_t>(std::max<long long>(256, std::min<long long>(RRMAX, want))), 64));
+    rr_rows = std::min(rr_rows, RRMAX);
+    const int nrr = (M.nrows + rr_rows - 1) / rr_rows;
+    const long long ntiles = static_cast<long long>(nrr) * ncb;
+    const long long nq = ntiles * rr_rows;
+    if (ntiles >= (1LL << 30) || nq >= (1LL << 31)) return;
+    int ncg = 1;
+    while (static_cast<long long>(nrr) * ncg < 2LL * ctx_.num_cu && ncg < ncb) ncg *= 2;
+    int cbpg = (ncb + ncg - 1) / ncg;
+    ncg = (ncb + cbpg - 1) / cbpg;
+    M.rr_rows = rr_rows; M.nrr = nrr; M.ncb = ncb; M.ncg = ncg; M.cb_per_group = cbpg;
+    const SellDims D = M.sdims();
+    M.scnt.alloc(nq); M.sslot.alloc(nq);
+    M.scnt.zero(s);
     const int g = std::max(1, std::min((M.nrows + 255) / 256, ctx_.num_cu * 16));
-    hipLaunchKernelGGL(bcsr_count_kernel, dim3(g), dim3(256), 0, s, M.ind.p, M.ptr.p, M.nrows, BW, cnt.p);
-    M.bptr.alloc(nq + 1);
-    exclusive_scan(cnt.p, static_cast<int>(nq), M.bptr.p);
-    M.bval.alloc(M.nnz);
-    M.loc.alloc(M.nnz);
-    M.ncb = ncb;
-    fill_blocked(M, true);
-    {
-      const int nwin = static_cast<int>(M.nnz / kBlkSlot) + 1;
-      DevBuf<int> flag(nq + 1), pos(nq + 1), win(nwin);
-      const int gq = static_cast<int>(std::min<long long>((nq + 255) / 256, ctx_.num_cu * 32));
-      hipLaunchKernelGGL(bcsr_windows_kernel, dim3((nwin + 255) / 256), dim3(256), 0, s, M.bptr.p,
-                         static_cast<int>(nq), nwin, win.p);
-      hipLaunchKernelGGL(bcsr_flag_kernel, dim3(gq), dim3(256), 0, s, M.bptr.p, win.p, static_cast<int>(nq), M.nrows,
-                         flag.p);
-      exclusive_scan(flag.p, static_cast<int>(nq), pos.p);
-      int nb = 0;
-      POGS_HIP_CHECK(hipMemcpyAsync(&nb, pos.p + nq, sizeof(int), hipMemcpyDeviceToHost, s));
-      ctx_.sync();
-      M.nbblocks = nb;
-      M.bdesc.alloc(nb + 1);
-      hipLaunchKernelGGL(bcsr_compact_kernel, dim3(gq), dim3(256), 0, s, flag.p, pos.p, M.bptr.p, static_cast<int>(nq),
-                         M.bdesc.p);
-      M.boff.alloc(nq + 1);
-      hipLaunchKernelGGL(bcsr_offsets_kernel, dim3(gq), dim3(256), 0, s, flag.p, pos.p, M.bptr.p, M.bdesc.p,
-                         static_cast<int>(nq), M.boff.p);
-      ctx_.sync();
+    hipLaunchKernelGGL(sell_count_kernel, dim3(g), dim3(256), 0, s, M.ind.p, M.ptr.p, D, M.scnt.p);
+    DevBuf<int> ns(ntiles + 1), nu(ntiles + 1), uptr(ntiles + 1);
+    M.tile_ptr.alloc(ntiles + 1);
+    const int gt = static_cast<int>(std::min<long long>(ntiles, ctx_.num_cu * 8));
+    hipLaunchKernelGGL(sell_plan_kernel<false>, dim3(gt), dim3(256), 0, s, M.scnt.p, D, ns.p, nu.p,
+                       static_cast<const int *>(nullptr), static_cast<const int *>(nullptr),
+                       static_cast<unsigned *>(nullptr), static_cast<unsigned short *>(nullptr),
+                       static_cast<unsigned short *>(nullptr));
+    exclusive_scan(ns.p, static_cast<int>(ntiles), M.tile_ptr.p);
+    exclusive_scan(nu.p, static_cast<int>(ntiles), uptr.p);
+    int tot[2] = {0, 0};
+    POGS_HIP_CHECK(hipMemcpyAsync(&tot[0], M.tile_ptr.p + ntiles, sizeof(int), hipMemcpyDeviceToHost, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(&tot[1], uptr.p + ntiles, sizeof(int), hipMemcpyDeviceToHost, s));
+    ctx_.sync();
+    // (units fit 26 bits of a descriptor; a padding blow-up beyond 4x the non-zeros -- a matrix
+    // of a few very long and many empty rows per tile -- is left to the plain kernel)
+    if (tot[0] <= 0 || tot[1] <= 0 || tot[1] >= (1 << 26) ||
+        static_cast<size_t>(tot[1]) * 64 > 4 * M.nnz + (static_cast<size_t>(1) << 22)) {
+      M.scnt.release(); M.sslot.release(); M.tile_ptr.release();
+      return;
     }
-    if (ncb > 1) M.part.alloc(nq);
+    M.sell_slices = static_cast<size_t>(tot[0]);
+    M.sell_elems = static_cast<size_t>(tot[1]) * 64;
+    M.sdesc.alloc(M.sell_slices);
+    M.sperm.alloc(M.sell_slices * 64);
+    M.sval.alloc(M.sell_elems);
+    M.sloc.alloc(M.sell_elems);
+    POGS_HIP_CHECK(hipMemsetAsync(M.sperm.p, 0xFF, M.sell_slices * 64 * sizeof(unsigned short), s));
+    M.sval.zero(s);
+    M.sloc.zero(s);
+    hipLaunchKernelGGL(sell_plan_kernel<true>, dim3(gt), dim3(256), 0, s, M.scnt.p, D, static_cast<int *>(nullptr),
+                       static_cast<int *>(nullptr), M.tile_ptr.p, uptr.p, M.sdesc.p, M.sperm.p, M.sslot.p);
+    M.sell_ready = true;
+    fill_sell(M, true);
+    if (ncg > 1) M.part.alloc(static_cast<size_t>(ncg) * M.nrows);
+    ctx_.sync();   // ns / nu / uptr are freed at scope exit
   }
 
-  // (re)writes the blocked values from M.val; with_loc also the local columns
-  void fill_blocked(DevCsr<T> &M, bool with_loc) {
-    if (M.ncb == 0) return;
+  // (re)writes the tiled values from M.val; with_loc also the local columns
+  void fill_sell(DevCsr<T> &M, bool with_loc) {
+    if (!M.sell_ready) return;
     hipStream_t s = ctx_.stream;
-    const size_t nq = static_cast<size_t>(M.ncb) * M.nrows;
-    DevBuf<int> cursor(nq + 1);
-    POGS_HIP_CHECK(hipMemcpyAsync(cursor.p, M.bptr.p, (nq + 1) * sizeof(int), hipMemcpyDeviceToDevice, s));
+    const size_t nq = static_cast<size_t>(M.nrr) * M.ncb * M.rr_rows;
+    DevBuf<unsigned short> cursor(nq);
+    cursor.zero(s);
     const int g = std::max(1, std::min((M.nrows + 255) / 256, ctx_.num_cu * 16));
-    hipLaunchKernelGGL(bcsr_fill_kernel<T>, dim3(g), dim3(256), 0, s, M.val.p, M.ind.p, M.ptr.p, M.nrows,
-                       BlkCfg<T>::BW, cursor.p, M.bval.p, with_loc ? M.loc.p : nullptr);
+    hipLaunchKernelGGL(sell_fill_kernel<T>, dim3(g), dim3(256), 0, s, M.val.p, M.ind.p, M.ptr.p, M.sdims(), M.scnt.p,
+                       M.sslot.p, cursor.p, M.tile_ptr.p, M.sdesc.p, M.sval.p, with_loc ? M.sloc.p : nullptr);
     ctx_.sync();   // cursor is freed at scope exit
+  }
+  // the values are final (equilibrated): refill and drop the build temporaries
+  void refill_sell(DevCsr<T> &M) {
+    fill_sell(M, false);
+    M.scnt.release();
+    M.sslot.release();
   }
 
   void alloc_state() {
@@ -980,7 +804,10 @@ class SparseSolver final : public SolverBase {
     if (multi_) tsum_.alloc(n_);
     spmv_grid_ = ctx_.num_cu * 8;
     const size_t vb = vec_blocks(n_) + vec_blocks(m_);
-    ctx_.ensure_spart(std::max<size_t>(static_cast<size_t>(spmv_grid_) * 4 + 64, vb * 3 + 64));
+    size_t sg = static_cast<size_t>(spmv_grid_);   // workgroups that write scalar partials in one launch
+    if (A_.sell_ready) sg = std::max(sg, static_cast<size_t>(A_.nrr) * A_.ncg);
+    if (At_.sell_ready) sg = std::max(sg, static_cast<size_t>(At_.nrr) * At_.ncg);
+    ctx_.ensure_spart(std::max<size_t>(sg * 4 + 64, vb * 3 + 64));
   }
 
   // y_i = op(sum_k val * x[ind]) over the rows of M; scalar sums land in S[slot..slot+NS)
@@ -990,23 +817,22 @@ class SparseSolver final : public SolverBase {
     hipStream_t s = ctx_.stream;
     int grid;
     if (timed) ctx_.stream_timer.begin(s);
-    if (M.ncb > 0) {
-      constexpr size_t smem = BlkCfg<T>::BYTES + 2 * kSpCap * sizeof(T) + 4 * kBlkTpb * sizeof(unsigned short);
-      const int g1 = std::max(1, std::min(M.nbblocks, ctx_.num_cu));
-      if (M.ncb == 1) {
-        static const bool once = allow_smem(reinterpret_cast<const void *>(&spmv_blocked_kernel<T, SQ, true, Op>), smem);
+    if (M.sell_ready) {
+      constexpr size_t smem = (static_cast<size_t>(SellCfg<T>::BW) + SellCfg<T>::RR) * sizeof(T);
+      const int g1 = M.nrr * M.ncg;
+      if (M.ncg == 1) {
+        static const bool once = allow_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, SQ, true, Op>), smem);
         (void)once;
-        hipLaunchKernelGGL((spmv_blocked_kernel<T, SQ, true, Op>), dim3(g1), dim3(kBlkTpb), smem, s, M.bval.p,
-                           M.loc.p, M.boff.p, M.bdesc.p, M.bdims(), x, x_nrm2, op, static_cast<T *>(nullptr),
-                           ctx_.spart.p);
+        hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, true, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
+                           x_nrm2, op, static_cast<T *>(nullptr), ctx_.spart.p);
         grid = g1;
       } else {
-        static const bool once = allow_smem(reinterpret_cast<const void *>(&spmv_blocked_kernel<T, SQ, false, Op>), smem);
+        static const bool once = allow_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, SQ, false, Op>), smem);
         (void)once;
-        hipLaunchKernelGGL((spmv_blocked_kernel<T, SQ, false, Op>), dim3(g1), dim3(kBlkTpb), smem, s, M.bval.p,
-                           M.loc.p, M.boff.p, M.bdesc.p, M.bdims(), x, x_nrm2, op, M.part.p, ctx_.spart.p);
+        hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, false, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
+                           x_nrm2, op, M.part.p, ctx_.spart.p);
         grid = std::max(1, std::min((M.nrows + 255) / 256, spmv_grid_));
-        hipLaunchKernelGGL((reduce_parts_kernel<T, Op>), dim3(grid), dim3(256), 0, s, M.part.p, M.nrows, M.ncb, op,
+        hipLaunchKernelGGL((reduce_parts_kernel<T, Op>), dim3(grid), dim3(256), 0, s, M.part.p, M.nrows, M.ncg, op,
                            ctx_.spart.p);
       }
     } else {
@@ -1107,8 +933,8 @@ class SparseSolver final : public SolverBase {
                     static_cast<T>(std::sqrt(std::min(mg, nn)));
     launch_scal<T>(A_.val.p, static_cast<T>(1) / normA, nnz_, s);
     launch_scal<T>(At_.val.p, static_cast<T>(1) / normA, nnz_, s);
-    fill_blocked(A_, false);
-    fill_blocked(At_, false);
+    refill_sell(A_);
+    refill_sell(At_);
     const T invs = static_cast<T>(1) / std::sqrt(normA);
     launch_scal<T>(d_.p, invs, m_, s);
     launch_scal<T>(e_.p, invs, n_, s);
@@ -1160,6 +986,8 @@ class SparseSolver final : public SolverBase {
     };
     up(f_, f, m_);
     up(g_, g, n_);
+    warn_negative_coeffs<T>(f, m_);   // prox_lib.h:62-69 (the clamp is in scale_objective_kernel)
+    warn_negative_coeffs<T>(g, n_);
     launch_scale_objective<T>(f_.view(), fs_.a.p, fs_.c.p, fs_.d.p, fs_.e.p, d_.p, m_, true, s);
     launch_scale_objective<T>(g_.view(), gs_.a.p, gs_.c.p, gs_.d.p, gs_.e.p, e_.p, n_, false, s);
     ctl_ = AdmmControl<T>();
@@ -1171,6 +999,7 @@ class SparseSolver final : public SolverBase {
     ctl_.rho0 = static_cast<T>(p.rho);
     ctl_.m_glob = ctx_.m_global;
     ctl_.n = n_;
+    loaded_ = true;
     ctx_.sync();
   }
   FnView<T> fview() const { return FnView<T>{f_.h.p, fs_.a.p, f_.b.p, fs_.c.p, fs_.d.p, fs_.e.p}; }
@@ -1327,9 +1156,10 @@ class SparseSolver final : public SolverBase {
       exact = true;
     }
     const bool stop = ctl_.check_stop(exact);
-    if (verbose > 1 && ((verbose > 2 && ctl_.k % 10 == 0) || ctl_.k % 100 == 0 || ctl_.converged))
-      std::printf("%5u : %.2e  %.2e  %.2e  %.2e  %.2e  %.2e\n", ctl_.k, (double)ctl_.nrm_r, (double)ctl_.eps_pri,
-                  (double)ctl_.nrm_s, (double)ctl_.eps_dua, (double)ctl_.gap, (double)ctl_.eps_gap);
+    if (wants_iter_line(verbose, ctl_)) {
+      const double obj = eval_objective();
+      if (ctx_.dist.rank() == 0) print_iter_line(ctl_, obj);
+    }
     if (stop) return true;
     std::swap(xt_, xtemp_);
     std::swap(yt_, ytemp_);
@@ -1337,6 +1167,19 @@ class SparseSolver final : public SolverBase {
     zt_scale_ = ctl_.adapt();
     ++ctl_.k;
     return false;
+  }
+
+  // sum f(y12) + sum g(x12) at the current prox point (pogs.cpp:385, 473)
+  double eval_objective() {
+    hipStream_t s = ctx_.stream;
+    const int by = vec_blocks(m_), bx = vec_blocks(n_);
+    launch_func_eval<T>(m_, fview(), y12_.p, ctx_.spart.p, s);
+    launch_func_eval<T>(n_, gview(), x12_.p, ctx_.spart.p + by, s);
+    SumJob j[2] = {{ctx_.spart.p, by, 1, ctx_.S.p + kFvalF}, {ctx_.spart.p + by, bx, 1, ctx_.S.p + kFvalG}};
+    launch_sum_jobs(j, 2, s);
+    reduce_y_scalars(ctx_.S.p + kFvalF, 1);
+    const double *S = ctx_.fetch_scalars();
+    return static_cast<double>(static_cast<T>(S[kFvalF]) + static_cast<T>(S[kFvalG]));
   }
 
   int epilogue(void *x, void *y, void *l, void *mu, double *optval) {
@@ -1360,10 +1203,14 @@ class SparseSolver final : public SolverBase {
     if (mu) POGS_HIP_CHECK(hipMemcpyAsync(mu, muout_.p, n_ * sizeof(T), hipMemcpyDeviceToHost, s));
     const double *S = ctx_.fetch_scalars();
     *optval = static_cast<double>(static_cast<T>(S[kFvalF]) + static_cast<T>(S[kFvalG]));
+    // the polled sequence word says the kernels are done; the D2H copies into the caller's
+    // (pageable) buffers are only guaranteed complete after a synchronizing call
+    POGS_HIP_CHECK(hipStreamSynchronize(s));
     return ctl_.status();
   }
 
   void collect_timer() {
+    ctx_.stats.reserved[2] = static_cast<double>(ctx_.dist.collectives());   // all-reduce calls since creation
     ctx_.stats.matvecs += timed_spmvs_;
     if (ctx_.stream_timer.enabled()) {
       unsigned long long cnt = 0;
@@ -1395,6 +1242,7 @@ class SparseSolver final : public SolverBase {
   DevBuf<double> cg_;
   FnBuf<T> f_, g_, fs_, gs_;
   AdmmControl<T> ctl_;
+  bool loaded_ = false;   // load_problem has run: f, g and the control block are valid
   int cur_ = 0;
   T zt_scale_ = 1;
   T nrmA_ = 0;

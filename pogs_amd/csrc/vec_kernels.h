@@ -93,18 +93,29 @@ struct SumJob {
   int stride = 0;   // doubles between consecutive partial records (0: ns)
   int offset = 0;   // first scalar of the record to sum
 };
+// Scalars that were summed over the ranks inside a packed buffer (dense_solver.h: pack buffer tail):
+// the publishing launch takes slots [slot[q], slot[q] + n[q]) from src instead of the device
+// block (and stores them there), q = 0, 1; src is read in that order.  n = {0, 0}: none.
+struct ScalarOverlay {
+  const double *src = nullptr;
+  int slot[2] = {0, 0};
+  int n[2] = {0, 0};
+};
 // Makes the runtime load this translation unit's code object (see preload_gemm_code).
 void preload_vec_code();
 constexpr int kMaxSumJobs = 8;
 // launch_sum_jobs and launch_publish_scalars in one launch (see sum_publish_kernel); *counter is a
 // zero-initialised device word the kernel leaves at zero.
-void launch_sum_publish(const SumJob *jobs, int njobs, const double *S, int count, double *host_S,
-                        unsigned long long *host_seq, unsigned long long seq, unsigned *counter, hipStream_t s);
+void launch_sum_publish(const SumJob *jobs, int njobs, double *S, int count, double *host_S,
+                        unsigned long long *host_seq, unsigned long long seq, unsigned *counter, hipStream_t s,
+                        const ScalarOverlay &ov = ScalarOverlay());
 // Copies the device scalar block to a host-mapped mirror and then raises *host_seq to `seq`
 // (system-scope release): the host reads the block after polling the sequence word, with no
 // copy-engine round trip and no stream-synchronize call.
-void launch_publish_scalars(const double *S, int count, double *host_S, unsigned long long *host_seq,
-                            unsigned long long seq, hipStream_t s);
+void launch_publish_scalars(double *S, int count, double *host_S, unsigned long long *host_seq,
+                            unsigned long long seq, hipStream_t s, const ScalarOverlay &ov = ScalarOverlay());
+// S[slot ...] = src[...] for the overlay's ranges (the non-polling fetch path and rare call sites)
+void launch_apply_overlay(double *S, const ScalarOverlay &ov, hipStream_t s);
 
 // u = y12 + c yt - yprev   (pogs.cpp:366-368, y half)
 template <typename T>

@@ -151,9 +151,9 @@ __global__ void __launch_bounds__(256) sum_jobs_kernel(SumJobs jobs) {
 // The iteration's closing launch: one workgroup per sum job, and the workgroup that finishes
 // last (a device counter) copies the scalar block to the host-mapped mirror and raises the
 // sequence word -- publish_scalars_kernel without a launch of its own.
-__global__ void __launch_bounds__(256) sum_publish_kernel(SumJobs jobs, int njobs, const double *S, int count,
+__global__ void __launch_bounds__(256) sum_publish_kernel(SumJobs jobs, int njobs, double *S, int count,
                                                           double *host_S, unsigned long long *host_seq,
-                                                          unsigned long long seq, unsigned *counter) {
+                                                          unsigned long long seq, unsigned *counter, ScalarOverlay ov) {
   __shared__ double s_w[4];
   __shared__ unsigned s_last;
   run_sum_job(jobs.j[blockIdx.x], s_w);
@@ -166,7 +166,19 @@ __global__ void __launch_bounds__(256) sum_publish_kernel(SumJobs jobs, int njob
   __threadfence();     // the other workgroups' sums before the copy
   const int t = threadIdx.x;
   if (t == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (t < count) host_S[t] = __hip_atomic_load(S + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t < count) {
+    double v = __hip_atomic_load(S + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {   // scalars summed over the ranks in the pack buffer (see ScalarOverlay)
+      if (t >= ov.slot[q] && t < ov.slot[q] + ov.n[q]) {
+        v = ov.src[base + t - ov.slot[q]];
+        S[t] = v;
+      }
+      base += ov.n[q];
+    }
+    host_S[t] = v;
+  }
   __threadfence_system();
   __syncthreads();
   if (t == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -241,19 +253,41 @@ void launch_unscale(const UnscaleArgs<T> &a, hipStream_t s) {
 }
 
 namespace {
-__global__ void __launch_bounds__(64) publish_scalars_kernel(const double *S, int count, double *host_S,
-                                                           unsigned long long *host_seq, unsigned long long seq) {
+// value of slot t: from the overlay if it covers t (then also stored into the device block)
+__device__ __forceinline__ double overlay_value(double *S, int t, const ScalarOverlay &ov) {
+  int base = 0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (t >= ov.slot[q] && t < ov.slot[q] + ov.n[q]) {
+      const double v = ov.src[base + t - ov.slot[q]];
+      S[t] = v;
+      return v;
+    }
+    base += ov.n[q];
+  }
+  return __hip_atomic_load(S + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void __launch_bounds__(64) publish_scalars_kernel(double *S, int count, double *host_S,
+                                                           unsigned long long *host_seq, unsigned long long seq,
+                                                           ScalarOverlay ov) {
   const int t = threadIdx.x;
-  if (t < count) host_S[t] = S[t];
+  if (t < count) host_S[t] = overlay_value(S, t, ov);
   __threadfence_system();
   __syncthreads();
   if (t == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__global__ void __launch_bounds__(64) apply_overlay_kernel(double *S, ScalarOverlay ov) {
+  const int t = threadIdx.x;
+  (void)overlay_value(S, t, ov);
+}
 }  // namespace
 
-void launch_publish_scalars(const double *S, int count, double *host_S, unsigned long long *host_seq,
-                            unsigned long long seq, hipStream_t s) {
-  hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, s, S, count, host_S, host_seq, seq);
+void launch_publish_scalars(double *S, int count, double *host_S, unsigned long long *host_seq,
+                            unsigned long long seq, hipStream_t s, const ScalarOverlay &ov) {
+  hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, s, S, count, host_S, host_seq, seq, ov);
+}
+void launch_apply_overlay(double *S, const ScalarOverlay &ov, hipStream_t s) {
+  if (ov.n[0] + ov.n[1] > 0) hipLaunchKernelGGL(apply_overlay_kernel, dim3(1), dim3(64), 0, s, S, ov);
 }
 
 namespace {
@@ -284,13 +318,14 @@ void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s) {
   hipLaunchKernelGGL(sum_jobs_kernel, dim3(njobs), dim3(256), 0, s, j);
 }
 
-void launch_sum_publish(const SumJob *jobs, int njobs, const double *S, int count, double *host_S,
-                        unsigned long long *host_seq, unsigned long long seq, unsigned *counter, hipStream_t s) {
+void launch_sum_publish(const SumJob *jobs, int njobs, double *S, int count, double *host_S,
+                        unsigned long long *host_seq, unsigned long long seq, unsigned *counter, hipStream_t s,
+                        const ScalarOverlay &ov) {
   POGS_CHECK(njobs >= 1 && njobs <= kMaxSumJobs && count <= 256, "sum jobs");
   SumJobs j;
   for (int i = 0; i < kMaxSumJobs; ++i) j.j[i] = jobs[i < njobs ? i : 0];
   hipLaunchKernelGGL(sum_publish_kernel, dim3(njobs), dim3(256), 0, s, j, njobs, S, count, host_S, host_seq, seq,
-                     counter);
+                     counter, ov);
 }
 
 namespace {

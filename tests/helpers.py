@@ -75,6 +75,7 @@ def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, **solve_kw):
 
     import numpy as np
 
+    os.environ["POGS_AMD_TEST_TRANSPORT"] = "1"   # the in-process communicator is refused without it
     m = A.shape[0]
     uid = (b"POGSLOCAL:" + os.urandom(8).hex().encode()).ljust(128, b"\0")
     bounds = np.linspace(0, m, world + 1).astype(int)

@@ -176,25 +176,66 @@ def ref_available():
     return os.path.exists(_REF_SO)
 
 
-def ref_solve(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0,
-              adaptive_rho=True, gap_stop=True, order=1, timeout=None):
-    """Run the compiled reference (PogsD/S, PogsSparseD/S) in a CLEAN subprocess.
+class RefRun:
+    """A reference solve running in its own process (ref_start); finish() waits for it."""
+
+    def __init__(self, td, proc, outp, t0):
+        self.td, self.proc, self.outp, self.t0 = td, proc, outp, t0
+
+    def finish(self, timeout=None):
+        import re
+        import time
+
+        try:
+            try:
+                out, err = self.proc.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                self.proc.kill()
+                self.proc.communicate()
+                raise
+            if self.proc.returncode != 0 or not os.path.exists(self.outp):
+                raise RuntimeError("reference runner failed:\n" + out[-2000:] + err[-2000:])
+            z = np.load(self.outp)
+            r = {"x": z["x"], "y": z["y"], "l": z["l"], "optval": float(z["optval"]),
+                 "iterations": int(z["iterations"]), "status": int(z["status"]), "wall_s": float(z["wall_s"]),
+                 "stdout": out, "elapsed_s": time.time() - self.t0}
+            mt = re.search(r"Total = ([0-9.eE+-]+) s, Init = ([0-9.eE+-]+) s", out)
+            if mt:
+                r["t_total"], r["t_init"] = float(mt.group(1)), float(mt.group(2))
+            return r
+        finally:
+            self.td.cleanup()
+
+
+REF_THREADS = 16   # BLAS threads of the reference subprocess: the fastest setting measured on the 2 x 64-core GPU
+                   # box (scripts/ref_threads_probe.py, 20000 x 10000 fp32: 16 -> 12.8 it/s, 32 -> 9.2, 64 -> 11.1,
+                   # 128 -> 7.2, 256 -> 8.8; at 100000 rows 256 threads need > 15 minutes)
+
+
+def ref_threads():
+    return max(1, min(REF_THREADS, os.cpu_count() or 1))
+
+
+def ref_start(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0,
+              adaptive_rho=True, gap_stop=True, order=1, threads=None):
+    """Start the compiled reference (PogsD/S, PogsSparseD/S) in a CLEAN subprocess and return a
+    RefRun (None if the reference is not available); RefRun.finish() collects the result.
 
     The reference links MKL; in a process that has PyTorch loaded (its own OpenMP /
     BLAS symbols) MKL's threading layer mis-binds and the reference returns NaN, so
-    it never shares a process with torch.  Returns None if the reference is not
-    available; raises subprocess.TimeoutExpired on timeout.  The result carries
-    't_total' / 't_init' parsed from the reference's own verbose=1 summary
-    (src/cpu/pogs.cpp:485-490) when verbose >= 1.
+    it never shares a process with torch.  The result carries 't_total' / 't_init' parsed
+    from the reference's own verbose=1 summary (src/cpu/pogs.cpp:485-490) when verbose >= 1.
     """
     import sys
     import tempfile
+    import time
 
     if not ref_available():
         return None
     sparse = hasattr(A, "indptr")
-    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
-        inp, outp = os.path.join(td, "in.npz"), os.path.join(td, "out.npz")
+    td = tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        inp, outp = os.path.join(td.name, "in.npz"), os.path.join(td.name, "out.npz")
         payload = {"dtype": np.dtype(dtype).name, "params": np.array([rho, abs_tol, rel_tol, max_iter, verbose,
                                                                       int(adaptive_rho), int(gap_stop), order],
                                                                      dtype=np.float64)}
@@ -205,23 +246,27 @@ def ref_solve(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, ma
             payload.update(sp_data=np.asarray(A.data, dtype=dtype), sp_ptr=np.asarray(A.indptr, np.int32),
                            sp_ind=np.asarray(A.indices, np.int32), sp_shape=np.array(A.shape))
         else:
-            np.save(os.path.join(td, "A.npy"), np.asarray(A, dtype=dtype))
+            np.save(os.path.join(td.name, "A.npy"), np.asarray(A, dtype=dtype))
         np.savez(inp, **payload)
         env = dict(os.environ)
         env.pop("PYTHONPATH", None)
-        cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_runner.py"), td]
-        proc = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
-        if proc.returncode != 0 or not os.path.exists(outp):
-            raise RuntimeError("reference runner failed:\n" + proc.stdout[-2000:] + proc.stderr[-2000:])
-        z = np.load(outp)
-        r = {"x": z["x"], "y": z["y"], "l": z["l"], "optval": float(z["optval"]), "iterations": int(z["iterations"]),
-             "status": int(z["status"]), "wall_s": float(z["wall_s"]), "stdout": proc.stdout}
-        import re
+        nthr = str(threads if threads else ref_threads())
+        env.update(MKL_NUM_THREADS=nthr, OMP_NUM_THREADS=nthr, MKL_DYNAMIC="FALSE")
+        cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_runner.py"), td.name]
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    except Exception:
+        td.cleanup()
+        raise
+    return RefRun(td, proc, outp, time.time())
 
-        mt = re.search(r"Total = ([0-9.eE+-]+) s, Init = ([0-9.eE+-]+) s", proc.stdout)
-        if mt:
-            r["t_total"], r["t_init"] = float(mt.group(1)), float(mt.group(2))
-        return r
+
+def ref_solve(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0,
+              adaptive_rho=True, gap_stop=True, order=1, timeout=None, threads=None):
+    """ref_start + finish.  Returns None if the reference is not available; raises
+    subprocess.TimeoutExpired on timeout."""
+    run = ref_start(A, f, g, dtype=dtype, rho=rho, abs_tol=abs_tol, rel_tol=rel_tol, max_iter=max_iter,
+                    verbose=verbose, adaptive_rho=adaptive_rho, gap_stop=gap_stop, order=order, threads=threads)
+    return None if run is None else run.finish(timeout)
 
 
 def oracle_solve_shard(A_local, m_global, f_local, g, allreduce, dtype=np.float64, rho=1.0, abs_tol=1e-4,

@@ -1,0 +1,178 @@
+"""Boundary behaviours of the C ABI that the reference shows to its callers:
+the non-convex-coefficient warning and clamp, the verbose summary, error returns instead of
+faults, and the device a handle lives on."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from helpers import relerr, soa
+
+pytestmark = pytest.mark.gpu
+
+
+def _pogs():
+    import pogs_amd
+
+    return pogs_amd
+
+
+def test_negative_c_and_e_are_clamped_with_the_reference_warning(capfd):
+    """FunctionObj::CheckConsts (src/include/prox_lib.h:62-69): c < 0 or e < 0 prints
+    'WARNING c < 0. Function not convex. Using c = 0' (resp. e) and the object is used with 0.
+    The solve must equal the oracle's (which restates the clamp) and the solve with the
+    coefficients already clamped."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.dense_lasso(400, 60, seed=3, dtype=np.float64)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 60)
+    g.e[:] = 0.05
+    g.h[5] = int(pogs.Function.kZero)
+    g.c[5] = -1.0       # c < 0 on a function whose prox ignores c: the clamp must not break the solve
+    g.e[7] = -0.5       # two negative e
+    f.e[3] = -1.0
+    got = pogs._solve_graph_form(A, f, g)
+    out = capfd.readouterr().out
+    assert out.count("WARNING c < 0. Function not convex. Using c = 0") == 1
+    assert out.count("WARNING e < 0. Function not convex. Using e = 0") == 2
+    fc, gc = f.slice(0, 400), g.slice(0, 60)
+    gc.c[5] = 0.0
+    gc.e[7] = 0.0
+    fc.e[3] = 0.0
+    clamped = pogs._solve_graph_form(A, fc, gc)
+    assert "WARNING" not in capfd.readouterr().out
+    want = ob.oracle_solve(A, soa(f), soa(g))     # 59 iterations, as the compiled reference
+    assert got["status"] == clamped["status"] == want["status"] == 0
+    assert got["iterations"] == clamped["iterations"]
+    assert np.array_equal(got["x"], clamped["x"])
+    assert abs(int(got["iterations"]) - int(want["iterations"])) <= 2
+    assert relerr(got["x"], want["x"]) < 1e-6
+    # many offenders: the first eight are printed, then a count
+    f.e[:100] = -1.0
+    pogs._solve_graph_form(A, f, g, max_iter=3)
+    out = capfd.readouterr().out
+    assert out.count("WARNING e < 0. Function not convex. Using e = 0") == 8 + 1   # f: the first eight of 100; g: its one
+    assert "WARNING e < 0 in 92 more function objects" in out
+    # a negative c where it matters makes the problem degenerate in the reference as well
+    # (c = 0 turns the prox parameter into infinity): same status and count as the oracle
+    f2, g2 = pogs.graph.lasso_functions(b, 0.1, 60)
+    f2.c[3] = -2.0
+    got2 = pogs._solve_graph_form(A, f2, g2, max_iter=200)
+    want2 = ob.oracle_solve(A, soa(f2), soa(g2), max_iter=200)
+    assert got2["status"] == want2["status"] and got2["iterations"] == want2["iterations"]
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_verbose_summary_in_the_reference_format(capfd, sparse):
+    """verbose >= 1: status / timing / iteration summary and the three normalised error metrics
+    (src/cpu/pogs.cpp:485-500); verbose >= 2: header and per-iteration lines with the primal
+    objective (pogs.cpp:193-195, 382-388)."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    if sparse:
+        A, b, _ = synth.csr_lasso(1500, 300, 12, seed=4, dtype=np.float64)
+    else:
+        A, b, _ = synth.dense_lasso(600, 80, seed=4, dtype=np.float64)
+    r = pogs.solve_lasso(A, b, 0.1, verbose=2)
+    out = capfd.readouterr().out
+    assert "Status: Solved" in out
+    assert "Timing: Total = " in out and ", Init = " in out
+    assert "Iter  : %u" % r["iterations"] in out
+    for key in ("Error Metrics:", "Pri: |Ax - y|    / (abs_tol sqrt(m)     / rel_tol + |y|)          = ",
+                "Dua: |A'l + u|   / (abs_tol sqrt(n)     / rel_tol + |u|)          = ",
+                "Gap: |x'u + y'l| / (abs_tol sqrt(m + n) / rel_tol + |x,u| |y,l|)  = "):
+        assert key in out, key
+    assert " Iter | pri res | pri tol | dua res | dua tol |   gap   | eps gap | pri obj" in out
+    lines = [ln for ln in out.splitlines() if ln[:5].strip().isdigit() and " : " in ln]
+    assert lines and lines[0].split(":")[0].strip() == "0"
+    last = lines[-1].split()
+    assert int(last[0]) == r["iterations"]
+    assert float(last[-1]) == pytest.approx(r["optval"], rel=1e-2)   # printed with 3 digits
+    # the normalised metrics are below rel_tol at convergence
+    for tag in ("Pri:", "Dua:", "Gap:"):
+        val = float([ln for ln in out.splitlines() if ln.startswith(tag)][0].split("=")[-1])
+        assert 0 <= val < 1e-4
+    pogs.solve_lasso(A, b, 0.1, verbose=0)
+    assert capfd.readouterr().out == ""
+
+
+def test_iterate_before_begin_run_is_an_error_not_a_garbage_run():
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.dense_lasso(300, 40, seed=5, dtype=np.float32)
+    with pogs.Solver(A, dtype=np.float32) as s:
+        with pytest.raises(RuntimeError, match="BeginRun"):
+            s.iterate(3)
+        f, g = pogs.graph.lasso_functions(b, 0.1, 40)
+        s.begin_run(f, g)
+        s.iterate(3)
+    As, bs, _ = synth.csr_lasso(500, 100, 8, seed=5, dtype=np.float32)
+    with pogs.Solver(As, dtype=np.float32) as s:
+        with pytest.raises(RuntimeError, match="BeginRun"):
+            s.iterate(1)
+
+
+def test_malformed_sparse_input_returns_pogs_error():
+    """Indices out of range / a decreasing ptr must come back as POGS_ERROR (6), not as
+    out-of-bounds device writes."""
+    pogs = _pogs()
+    from pogs_amd import _lib, synth
+
+    A, b, _ = synth.csr_lasso(200, 50, 5, seed=6, dtype=np.float64)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 50)
+    fa, ga = f.arrays(np.float64), g.arrays(np.float64)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+
+    def call(data, ptr, ind):
+        x, y, l = np.zeros(50), np.zeros(200), np.zeros(200)
+        ov, it = ctypes.c_double(), ctypes.c_uint()
+        return _lib.lib.PogsSparseD(1, 200, 50, len(data), P(data), P(ptr), P(ind),
+                                    *[P(fa[k]) for k in "abcdeh"], *[P(ga[k]) for k in "abcdeh"],
+                                    1.0, 1e-4, 1e-4, 100, 0, 1, 1, P(x), P(y), P(l), ctypes.byref(ov), ctypes.byref(it))
+
+    data, ptr, ind = A.data.copy(), A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    assert call(data, ptr, ind) == 0
+    bad = ind.copy()
+    bad[17] = 50
+    assert call(data, ptr, bad) == 6 and "index" in _lib.last_error()
+    bad[17] = -1
+    assert call(data, ptr, bad) == 6
+    badp = ptr.copy()
+    badp[10], badp[11] = ptr[11], ptr[10]
+    if badp[11] < badp[10]:
+        assert call(data, badp, ind) == 6 and "ptr" in _lib.last_error()
+
+
+def test_handle_keeps_its_device_and_leaves_the_callers_device_alone():
+    """The device is selected per entry point, not once at creation (HIP's current device is
+    per thread): a handle used from another thread works, and creation with an explicit device
+    leaves the caller's current device as it was."""
+    import threading
+
+    import torch
+
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.dense_lasso(500, 64, seed=7, dtype=np.float32)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 64)
+    before = torch.cuda.current_device()
+    s = pogs.Solver(A, dtype=np.float32, device=0)
+    assert torch.cuda.current_device() == before
+    want = s.solve(f, g)
+    got = {}
+
+    def other_thread():
+        got["r"] = s.solve(f, g)
+        got["eq"] = s.equilibrated(want_matrix=False)[3]
+
+    t = threading.Thread(target=other_thread)
+    t.start()
+    t.join(120)
+    assert got["r"]["status"] == 0 and np.array_equal(got["r"]["x"], want["x"])
+    s.close()
+    assert torch.cuda.current_device() == before

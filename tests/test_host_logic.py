@@ -84,3 +84,34 @@ def test_length_validation_like_reference():
         G._solve_graph_form(A, f.slice(0, 5), g)
     with pytest.raises(ValueError):
         G._solve_graph_form(A, f, g, dtype=np.int32)
+
+
+def test_bench_self_launches_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus 8` without a launcher re-executes itself under torch.distributed.run
+    (one rank per GPU, 127.0.0.1 rendezvous); under a launcher (WORLD_SIZE set) it does not."""
+    import importlib.util
+    import os
+    import sys
+    import types
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    spec = importlib.util.spec_from_file_location("_bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+    monkeypatch.setattr(bench.os, "execve", lambda exe, argv, env: calls.append((exe, argv, env)))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    bench.maybe_spawn(types.SimpleNamespace(gpus=8))
+    assert len(calls) == 1
+    exe, argv, env = calls[0]
+    assert exe == sys.executable and argv[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in argv and argv[argv.index("--nproc-per-node") + 1] == "8"
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert argv[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # single GPU or already under a launcher: nothing happens
+    bench.maybe_spawn(types.SimpleNamespace(gpus=1))
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    bench.maybe_spawn(types.SimpleNamespace(gpus=8))
+    assert len(calls) == 1
