@@ -457,18 +457,18 @@ struct DevCsr {
   int nrows = 0, ncols = 0, nblocks = 0;
   size_t nnz = 0;
   Csr<T> view() const { return Csr<T>{val.p, ind.p, ptr.p, blocks.p, nrows, nblocks}; }
-  // tiled sliced-ELL copy (sell.h); sell_ready == false: not built, the plain kernel runs
+  // tiled lane-stream copy (sell.h); sell_ready == false: not built, the plain kernel runs
   DevBuf<T> sval, part;
-  DevBuf<unsigned short> sloc, sperm;
-  DevBuf<unsigned> sdesc;
-  DevBuf<int> tile_ptr;
-  DevBuf<unsigned short> scnt, sslot;   // build temporaries kept until the values are final (refill_sell)
+  DevBuf<unsigned short> sloc, srid;
+  DevBuf<int> tile_unit;
+  DevBuf<unsigned short> scnt;   // build temporaries kept until the values are final (refill_sell)
+  DevBuf<unsigned> ssoff;
   bool sell_ready = false;
-  int rr_rows = 0, nrr = 0, ncb = 0, ncg = 1, cb_per_group = 1;
-  size_t sell_elems = 0, sell_slices = 0;
+  int rr_rows = 0, nrr = 0, ncb = 0, ncg = 1;
+  size_t sell_elems = 0;
   SellDims sdims() const { return SellDims{nrows, ncols, rr_rows, nrr, ncb, SellCfg<T>::BW}; }
   SellView<T> sview() const {
-    return SellView<T>{sval.p, sloc.p, sperm.p, sdesc.p, tile_ptr.p, nrows, ncols, rr_rows, nrr, ncb, ncg, cb_per_group};
+    return SellView<T>{sval.p, sloc.p, srid.p, tile_unit.p, nrows, ncols, rr_rows, nrr, ncb, ncg};
   }
 };
 
@@ -707,9 +707,9 @@ class SparseSolver final : public SolverBase {
     ctx_.sync();   // temporaries are freed at scope exit
   }
 
-  // Tiled sliced-ELL copy of M (sell.h): structure and values now, values again after the
+  // Tiled lane-stream copy of M (sell.h): structure and values now, values again after the
   // equilibration has rescaled the CSR copy (refill_sell).  Skipped (the plain CSR kernel then
-  // runs) when the per-(tile, row) bookkeeping could not be indexed with 32 bits.
+  // runs) when the bookkeeping could not be indexed with 32 bits or the padding would blow up.
   void build_sell(DevCsr<T> &M) {
     hipStream_t s = ctx_.stream;
     constexpr int BW = SellCfg<T>::BW, RRMAX = SellCfg<T>::RR;
@@ -718,60 +718,61 @@ class SparseSolver final : public SolverBase {
     // rows per row range: as many as the LDS holds, fewer when the matrix would otherwise give
     // the chip less than ~2 workgroups per CU (column groups can only multiply by ncb)
     const long long want = static_cast<long long>(M.nrows) * ncb / (2LL * ctx_.num_cu);
-    int rr_rows = static_cast<int>(round_up(static_cast<size_t>(std::max<long long>(256, std::min<long long>(RRMAX, want))), 64));
+    int rr_rows = static_cast<int>(round_up(static_cast<size_t>(std::max<long long>(512, std::min<long long>(RRMAX, want))), 64));
     rr_rows = std::min(rr_rows, RRMAX);
     const int nrr = (M.nrows + rr_rows - 1) / rr_rows;
     const long long ntiles = static_cast<long long>(nrr) * ncb;
     const long long nq = ntiles * rr_rows;
     if (ntiles >= (1LL << 30) || nq >= (1LL << 31)) return;
+    // column groups: the count that fills whole rounds of workgroups (one per CU) best, with the
+    // column blocks split evenly; ties go to fewer groups (fewer partial sums)
     int ncg = 1;
-    while (static_cast<long long>(nrr) * ncg < 2LL * ctx_.num_cu && ncg < ncb) ncg *= 2;
-    int cbpg = (ncb + ncg - 1) / ncg;
-    ncg = (ncb + cbpg - 1) / cbpg;
-    M.rr_rows = rr_rows; M.nrr = nrr; M.ncb = ncb; M.ncg = ncg; M.cb_per_group = cbpg;
+    double best = -1;
+    for (int g = 1; g <= std::min(ncb, 32); ++g) {
+      const long long nwg = static_cast<long long>(nrr) * g;
+      const long long rounds = (nwg + ctx_.num_cu - 1) / ctx_.num_cu;
+      const double fill = static_cast<double>(nwg) / static_cast<double>(rounds * ctx_.num_cu);
+      const double even = (static_cast<double>(ncb) / g) / static_cast<double>((ncb + g - 1) / g);
+      const double eff = fill * even;
+      if (eff > best + 1e-9) { best = eff; ncg = g; }
+    }
+    M.rr_rows = rr_rows; M.nrr = nrr; M.ncb = ncb; M.ncg = ncg;
     const SellDims D = M.sdims();
-    M.scnt.alloc(nq); M.sslot.alloc(nq);
+    M.scnt.alloc(nq); M.ssoff.alloc(nq);
     M.scnt.zero(s);
     const int g = std::max(1, std::min((M.nrows + 255) / 256, ctx_.num_cu * 16));
     hipLaunchKernelGGL(sell_count_kernel, dim3(g), dim3(256), 0, s, M.ind.p, M.ptr.p, D, M.scnt.p);
-    DevBuf<int> ns(ntiles + 1), nu(ntiles + 1), uptr(ntiles + 1);
-    M.tile_ptr.alloc(ntiles + 1);
+    DevBuf<int> nu(ntiles + 1), err(1);
+    err.zero(s);
+    M.tile_unit.alloc(ntiles + 1);
     const int gt = static_cast<int>(std::min<long long>(ntiles, ctx_.num_cu * 8));
-    hipLaunchKernelGGL(sell_plan_kernel<false>, dim3(gt), dim3(256), 0, s, M.scnt.p, D, ns.p, nu.p,
-                       static_cast<const int *>(nullptr), static_cast<const int *>(nullptr),
-                       static_cast<unsigned *>(nullptr), static_cast<unsigned short *>(nullptr),
-                       static_cast<unsigned short *>(nullptr));
-    exclusive_scan(ns.p, static_cast<int>(ntiles), M.tile_ptr.p);
-    exclusive_scan(nu.p, static_cast<int>(ntiles), uptr.p);
-    int tot[2] = {0, 0};
-    POGS_HIP_CHECK(hipMemcpyAsync(&tot[0], M.tile_ptr.p + ntiles, sizeof(int), hipMemcpyDeviceToHost, s));
-    POGS_HIP_CHECK(hipMemcpyAsync(&tot[1], uptr.p + ntiles, sizeof(int), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(sell_plan_kernel, dim3(gt), dim3(256), rr_rows * sizeof(unsigned short), s, M.scnt.p, D, nu.p,
+                       M.ssoff.p, err.p);
+    exclusive_scan(nu.p, static_cast<int>(ntiles), M.tile_unit.p);
+    int tot = 0, herr = 0;
+    POGS_HIP_CHECK(hipMemcpyAsync(&tot, M.tile_unit.p + ntiles, sizeof(int), hipMemcpyDeviceToHost, s));
+    POGS_HIP_CHECK(hipMemcpyAsync(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost, s));
     ctx_.sync();
-    // (units fit 26 bits of a descriptor; a padding blow-up beyond 4x the non-zeros -- a matrix
-    // of a few very long and many empty rows per tile -- is left to the plain kernel)
-    if (tot[0] <= 0 || tot[1] <= 0 || tot[1] >= (1 << 26) ||
-        static_cast<size_t>(tot[1]) * 64 > 4 * M.nnz + (static_cast<size_t>(1) << 22)) {
-      M.scnt.release(); M.sslot.release(); M.tile_ptr.release();
+    // (a padding blow-up beyond 4x the non-zeros -- a few very long rows among many short ones in
+    // a tile -- is left to the plain kernel)
+    if (herr != 0 || tot <= 0 || static_cast<size_t>(tot) * 64 > 4 * M.nnz + (static_cast<size_t>(1) << 22)) {
+      M.scnt.release(); M.ssoff.release(); M.tile_unit.release();
       return;
     }
-    M.sell_slices = static_cast<size_t>(tot[0]);
-    M.sell_elems = static_cast<size_t>(tot[1]) * 64;
-    M.sdesc.alloc(M.sell_slices);
-    M.sperm.alloc(M.sell_slices * 64);
+    M.sell_elems = static_cast<size_t>(tot) * 64;
     M.sval.alloc(M.sell_elems);
     M.sloc.alloc(M.sell_elems);
-    POGS_HIP_CHECK(hipMemsetAsync(M.sperm.p, 0xFF, M.sell_slices * 64 * sizeof(unsigned short), s));
+    M.srid.alloc(M.sell_elems);
     M.sval.zero(s);
     M.sloc.zero(s);
-    hipLaunchKernelGGL(sell_plan_kernel<true>, dim3(gt), dim3(256), 0, s, M.scnt.p, D, static_cast<int *>(nullptr),
-                       static_cast<int *>(nullptr), M.tile_ptr.p, uptr.p, M.sdesc.p, M.sperm.p, M.sslot.p);
+    POGS_HIP_CHECK(hipMemsetAsync(M.srid.p, 0xFF, M.sell_elems * sizeof(unsigned short), s));
     M.sell_ready = true;
     fill_sell(M, true);
     if (ncg > 1) M.part.alloc(static_cast<size_t>(ncg) * M.nrows);
-    ctx_.sync();   // ns / nu / uptr are freed at scope exit
+    ctx_.sync();   // nu / err are freed at scope exit
   }
 
-  // (re)writes the tiled values from M.val; with_loc also the local columns
+  // (re)writes the tiled values from M.val; with_loc also the local columns and the row tags
   void fill_sell(DevCsr<T> &M, bool with_loc) {
     if (!M.sell_ready) return;
     hipStream_t s = ctx_.stream;
@@ -780,14 +781,14 @@ class SparseSolver final : public SolverBase {
     cursor.zero(s);
     const int g = std::max(1, std::min((M.nrows + 255) / 256, ctx_.num_cu * 16));
     hipLaunchKernelGGL(sell_fill_kernel<T>, dim3(g), dim3(256), 0, s, M.val.p, M.ind.p, M.ptr.p, M.sdims(), M.scnt.p,
-                       M.sslot.p, cursor.p, M.tile_ptr.p, M.sdesc.p, M.sval.p, with_loc ? M.sloc.p : nullptr);
+                       M.ssoff.p, cursor.p, M.tile_unit.p, M.sval.p, with_loc ? M.sloc.p : nullptr, M.srid.p);
     ctx_.sync();   // cursor is freed at scope exit
   }
   // the values are final (equilibrated): refill and drop the build temporaries
   void refill_sell(DevCsr<T> &M) {
     fill_sell(M, false);
     M.scnt.release();
-    M.sslot.release();
+    M.ssoff.release();
   }
 
   void alloc_state() {
