@@ -143,7 +143,8 @@ typedef struct PogsAmdStats {
   /* one-time setup pieces, HIP-event timed */
   double equil_ms, normest_ms, gram_ms, chol_ms, trtri_ms;
   double gram_flops;
-  double reserved[8];
+  double reserved[8];             /* [0] / [1]: one-pass iteration, rho predictions hit / missed;
+                                     [2]: all-reduce calls issued by the handle so far      */
 } PogsAmdStats;
 
 /* Fill `out` (POGS_AMD_UNIQUE_ID_BYTES) with a fresh RCCL unique id (rank 0
@@ -224,6 +225,12 @@ int PogsAmdProxEval(int dtype, size_t n, const int *h, const void *a, const void
 int PogsAmdFuncEval(int dtype, size_t n, const int *h, const void *a, const void *b,
                     const void *c, const void *d, const void *e, const void *in,
                     double *out);
+/* v_out[i] = ProjSubgrad{f_i}(v_in[i]) at x_in[i]: the point of the subdifferential of f_i at
+ * x_in[i] closest to v_in[i] (reference: ProjSubgradEval, src/include/prox_lib.h:468-493,
+ * 538-546; unused by the reference's solvers, part of its prox library).  HOST pointers. */
+int PogsAmdProjSubgradEval(int dtype, size_t n, const int *h, const void *a, const void *b,
+                           const void *c, const void *d, const void *e, const void *x_in,
+                           const void *v_in, void *v_out);
 /* Equilibrated matrix, scalings and norm estimate of a solver (HOST outputs,
  * any may be NULL): A_eq (m*n row-major), d (m), e (n). */
 int PogsAmdGetEquil(const PogsAmdSolver *s, void *A_eq, void *d, void *e, double *nrmA);

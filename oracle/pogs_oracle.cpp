@@ -11,7 +11,7 @@
 // (oracle/_ref/libpogs_cpu.so built by oracle/Makefile from the reference's
 // own sources + MKL) and against the golden fixtures in tests/golden/ that the
 // compiled reference produced (tests/golden/make_golden.py).  See
-// tests/test_oracle_vs_golden.py and tests/test_oracle_vs_ref.py.
+// tests/test_oracle_golden.py and tests/test_oracle_vs_ref.py.
 //
 // The vendor BLAS/LAPACK arithmetic the reference delegates to
 // (CMakeLists.txt:72-73, un-pinned) is restated as plain loops; results agree
@@ -280,6 +280,36 @@ inline T FuncEval(const FunctionObj<T> &f, T x) {         // prox_lib.h:326-349
     case kZero: default: x = 0; break;
   }
   return f.c * x + dx + ex;
+}
+
+// Projection onto the subdifferential (prox_lib.h:359-466 per function, :468-493 with the
+// affine composition): restated case by case as the reference lists them.
+template <typename T>
+inline T ProjSubgradEval(const FunctionObj<T> &f, T v, T x) {
+  const T a = f.a, b = f.b, c = f.c, d = f.d, e = f.e;
+  if (a == static_cast<T>(0) || c == static_cast<T>(0)) return d + e * x;   // :471-472
+  v = static_cast<T>(1) / (a * c) * (v - d - e * x);                          // :473
+  const T u = a * x - b;                                                     // :474
+  const T zero = 0, one = 1;
+  switch (f.h) {
+    case kAbs: v = u < zero ? -one : (u > zero ? one : Max(-one, Min(one, v))); break;            // :360-368
+    case kNegEntr: v = -Log(u) - one; break;                                                       // :371-373
+    case kExp: v = Exp(u); break;                                                                  // :376-378
+    case kHuber: v = Max(-one, Min(one, u)); break;                                                // :381-383
+    case kIdentity: v = one; break;                                                                // :386-388
+    case kIndBox01: v = u <= zero ? Min(zero, v) : (u >= one ? Max(zero, v) : zero); break;        // :391-398
+    case kIndEq0: break;                                                                           // :401-403
+    case kIndGe0: v = u <= zero ? Min(zero, v) : zero; break;                                      // :406-411
+    case kIndLe0: v = u >= zero ? Max(zero, v) : zero; break;                                      // :414-419
+    case kLogistic: v = Exp(u) / (one + Exp(u)); break;                                            // :422-424
+    case kMaxNeg0: v = u < zero ? -one : (u > zero ? zero : Min(zero, Max(-one, v))); break;       // :427-434
+    case kMaxPos0: v = u < zero ? zero : (u > zero ? one : Min(one, Max(zero, v))); break;         // :437-444
+    case kNegLog: v = -one / u; break;                                                             // :447-449
+    case kRecipr: v = one / (u * u); break;                                                        // :452-454
+    case kSquare: v = u; break;                                                                    // :457-459
+    case kZero: default: v = zero; break;                                                          // :462-464
+  }
+  return a * c * v + d + e * x;                                                                    // :492
 }
 
 template <typename T>
@@ -1229,6 +1259,16 @@ ORACLE_SPARSE_SHARD(OraclePogsSparseShardS, float)
   }
 ORACLE_PROX(OracleProxEvalD, OracleFuncEvalD, double)
 ORACLE_PROX(OracleProxEvalS, OracleFuncEvalS, float)
+
+// v_out[i] = ProjSubgradEval(f_i, v_in[i], x_in[i])   (prox_lib.h:538-546)
+#define ORACLE_PROJSUB(NAME, T)                                                            \
+  void NAME(size_t n, const int *h, const T *a, const T *b, const T *c, const T *d,        \
+            const T *e, const T *x_in, const T *v_in, T *v_out) {                          \
+    auto f = make_objs(n, a, b, c, d, e, h);                                               \
+    for (size_t i = 0; i < n; ++i) v_out[i] = ProjSubgradEval(f[i], v_in[i], x_in[i]);     \
+  }
+ORACLE_PROJSUB(OracleProjSubgradEvalD, double)
+ORACLE_PROJSUB(OracleProjSubgradEvalS, float)
 
 // Raw prox_h(v, rho) (the functions tests/test_proximal.cpp of the reference pins).
 double OracleProxRawD(int h, double v, double rho) {

@@ -81,6 +81,12 @@ ORACLE_DECL_SPARSE(OraclePogsSparseS, float)
 ORACLE_DECL_PROX(OracleProxEvalD, OracleFuncEvalD, double)
 ORACLE_DECL_PROX(OracleProxEvalS, OracleFuncEvalS, float)
 
+#define ORACLE_DECL_PROJSUB(NAME, T)                                                  \
+  void NAME(size_t n, const int *h, const T *a, const T *b, const T *c, const T *d,  \
+            const T *e, const T *x_in, const T *v_in, T *v_out);
+ORACLE_DECL_PROJSUB(OracleProjSubgradEvalD, double)
+ORACLE_DECL_PROJSUB(OracleProjSubgradEvalS, float)
+
 double OracleProxRawD(int h, double v, double rho);
 float OracleProxRawS(int h, float v, float rho);
 void OracleRandS(float *x, size_t n);

@@ -13,6 +13,7 @@ from .graph import (  # noqa: F401
     _solve_graph_form,
     dist_unique_id,
     func_eval,
+    proj_subgrad_eval,
     prox_eval,
     rand_uniform,
     solve_elastic_net,

@@ -101,6 +101,7 @@ lib.PogsAmdDestroy.restype = None
 lib.PogsAmdLastError.restype = ctypes.c_char_p
 lib.PogsAmdProxEval.argtypes = [c_int, c_size_t] + [c_void_p] * 6 + [c_double, c_void_p, c_void_p]
 lib.PogsAmdFuncEval.argtypes = [c_int, c_size_t] + [c_void_p] * 6 + [c_void_p, ctypes.POINTER(c_double)]
+lib.PogsAmdProjSubgradEval.argtypes = [c_int, c_size_t] + [c_void_p] * 6 + [c_void_p, c_void_p, c_void_p]
 lib.PogsAmdGetEquil.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_double)]
 lib.PogsAmdProject.argtypes = [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p]
 lib.PogsAmdMul.argtypes = [c_void_p, c_char, c_double, c_void_p, c_double, c_void_p]
@@ -111,7 +112,7 @@ ABI_SYMBOLS = [
     "PogsD", "PogsS", "PogsSparseD", "PogsSparseS",
     "PogsAmdDistUniqueId", "PogsAmdCreateDense", "PogsAmdCreateSparse", "PogsAmdSolve", "PogsAmdBeginRun",
     "PogsAmdIterate", "PogsAmdSetWarmStart", "PogsAmdGetStats", "PogsAmdResetStats", "PogsAmdDestroy", "PogsAmdLastError",
-    "PogsAmdProxEval", "PogsAmdFuncEval", "PogsAmdGetEquil", "PogsAmdProject", "PogsAmdMul", "PogsAmdRandUniform",
+    "PogsAmdProxEval", "PogsAmdFuncEval", "PogsAmdProjSubgradEval", "PogsAmdGetEquil", "PogsAmdProject", "PogsAmdMul", "PogsAmdRandUniform",
 ]
 
 

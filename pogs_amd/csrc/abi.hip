@@ -162,7 +162,7 @@ int pogs_sparse(enum ORD ord, size_t m, size_t n, size_t nnz, const T *data, con
 
 template <typename T>
 void prox_eval_host(size_t n, const int *h, const void *a, const void *b, const void *c, const void *d,
-                    const void *e, double rho, const void *in, void *out, double *fsum) {
+                    const void *e, double rho, const void *in, void *out, double *fsum, const void *xin = nullptr) {
   POGS_CHECK(n < (1u << 31), "n too large");
   hipStream_t s = nullptr;
   const int cnt = static_cast<int>(n);
@@ -176,11 +176,21 @@ void prox_eval_host(size_t n, const int *h, const void *a, const void *b, const 
   up(fb.a.p, a, n * sizeof(T)); up(fb.b.p, b, n * sizeof(T)); up(fb.c.p, c, n * sizeof(T));
   up(fb.d.p, d, n * sizeof(T)); up(fb.e.p, e, n * sizeof(T));
   up(vin.p, in, n * sizeof(T));
+  {
+    FnHost fh{a, b, c, d, e, h};
+    warn_negative_coeffs<T>(fh, n);
+  }
   // clamp c, e >= 0 as FunctionObj's constructor does (prox_lib.h:62-69): scale by 1.
   DevBuf<T> ones(n);
   launch_fill<T>(ones.p, static_cast<T>(1), n, s);
   launch_scale_objective<T>(fb.view(), fb.a.p, fb.c.p, fb.d.p, fb.e.p, ones.p, cnt, false, s);
-  if (out) {
+  if (out && xin) {   // ProjSubgradEval: `in` is v, `xin` the point x
+    DevBuf<T> xv(n);
+    up(xv.p, xin, n * sizeof(T));
+    launch_proj_subgrad<T>(cnt, fb.view(), xv.p, vin.p, vout.p, s);
+    POGS_HIP_CHECK(hipMemcpyAsync(out, vout.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+    POGS_HIP_CHECK(hipStreamSynchronize(s));   // xv is freed at scope exit
+  } else if (out) {
     launch_prox_eval<T>(cnt, fb.view(), static_cast<T>(rho), vin.p, vout.p, s);
     POGS_HIP_CHECK(hipMemcpyAsync(out, vout.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
   }
@@ -368,6 +378,16 @@ int PogsAmdFuncEval(int dtype, size_t n, const int *h, const void *a, const void
   return guarded([&]() {
     if (dtype == POGS_AMD_F32) prox_eval_host<float>(n, h, a, b, c, d, e, 1.0, in, nullptr, out);
     else prox_eval_host<double>(n, h, a, b, c, d, e, 1.0, in, nullptr, out);
+    return 0;
+  });
+}
+
+int PogsAmdProjSubgradEval(int dtype, size_t n, const int *h, const void *a, const void *b, const void *c,
+                           const void *d, const void *e, const void *x_in, const void *v_in, void *v_out) {
+  return guarded([&]() {
+    POGS_CHECK(x_in && v_in && v_out, "null argument");
+    if (dtype == POGS_AMD_F32) prox_eval_host<float>(n, h, a, b, c, d, e, 1.0, v_in, v_out, nullptr, x_in);
+    else prox_eval_host<double>(n, h, a, b, c, d, e, 1.0, v_in, v_out, nullptr, x_in);
     return 0;
   });
 }

@@ -409,7 +409,7 @@ class DenseSolver final : public SolverBase {
     const size_t vb = vec_blocks(n_) + vec_blocks(m_);
     const size_t r01 = static_cast<size_t>(planA_.grid_max) * 6 + std::max<size_t>(4096, vb * 3 + 64);
     sp_pre_off_ = r01;   // [y-half prox sums: vec_blocks(m) x 3 | pre_cols sums: column blocks x 4]
-    sp_tail_off_ = r01 + vb * 3 + static_cast<size_t>(reduce_cols_grid(n_pad_, Vec16<T>::N)) * 4 + 64;
+    sp_tail_off_ = r01 + vb * 3 + static_cast<size_t>(pre_cols_grid(n_pad_, Vec16<T>::N)) * 4 + 64;
     ctx_.ensure_spart(sp_tail_off_ + static_cast<size_t>(ctx_.num_cu) * 32);
   }
 
@@ -1288,7 +1288,7 @@ class DenseSolver final : public SolverBase {
     hipStream_t s = ctx_.stream;
     const int nw = cur_ ^ 1;
     const int by = vec_blocks(m_);
-    const int gridC = reduce_cols_grid(n_pad_, Vec16<T>::N);
+    const int gridC = pre_cols_grid(n_pad_, Vec16<T>::N);
     // every scalar sum of the iteration that needs no exchange runs in the launch that publishes
     // the scalar block; on row shards the y-side sums travel in the tail of the pack buffer
     struct DeferGuard {

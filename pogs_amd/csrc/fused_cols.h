@@ -54,64 +54,82 @@ struct PreColsArgs {
   double *partials;         // out: [grid][4] = sum w h, |w|^2, |h|^2, |exact dual residual|^2
 };
 
+// Workgroup = 256 threads = 16 column vectors (64 fp32 / 32 fp64 columns) x 16 groups of partials;
+// then one thread per column finishes the sums and runs the column's x-half.  (Narrow column
+// blocks: the launch has ~n / 64 workgroups, enough to spread the 40 MB of partials over the CUs.)
+constexpr int kPreColsVecs = 16, kPreColsGroups = 16;
+inline int pre_cols_grid(int n_pad, int vec) { return (n_pad / vec + kPreColsVecs - 1) / kPreColsVecs; }
+
 template <typename T, bool SRC64>
 __global__ void __launch_bounds__(256) pre_cols_kernel(PreColsArgs<T> a) {
   using V = typename Vec16<T>::type;
   constexpr int VEC = Vec16<T>::N;
-  __shared__ V s_v[2][8][32];
+  constexpr int NC = kPreColsVecs * VEC;   // columns per workgroup
+  __shared__ T s_v[2][kPreColsGroups][NC];
   __shared__ double s_red[4 * 4];
-  const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int col = (blockIdx.x * 32 + cx) * VEC;
+  const int cx = threadIdx.x % kPreColsVecs, g = threadIdx.x / kPreColsVecs;
+  const int col0 = blockIdx.x * NC;
   if (!SRC64) {
+    const int col = col0 + cx * VEC;
     V s0 = dev::vzero<V>(), s1 = dev::vzero<V>();
     if (col < a.n_pad) {
-      s0 = colsum_group<T>(a.part0, a.nparts, a.n_pad, col, g);
-      s1 = colsum_group<T>(a.part1, a.nparts, a.n_pad, col, g);
+      // two independent chains per set keep more loads in flight (the partials sit in L2 / Infinity Cache)
+      V t0 = dev::vzero<V>(), t1 = dev::vzero<V>();
+      int b = g;
+      for (; b + kPreColsGroups < a.nparts; b += 2 * kPreColsGroups) {
+        const V u0 = *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col);
+        const V u1 = *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b) * a.n_pad + col);
+        const V w0 = *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b + kPreColsGroups) * a.n_pad + col);
+        const V w1 = *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b + kPreColsGroups) * a.n_pad + col);
+        dev::vfma(s0, static_cast<T>(1), u0);
+        dev::vfma(s1, static_cast<T>(1), u1);
+        dev::vfma(t0, static_cast<T>(1), w0);
+        dev::vfma(t1, static_cast<T>(1), w1);
+      }
+      if (b < a.nparts) {
+        dev::vfma(s0, static_cast<T>(1), *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col));
+        dev::vfma(s1, static_cast<T>(1), *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b) * a.n_pad + col));
+      }
+      dev::vfma(s0, static_cast<T>(1), t0);
+      dev::vfma(s1, static_cast<T>(1), t1);
     }
-    s_v[0][g][cx] = s0;
-    s_v[1][g][cx] = s1;
+    *reinterpret_cast<V *>(&s_v[0][g][cx * VEC]) = s0;
+    *reinterpret_cast<V *>(&s_v[1][g][cx * VEC]) = s1;
     __syncthreads();
   }
   double sacc[4] = {0.0, 0.0, 0.0, 0.0};
-  if (g == 0 && col < a.n_pad) {
-    T t0[VEC], t1[VEC];
+  const int j = col0 + static_cast<int>(threadIdx.x);
+  if (threadIdx.x < NC && j < a.n_pad) {
+    T t0, t1;
     if (SRC64) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        t0[i] = static_cast<T>(a.tot64[col + i]);
-        t1[i] = static_cast<T>(a.tot64[a.n_pad + col + i]);
-      }
+      t0 = static_cast<T>(a.tot64[j]);
+      t1 = static_cast<T>(a.tot64[a.n_pad + j]);
     } else {
-      V tot0 = s_v[0][0][cx], tot1 = s_v[1][0][cx];
+      t0 = s_v[0][0][threadIdx.x];
+      t1 = s_v[1][0][threadIdx.x];
 #pragma unroll
-      for (int q = 1; q < 8; ++q) {
-        dev::vfma(tot0, static_cast<T>(1), s_v[0][q][cx]);
-        dev::vfma(tot1, static_cast<T>(1), s_v[1][q][cx]);
+      for (int q = 1; q < kPreColsGroups; ++q) {   // groups in order: a fixed summation order
+        t0 += s_v[0][q][threadIdx.x];
+        t1 += s_v[1][q][threadIdx.x];
       }
-      __builtin_memcpy(t0, &tot0, sizeof(V));
-      __builtin_memcpy(t1, &tot1, sizeof(V));
     }
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const int j = col + i;
-      if (j < a.n) {
-        const T prev = a.x_cur[j];
-        const T xtj = a.xt[j];
-        const T ztv = a.zt_scale * xtj;
-        const T v = prev - ztv;                                                          // pogs.cpp:257
-        const T h = dev::ProxEval(a.g.h[j], a.g.a[j], a.g.b[j], a.g.c[j], a.g.d[j], a.g.e[j], v, a.rho);   // :263
-        const T w = v - h;                                                               // :267
-        a.x12[j] = h;
-        a.xtemp[j] = ztv + a.alpha * h + (static_cast<T>(1) - a.alpha) * prev;           // :276-278
-        sacc[0] += static_cast<double>(w) * h;                                           // :268
-        sacc[1] += static_cast<double>(w) * w;
-        sacc[2] += static_cast<double>(h) * h;
-        a.rhs[j] = t0[i];
-        const T sd = t1[i] + h + a.zt_scale * xtj - prev;                                // :366-373
-        sacc[3] += static_cast<double>(sd) * sd;
-      } else {
-        a.rhs[j] = static_cast<T>(0);
-      }
+    if (j < a.n) {
+      const T prev = a.x_cur[j];
+      const T xtj = a.xt[j];
+      const T ztv = a.zt_scale * xtj;
+      const T v = prev - ztv;                                                          // pogs.cpp:257
+      const T h = dev::ProxEval(a.g.h[j], a.g.a[j], a.g.b[j], a.g.c[j], a.g.d[j], a.g.e[j], v, a.rho);   // :263
+      const T w = v - h;                                                               // :267
+      a.x12[j] = h;
+      a.xtemp[j] = ztv + a.alpha * h + (static_cast<T>(1) - a.alpha) * prev;           // :276-278
+      sacc[0] = static_cast<double>(w) * h;                                            // :268
+      sacc[1] = static_cast<double>(w) * w;
+      sacc[2] = static_cast<double>(h) * h;
+      a.rhs[j] = t0;
+      const T sd = t1 + h + a.zt_scale * xtj - prev;                                   // :366-373
+      sacc[3] = static_cast<double>(sd) * sd;
+    } else {
+      a.rhs[j] = static_cast<T>(0);
     }
   }
   __syncthreads();
@@ -124,7 +142,7 @@ __global__ void __launch_bounds__(256) pre_cols_kernel(PreColsArgs<T> a) {
 
 template <typename T>
 void launch_pre_cols(const PreColsArgs<T> &a, bool src64, hipStream_t s) {
-  const int grid = reduce_cols_grid(a.n_pad, Vec16<T>::N);
+  const int grid = pre_cols_grid(a.n_pad, Vec16<T>::N);
   if (src64) hipLaunchKernelGGL((pre_cols_kernel<T, true>), dim3(grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((pre_cols_kernel<T, false>), dim3(grid), dim3(256), 0, s, a);
 }

@@ -242,6 +242,57 @@ __device__ inline T FuncEval(int h, T a, T b, T c, T d, T e, T x) {
   return c * x + dx + ex;
 }
 
+// ---- projection onto the subdifferential (prox_lib.h:359-493) --------------------------------
+// ProjSubgrad{h}(v, x): the point of the subdifferential of h at x closest to v.  Three families:
+//   * differentiable h: the gradient, whatever v is (values as the reference's, including its
+//     +1/x^2 for kRecipr);
+//   * one kink at 0 with slopes lo (left) and hi (right) -- |x|, max(0, -x), max(0, x): the slope
+//     away from the kink, v clipped to [lo, hi] on it;
+//   * indicators of an interval: the normal cone -- 0 inside, v's non-positive part at the lower
+//     end, its non-negative part at the upper end (kIndEq0: the whole line, i.e. v).
+template <typename T>
+__device__ __forceinline__ T kink_subgrad(T x, T lo, T hi, T v) {
+  if (x < 0) return lo;
+  if (x > 0) return hi;
+  return Max(lo, Min(hi, v));
+}
+template <typename T>
+__device__ inline T ProjSubgradBase(int h, T v, T x) {
+  const T zero = 0, one = 1;
+  switch (h) {
+    case kAbs: return kink_subgrad(x, -one, one, v);
+    case kMaxNeg0: return kink_subgrad(x, -one, zero, v);
+    case kMaxPos0: return kink_subgrad(x, zero, one, v);
+    case kIndGe0: return x <= zero ? Min(zero, v) : zero;
+    case kIndLe0: return x >= zero ? Max(zero, v) : zero;
+    case kIndBox01: return x <= zero ? Min(zero, v) : (x >= one ? Max(zero, v) : zero);
+    case kIndEq0: return v;
+    case kNegEntr: return -Log(x) - one;
+    case kExp: return Exp(x);
+    case kHuber: return Max(-one, Min(one, x));
+    case kIdentity: return one;
+    case kLogistic: {
+      const T ex = Exp(x);
+      return ex / (one + ex);
+    }
+    case kNegLog: return -one / x;
+    case kRecipr: return one / (x * x);
+    case kSquare: return x;
+    case kZero:
+    default: return zero;
+  }
+}
+// The same for c*h(a*x-b) + d*x + e*x^2/2 (chain rule, prox_lib.h:468-493); c, e are expected
+// clamped to >= 0 as FunctionObj's constructor does.
+template <typename T>
+__device__ inline T ProjSubgradEval(int h, T a, T b, T c, T d, T e, T v, T x) {
+  const T lin = d + e * x;
+  if (a == static_cast<T>(0) || c == static_cast<T>(0)) return lin;
+  const T ac = a * c;
+  const T inner = ProjSubgradBase(h, static_cast<T>(1) / ac * (v - lin), a * x - b);
+  return ac * inner + lin;
+}
+
 }  // namespace dev
 
 inline bool is_cheap_prox(int h) {

@@ -74,6 +74,10 @@ void launch_func_eval(int n, FnView<T> f, const T *v, double *partials, hipStrea
 template <typename T>
 void launch_prox_eval(int n, FnView<T> f, T rho, const T *in, T *out, hipStream_t s);
 
+// out[i] = ProjSubgradEval(f_i, v[i], x[i])   (prox_lib.h:468-493, 538-546)
+template <typename T>
+void launch_proj_subgrad(int n, FnView<T> f, const T *x, const T *v, T *out, hipStream_t s);
+
 // Un-scaling of the outputs (pogs.cpp:510-518).
 template <typename T>
 struct UnscaleArgs {

@@ -95,6 +95,12 @@ __global__ void __launch_bounds__(kVecTpb) prox_eval_kernel(int n, FnView<T> f, 
 }
 
 template <typename T>
+__global__ void __launch_bounds__(kVecTpb) proj_subgrad_kernel(int n, FnView<T> f, const T *x, const T *v, T *out) {
+  const int i = blockIdx.x * kVecTpb + threadIdx.x;
+  if (i < n) out[i] = dev::ProjSubgradEval(f.h[i], f.a[i], f.b[i], f.c[i], f.d[i], f.e[i], v[i], x[i]);
+}
+
+template <typename T>
 __global__ void __launch_bounds__(kVecTpb) unscale_kernel(UnscaleArgs<T> a, int blocks_x) {
   const bool is_x = static_cast<int>(blockIdx.x) < blocks_x;
   const int blk = is_x ? blockIdx.x : blockIdx.x - blocks_x;
@@ -247,6 +253,12 @@ void launch_prox_eval(int n, FnView<T> f, T rho, const T *in, T *out, hipStream_
 }
 
 template <typename T>
+void launch_proj_subgrad(int n, FnView<T> f, const T *x, const T *v, T *out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(proj_subgrad_kernel<T>, dim3(vec_blocks(n)), dim3(kVecTpb), 0, s, n, f, x, v, out);
+}
+
+template <typename T>
 void launch_unscale(const UnscaleArgs<T> &a, hipStream_t s) {
   const int bx = vec_blocks(a.n_x);
   hipLaunchKernelGGL(unscale_kernel<T>, dim3(bx + vec_blocks(a.n_y)), dim3(kVecTpb), 0, s, a, bx);
@@ -366,6 +378,7 @@ void launch_axpby(size_t n, T a, const T *x, T b, T *y, hipStream_t s) {
   template void launch_admm_tail<T>(int, const T *, const T *, const T *, T *, double *, hipStream_t);   \
   template void launch_func_eval<T>(int, FnView<T>, const T *, double *, hipStream_t);                   \
   template void launch_prox_eval<T>(int, FnView<T>, T, const T *, T *, hipStream_t);                     \
+  template void launch_proj_subgrad<T>(int, FnView<T>, const T *, const T *, T *, hipStream_t);          \
   template void launch_unscale<T>(const UnscaleArgs<T> &, hipStream_t);                                  \
   template void launch_exact_u<T>(int, const T *, const T *, const T *, T, T *, hipStream_t);            \
   template void launch_fill<T>(T *, T, size_t, hipStream_t);                                             \

@@ -469,6 +469,23 @@ def func_eval(f, v, dtype=None):
     return out.value
 
 
+def proj_subgrad_eval(f, x, v, dtype=None):
+    """Element-wise projection of v onto the subdifferential of f_i at x_i, on the GPU
+    (reference: ProjSubgradEval, src/include/prox_lib.h:468-493, 538-546)."""
+    dt = _resolve_dtype(dtype)
+    fa = _as_vector(f).arrays(dt)
+    x = np.ascontiguousarray(x, dt)
+    v = np.ascontiguousarray(v, dt)
+    assert x.shape == v.shape
+    out = np.zeros_like(v)
+    st = lib.PogsAmdProjSubgradEval(_lib.F64 if dt == np.float64 else _lib.F32, len(v), _ptr(fa["h"]), _ptr(fa["a"]),
+                                    _ptr(fa["b"]), _ptr(fa["c"]), _ptr(fa["d"]), _ptr(fa["e"]), _ptr(x), _ptr(v),
+                                    _ptr(out))
+    if st != 0:
+        raise RuntimeError("pogs_amd: " + _lib.last_error())
+    return out
+
+
 def rand_uniform(n, dtype=None):
     """The Norm2Est start vector (reference: src/cpu/include/gsl/gsl_rand.h:8-16)."""
     dt = _resolve_dtype(dtype)

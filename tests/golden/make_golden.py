@@ -235,5 +235,22 @@ def prox_table():
     print("prox_table.npz:", tab.shape)
 
 
+def projsub_table():
+    """ProjSubgradEval of the reference header on a grid, via projsub_driver.cpp."""
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "projsub_driver")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I/root/reference/src/include",
+                               os.path.join(HERE, "projsub_driver.cpp"), "-o", exe])
+        raw = subprocess.check_output([exe])
+    # rows of [is_float, h, a, b, c, d, e, x, v, result]
+    tab = np.frombuffer(raw, dtype=np.float64).reshape(-1, 10)
+    np.savez_compressed(os.path.join(HERE, "projsub_table.npz"), table=tab)
+    print("projsub_table.npz:", tab.shape)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "projsub":
+        projsub_table()   # only this fixture (the others are unchanged)
+    else:
+        main()
+        projsub_table()

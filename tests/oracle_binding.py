@@ -332,6 +332,19 @@ def oracle_func(objs, v, dtype=np.float64):
     return fn(ctypes.c_size_t(len(v)), _p(o["h"]), _p(o["a"]), _p(o["b"]), _p(o["c"]), _p(o["d"]), _p(o["e"]), _p(v))
 
 
+def oracle_proj_subgrad(objs, x, v, dtype=np.float64):
+    """ProjSubgradEval of the oracle (prox_lib.h:468-493): v projected onto the subdifferential at x."""
+    lib = oracle_lib()
+    o = _coef_arrays(objs, dtype)
+    x = np.ascontiguousarray(x, dtype=dtype)
+    v = np.ascontiguousarray(v, dtype=dtype)
+    out = np.zeros_like(v)
+    fn = lib.OracleProjSubgradEvalD if dtype == np.float64 else lib.OracleProjSubgradEvalS
+    fn(ctypes.c_size_t(len(v)), _p(o["h"]), _p(o["a"]), _p(o["b"]), _p(o["c"]), _p(o["d"]), _p(o["e"]), _p(x), _p(v),
+       _p(out))
+    return out
+
+
 def oracle_prox_raw(h, v, rho, dtype=np.float64):
     lib = oracle_lib()
     if dtype == np.float64:

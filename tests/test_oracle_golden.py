@@ -129,6 +129,21 @@ def test_prox_table_golden():
                 assert not np.isfinite(got) or np.isnan(row[10])
 
 
+def test_proj_subgrad_table_golden():
+    """ProjSubgradEval of the reference header (prox_lib.h:468-493) on a 16 x 4 x 11 x 7 grid that
+    sits on and around every kink, incl. the a = 0 / c = 0 shortcuts; both precisions."""
+    tab = np.load(os.path.join(GOLD, "projsub_table.npz"))["table"]
+    assert tab.shape == (2 * 16 * 4 * 11 * 7, 10)
+    for is_float, dtype in ((0.0, np.float64), (1.0, np.float32)):
+        r = tab[tab[:, 0] == is_float]
+        objs = {"h": r[:, 1].astype(np.int32), "a": r[:, 2], "b": r[:, 3], "c": r[:, 4], "d": r[:, 5], "e": r[:, 6]}
+        got = ob.oracle_proj_subgrad(objs, r[:, 7], r[:, 8], dtype=dtype).astype(np.float64)
+        want = r[:, 9]
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        assert np.array_equal(got[ok], want[ok])   # same arithmetic, same compiler: bitwise (infinities included)
+
+
 def test_prox_known_answers_of_reference_tests():
     """tests/test_proximal.cpp:12-220 (closed-form raw prox values)."""
     F = G.Function
