@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(kVecTpb) cg_update_xr_kernel(int n, int m, con
   } else {
     const int i = (blockIdx.x - blocks_x) * kVecTpb + threadIdx.x;
     if (i < m) r[i] += neg_alpha * q[i];
+    return;   // (uniform per workgroup) only the x blocks carry a partial sum: partials has blocks_x entries
   }
   dev::block_sum<1, kVecTpb>(acc, s_red);
   if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];

@@ -43,6 +43,19 @@ __device__ __forceinline__ double Acos(double a) { return acos(a); }
 __device__ __forceinline__ float Cos(float a) { return cosf(a); }
 __device__ __forceinline__ double Cos(double a) { return cos(a); }
 
+// a * b rounded on its own: the empty asm makes the product opaque, so the compiler cannot contract
+// it with a following add / subtract into one fused multiply-add (-ffp-contract=fast is the default)
+__device__ __forceinline__ float MulRn(float a, float b) {
+  float p = a * b;
+  asm volatile("" : "+v"(p));
+  return p;
+}
+__device__ __forceinline__ double MulRn(double a, double b) {
+  double p = a * b;
+  asm volatile("" : "+v"(p));
+  return p;
+}
+
 template <typename T> __device__ __forceinline__ T BisectTol();   // prox_tools.h:57-62
 template <> __device__ __forceinline__ float BisectTol<float>() { return 1e-5f; }
 template <> __device__ __forceinline__ double BisectTol<double>() { return 1e-10; }
@@ -289,7 +302,9 @@ __device__ inline T ProjSubgradEval(int h, T a, T b, T c, T d, T e, T v, T x) {
   const T lin = d + e * x;
   if (a == static_cast<T>(0) || c == static_cast<T>(0)) return lin;
   const T ac = a * c;
-  const T inner = ProjSubgradBase(h, static_cast<T>(1) / ac * (v - lin), a * x - b);
+  // a x - b decides on which side of a kink x lies: the product is rounded on its own, as the
+  // reference's host arithmetic does (no fused multiply-add), so points ON a kink stay on it
+  const T inner = ProjSubgradBase(h, static_cast<T>(1) / ac * (v - lin), MulRn(a, x) - b);
   return ac * inner + lin;
 }
 

@@ -130,6 +130,11 @@ void launch_max_partials(const double *partials, int n, double *out, hipStream_t
 
 void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s);
 
+// One sum job and, in the same launch, the CGLS scalar that needs it (cg_kernels.h: the three
+// one-thread kernels): mode 1 alpha = gamma / (S[kCgQ2] + shift S[kCgP2]) (cgls.h:262-271),
+// mode 2 beta = S[kCgS2] / gamma, gamma = S[kCgS2] (:288-292), mode 3 gamma = S[kCgS2] (:245).
+void launch_sum_cg(const SumJob &job, double *S, double *cg, int mode, double shift, double eps, hipStream_t s);
+
 // Misc vector helpers.
 template <typename T> void launch_fill(T *p, T v, size_t n, hipStream_t s);
 template <typename T> void launch_sqrt_inplace(T *p, size_t n, hipStream_t s);

@@ -323,6 +323,33 @@ void launch_max_partials(const double *partials, int n, double *out, hipStream_t
   hipLaunchKernelGGL(max_partials_kernel, dim3(1), dim3(256), 0, s, partials, n, out);
 }
 
+namespace {
+// (slot numbers of the CG block: cg_kernels.h CgSlot -- gamma 0, alpha 1, beta 2, delta 3, indefinite 4)
+__global__ void __launch_bounds__(256) sum_cg_kernel(SumJob job, double *S, double *cg, int mode, double shift, double eps) {
+  __shared__ double s_w[4];
+  run_sum_job(job, s_w);   // ends with a barrier: thread 0 sees its own store
+  if (threadIdx.x != 0) return;
+  if (mode == 1) {
+    double delta = S[kCgQ2] + shift * S[kCgP2];
+    if (delta <= 0.0) cg[4] = 1.0;
+    if (delta == 0.0) delta = eps;
+    cg[3] = delta;
+    cg[1] = cg[0] / delta;
+  } else if (mode == 2) {
+    const double g1 = cg[0], g = S[kCgS2];
+    cg[0] = g;
+    cg[2] = g / g1;
+  } else if (mode == 3) {
+    cg[0] = S[kCgS2];
+    cg[4] = 0.0;
+  }
+}
+}  // namespace
+
+void launch_sum_cg(const SumJob &job, double *S, double *cg, int mode, double shift, double eps, hipStream_t s) {
+  hipLaunchKernelGGL(sum_cg_kernel, dim3(1), dim3(256), 0, s, job, S, cg, mode, shift, eps);
+}
+
 void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s) {
   POGS_CHECK(njobs >= 1 && njobs <= kMaxSumJobs, "sum jobs");
   SumJobs j;

@@ -54,3 +54,21 @@ def csr_lasso(m, n, nnz_per_row=50, seed=0, dtype=np.float64, density=0.05, nois
     x_true = rng.standard_normal(n) * (rng.random(n) < density)
     b = A.astype(np.float64) @ x_true + noise * rng.standard_normal(m)
     return A, b, x_true
+
+
+def dense_lasso_rows(m, n, seed=0, density=0.1, noise=0.1, chunk=4000):
+    """The dense-lasso recipe generated in row chunks (fp32 A, no fp64 copy of the matrix): the
+    same bits on every machine for a given (m, n, seed, chunk).  Used for the full-size C2 problem
+    whose reference solution is a committed fixture (tests/golden/c2_reference.npz)."""
+    rng = np.random.default_rng(seed)
+    x_true = rng.standard_normal(n) * (rng.random(n) < density)
+    A = np.empty((m, n), np.float32)
+    b = np.empty(m, np.float64)
+    nz = np.flatnonzero(x_true)
+    for r0 in range(0, m, chunk):
+        r1 = min(m, r0 + chunk)
+        blk = rng.standard_normal((r1 - r0, n), dtype=np.float32)
+        A[r0:r1] = blk
+        # (element-wise product + numpy's own pairwise sum: no BLAS, so no dependence on its threads)
+        b[r0:r1] = (blk[:, nz].astype(np.float64) * x_true[nz]).sum(axis=1) + noise * rng.standard_normal(r1 - r0)
+    return A, b, x_true

@@ -1,22 +1,23 @@
 #!/bin/bash
-# Round profile of the bench command on the GPU box.  Writes into gpurun_out/prof_<tag>/:
-#   bench.json                plain run (no profiler)
+# Round profile of the bench command on the GPU box.  Writes into gpurun_out/prof_<tag>_<config>/:
+#   bench.json                plain run (no profiler), with the CPU baseline
 #   kernel_stats.csv          rocprofv3 --kernel-trace --stats summary of the same command
 #   pmc_traffic.json          FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes, corrected)
-# usage: profile_round.sh <tag>       (then copy the three files into profiles/)
-tag=${1:-r01}
+# usage: profile_round.sh <tag> [c2|c3|c4]       (then copy the three files into profiles/)
+tag=${1:-r02}
+cfg=${2:-c2}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/prof_$tag
+O=$R/gpurun_out/prof_${tag}_${cfg}
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cat $R/pogs_amd/libpogs_amd.so > /dev/null   # fresh box: page cache cold, the first process would pay the disk reads
 python -c 'import torch; torch.zeros(1, device="cuda")' > /dev/null 2>&1
-python $R/bench.py --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/kt.log 2>&1
+python $R/bench.py --config $cfg --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python $R/bench.py --config $cfg --steps 200 --warmup 20 --no-cpu-baseline > $O/kt.log 2>&1
 db=$(find $O/kt -name "*.db" | head -1)
 python $R/scripts/rocpd_summary.py $db $O/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o g -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o g -- python $R/bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline > $O/pmc_$c.log 2>&1
 done
 python $R/scripts/pmc_summary.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json
 rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE

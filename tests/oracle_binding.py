@@ -207,13 +207,32 @@ class RefRun:
             self.td.cleanup()
 
 
-REF_THREADS = 16   # BLAS threads of the reference subprocess: the fastest setting measured on the 2 x 64-core GPU
-                   # box (scripts/ref_threads_probe.py, 20000 x 10000 fp32: 16 -> 12.8 it/s, 32 -> 9.2, 64 -> 11.1,
-                   # 128 -> 7.2, 256 -> 8.8; at 100000 rows 256 threads need > 15 minutes)
+REF_THREADS = 16   # BLAS threads of the reference subprocess: the fastest setting measured on the GPU box
+                   # (scripts/ref_threads_probe.py, 20000 x 10000 fp32: 16 -> 12.8 it/s, 32 -> 9.2, 64 -> 11.1,
+                   # 128 -> 7.2, 256 -> 8.8) -- its container has a CPU quota of 16 cores (cgroup cpu.max) although
+                   # 256 hardware threads are visible
+
+
+def cpu_quota():
+    """CPUs this container may use: the cgroup quota if there is one, else the visible count."""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(round(int(q) / int(per)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / per))))
+        except Exception:
+            pass
+    return n
 
 
 def ref_threads():
-    return max(1, min(REF_THREADS, os.cpu_count() or 1))
+    return max(1, min(REF_THREADS, cpu_quota()))
 
 
 def ref_start(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0,

@@ -27,6 +27,36 @@ def _tol(dtype, f64, f32):
     return f64 if dtype == np.float64 else f32
 
 
+def _relerr_same_iteration(got, want, solve_engine, solve_oracle):
+    """||dx|| / ||x|| with both sides stopped at the SAME iteration.  Near convergence the fp32 dual
+    residual is a difference of O(1) terms, so its last bits -- and with them the iteration at which
+    it crosses its threshold -- depend on summation orders; an ill-conditioned problem still moves
+    by 1e-3 per iteration there.  When the two stop k iterations apart the later one is re-run with
+    max_iter cut to the earlier one's count: the trajectories are then compared, not the noise of
+    the stopping decision.  solve_*(max_iter) -> result dict."""
+    gi, wi = int(got["iterations"]), int(want["iterations"])
+    if gi == wi:
+        return relerr(got["x"], want["x"])
+    k = min(gi, wi) + 1
+    g2 = got if gi < wi else solve_engine(k)
+    w2 = want if wi < gi else solve_oracle(k)
+    assert int(g2["iterations"]) == int(w2["iterations"]) == k - 1
+    return relerr(g2["x"], w2["x"])
+
+
+def _xtol32(got_iters, want_iters, loose=3e-4):
+    """fp32 bound on ||dx|| / ||x|| against the oracle.  When both stop at the same iteration they
+    walked the same trajectory and differ by rounding only -- measured 2e-7 .. 1.2e-6 on every
+    problem family (scripts/parity_report.py; the compiled reference differs from ITSELF by the
+    same amount between fp32 and fp64 or between BLAS thread counts, scripts/fp32_spread.py) --
+    so the bound is 2e-5.  When they stop a few iterations apart (a rounding-sized difference in a
+    residual next to its threshold) the iterates differ by what ADMM still moves per iteration at
+    that point, which the stopping rule itself puts at ~1e-4: the north-star tolerance, with the
+    number of iterations apart as the factor, capped at `loose`."""
+    d = abs(int(got_iters) - int(want_iters))
+    return 2e-5 if d == 0 else min(loose, 1e-4 * (1 + d))
+
+
 # --------------------------------------------------------------------------- prox
 ALL_FUNCS = list(range(16))
 
@@ -480,6 +510,8 @@ def test_dense_cgls_projector_option(dtype, shape):
         # ABI, SURVEY.md finding 5): judge the solution against the direct projector's optimum
         want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype, use_cgls=False)
         assert want["status"] == 0
+    # fp32: the inexact CGLS projection (tolerance 1e-2 sqrt(r), pogs.cpp:287-290) makes the iterates
+    # themselves tolerance-sized apart: measured 1.3e-4 against the direct projector's optimum
     assert relerr(got["x"], want["x"]) < _tol(dtype, 1e-5, 3e-4)
     if dtype == np.float64:
         assert got["optval"] == pytest.approx(want["optval"], rel=1e-6)
@@ -567,7 +599,7 @@ def test_512_thread_plan_one_pass_iteration(dtype, shape, monkeypatch):
     assert st["spec_hits"] > 0.8 * got["iterations"] and st_ref["spec_hits"] == 0   # one-pass vs two-pass
     assert st["matvecs"] < 0.7 * st_ref["matvecs"]
     assert abs(int(got["iterations"]) - int(ref["iterations"])) <= (1 if dtype == np.float64 else max(3, ref["iterations"] // 10))
-    assert relerr(got["x"], ref["x"]) < _tol(dtype, 1e-7, 5e-4)
+    assert relerr(got["x"], ref["x"]) < _tol(dtype, 1e-7, _xtol32(got["iterations"], ref["iterations"], loose=5e-4))
     assert got["optval"] == pytest.approx(ref["optval"], rel=_tol(dtype, 1e-8, 2e-4))
 
 
@@ -638,7 +670,7 @@ def test_row_sharded_engine_matches_single_rank(dtype, world):
     with pogs.Solver(A, dtype=dtype) as s:
         one = s.solve(f, g)
     res, bounds = run_row_sharded(pogs, A, f, g, world, dtype)
-    tol = 1e-9 if dtype == np.float64 else 2e-4
+    tol = 1e-9 if dtype == np.float64 else _xtol32(res[0]["iterations"], one["iterations"], loose=2e-4)
     for r, out in enumerate(res):
         assert out["status"] == one["status"] == 0
         if dtype == np.float64:
@@ -730,6 +762,10 @@ def test_wide_matrix_with_many_columns(dtype, shape):
     want_r = ob.oracle_solve(A, soa(fr), soa(gr), dtype=dtype)
     assert ridge["status"] == want_r["status"] == 0
     assert abs(int(ridge["iterations"]) - int(want_r["iterations"])) <= (1 if dtype == np.float64 else 10)
+    # fp32 with rows of 4e4 .. 5e4 elements: the ORACLE's plain-loop dot products are the noisy side
+    # here -- measured with the compiled reference on these very problems (300 x 50000: oracle32 vs
+    # reference32 1.09e-4, reference32 vs reference64 8.7e-6, and the engine sits 1.09e-4 from the
+    # oracle, i.e. next to the reference; 33 x 40001: reference32 vs reference64 1.2e-4) -- so 3e-4
     assert relerr(ridge["x"], want_r["x"]) < _tol(dtype, 1e-6, 3e-4)
     assert got["status"] == want["status"] == 0
     assert abs(int(got["iterations"]) - int(want["iterations"])) <= (1 if dtype == np.float64 else max(3, want["iterations"] // 10))
@@ -809,7 +845,11 @@ def test_degenerate_inputs_fp32_with_equilibration_shortcut():
         assert abs(int(got["iterations"]) - int(want["iterations"])) <= max(1, int(want["iterations"]) // 50), tag
         assert np.array_equal(np.isfinite(got["x"]), np.isfinite(want["x"])), tag
         if tol is not None:
-            assert relerr(got["x"], want["x"]) < tol, tag
+            err = _relerr_same_iteration(
+                got, want,
+                lambda k: pogs.graph._solve_graph_form(M, f, g, 1e-4, 1e-4, k, 0, 1.0, dtype=np.float32),
+                lambda k: ob.oracle_solve(M, soa(f), soa(g), dtype=np.float32, max_iter=k))
+            assert err < tol, tag
 
 
 @pytest.mark.gpu
@@ -872,8 +912,11 @@ def test_windowed_passes_on_small_matrices(dtype, shape, cgls, monkeypatch):
     assert got["status"] == 0
     slack = 2 if dtype == np.float64 else max(3, want["iterations"] // 10)
     assert abs(int(got["iterations"]) - int(want["iterations"])) <= slack
-    # (fp32: the window partial sums round differently, the solve may stop an iteration apart)
-    assert relerr(got["x"], want["x"]) < _tol(dtype, 1e-6, 2e-3)
+    # (fp32: the window partial sums round differently, the solve may stop an iteration apart;
+    # measured with equal counts: 1.2e-6, scripts/parity_report.py)
+    # the dense CGLS option is inexact by construction (projection tolerance 1e-2 sqrt(r)): 1e-3
+    xt = 1e-3 if cgls else _xtol32(got["iterations"], want["iterations"], loose=1e-3)
+    assert relerr(got["x"], want["x"]) < _tol(dtype, 1e-6, xt)
     assert got["optval"] == pytest.approx(want["optval"], rel=_tol(dtype, 1e-7, 5e-3))
 
 
@@ -907,4 +950,4 @@ def test_fp16_split_gram_is_as_exact_as_the_fp32_product(shape, monkeypatch):
     rb, rf = out["f16"][1], out["fp32"][1]
     assert rb["status"] == rf["status"] == 0
     assert abs(int(rb["iterations"]) - int(rf["iterations"])) <= max(3, rf["iterations"] // 10)
-    assert relerr(rb["x"], rf["x"]) < 5e-4
+    assert relerr(rb["x"], rf["x"]) < _xtol32(rb["iterations"], rf["iterations"], loose=5e-4)

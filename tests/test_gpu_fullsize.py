@@ -318,30 +318,71 @@ def _assert_matches_reference(r, ref, what):
 
 
 def test_c2_solution_matches_compiled_reference():
-    """configs[1] at FULL size against the reference itself: the compiled reference
-    (oracle/_ref/libpogs_cpu.so = src/interface_c/pogs_c.cpp:9-55 -> src/cpu/pogs.cpp:91) solves the
-    same 100000 x 10000 fp32 (A, b, lambda) on the host cores (clean subprocess, ~2 minutes with
-    16 BLAS threads) while the engine solves it with the shipped defaults (Sinkhorn-Knopp early
-    exit, fp16-split Gram) and with POGS_AMD_SK_FULL=1 POGS_AMD_GRAM=fp32."""
-    import oracle_binding as ob
+    """configs[1] at FULL size against the reference itself.  The compiled reference
+    (oracle/_ref/libpogs_cpu.so = src/interface_c/pogs_c.cpp:9-55 -> src/cpu/pogs.cpp:91) solved
+    the 100000 x 10000 fp32 problem of pogs_amd.synth.dense_lasso_rows(seed=2024) in the build
+    container (tests/golden/make_c2_reference.py: 154 iterations, 143 s on 8 cores; the GPU box's
+    host needs more than 15 minutes for that call, so the solution is a committed fixture); the
+    matrix is regenerated here bit for bit (checksums in the fixture) and solved by the engine with
+    the shipped defaults (Sinkhorn-Knopp early exit, fp16-split Gram) and with POGS_AMD_SK_FULL=1
+    POGS_AMD_GRAM=fp32.  POGS_AMD_LIVE_REF=1 additionally runs the reference live on this box."""
+    import os
 
-    if not ob.ref_available():
-        pytest.skip("compiled reference not present (oracle/_ref is built in the build container)")
+    from pogs_amd import synth
+
     torch = _torch()
     pogs = _pogs()
-    A, f, gg = _c2_problem(torch, pogs)
-    soa = lambda fv: {k: getattr(fv, k) for k in "habcde"}  # noqa: E731
-    run = ob.ref_start(A.cpu().numpy(), soa(f), soa(gg), dtype=np.float32, verbose=1)
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "c2_reference.npz"))
+    m, n = (int(v) for v in fx["shape"])
+    A_host, b, _ = synth.dense_lasso_rows(m, n, seed=int(fx["seed"]))
+    chk = np.array([float(A_host[::997].astype(np.float64).sum()), float(np.abs(A_host[:, ::113]).astype(np.float64).sum()),
+                    float(np.linalg.norm(b)), float(b[::101].sum())])
+    np.testing.assert_allclose(chk, fx["checksums"], rtol=1e-12, err_msg="the generator no longer reproduces the fixture's inputs")
+    f, gg = pogs.graph.lasso_functions(b, float(fx["lam"]), n)
+    A = torch.from_numpy(A_host).to("cuda:0")
+    ref = {"x": fx["x"], "optval": float(fx["optval"]), "iterations": int(fx["iterations"]), "status": int(fx["status"])}
+
+    def check(r, what):
+        xr = ref["x"].astype(np.float64)
+        assert r["status"] == ref["status"] == 0, what
+        rel_x = np.linalg.norm(r["x"].astype(np.float64) - xr) / np.linalg.norm(xr)
+        assert rel_x <= 1e-4, (what, rel_x)                                   # north_star: 1e-4 rel-tol
+        it, itr = r["iterations"] + 1, ref["iterations"] + 1
+        assert abs(it - itr) <= max(3, itr // 10), (what, it, itr)           # SURVEY.md 8(c): +-10 %
+        # the objective AT x, recomputed in fp64, within 1e-4 of the reference's.  (optval itself is taken
+        # at the prox point, y12 != A x12: |y12 - b| ~ 30 while y12 is only fixed to rel_tol |y| ~ 1, so two
+        # runs that stop a few iterations apart differ by percents in it -- the reference's own optval,
+        # 510.45, is 3 % from its objective at x, 527.56 -- and it is compared only on equal counts)
+        x64 = r["x"].astype(np.float64)
+        y64 = np.concatenate([A_host[r0:r0 + 10000].astype(np.float64) @ x64 for r0 in range(0, m, 10000)])
+        obj = 0.5 * float(np.sum((y64 - b) ** 2)) + float(fx["lam"]) * float(np.abs(x64).sum())
+        assert abs(obj - float(fx["objective_at_x"])) <= 1e-4 * float(fx["objective_at_x"]), (what, obj)
+        if it == itr:
+            assert abs(r["optval"] - ref["optval"]) <= 1e-4 * abs(ref["optval"]), (what, r["optval"], ref["optval"])
+        else:
+            assert abs(r["optval"] - ref["optval"]) <= 0.1 * abs(ref["optval"]), (what, r["optval"], ref["optval"])
+        yh = fx["y_head"].astype(np.float64)
+        assert np.linalg.norm(r["y"][:len(yh)].astype(np.float64) - yh) <= 2e-4 * np.linalg.norm(yh), what
+        assert np.linalg.norm(r["y"].astype(np.float64)) == pytest.approx(float(fx["y_norm"]), rel=1e-4)
+        lh = fx["l_head"].astype(np.float64)
+        assert np.linalg.norm(r["l"][:len(lh)].astype(np.float64) - lh) <= 2e-3 * np.linalg.norm(lh), what
+        return rel_x
+
     default = _engine_solve(pogs, A, f, gg, {})
     full = _engine_solve(pogs, A, f, gg, {"POGS_AMD_SK_FULL": "1", "POGS_AMD_GRAM": "fp32"})
-    del A
-    ref = run.finish(timeout=900)
-    _assert_matches_reference(default, ref, "defaults")
-    _assert_matches_reference(full, ref, "SK_FULL + GRAM=fp32")
+    check(default, "defaults")
+    check(full, "SK_FULL + GRAM=fp32")
     # the two engine configurations agree far below the tolerance: the default-on deviations
     # (closed-form Sinkhorn-Knopp tail, fp16-split Gram) do not move the solution
     xd, xf = default["x"].astype(np.float64), full["x"].astype(np.float64)
     assert np.linalg.norm(xd - xf) <= 2e-5 * np.linalg.norm(xf)
+    if os.environ.get("POGS_AMD_LIVE_REF") == "1":
+        import oracle_binding as ob
+
+        soa = lambda fv: {k: getattr(fv, k) for k in "habcde"}  # noqa: E731
+        live = ob.ref_solve(A_host, soa(f), soa(gg), dtype=np.float32, verbose=1, timeout=3000)
+        assert live["iterations"] == ref["iterations"]
+        _assert_matches_reference(default, live, "defaults vs live reference")
 
 
 def test_c3_solution_matches_compiled_reference():

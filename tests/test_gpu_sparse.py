@@ -127,8 +127,9 @@ def test_sparse_lasso_fp32_scaled_c4():
     got = pogs.solve_lasso(A, b, 0.1, dtype=np.float32)
     f, g = pogs.graph.lasso_functions(b, 0.1, 5000)
     want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float32)
-    _check(got, want, 2e-4, max(5, int(0.1 * want["iterations"])))
-    assert relerr(got["x"], GOLD["csr20000_f32_x"]) < 3e-4
+    # measured (scripts/parity_report.py): 128 iterations like the oracle, ||dx|| / ||x|| = 2.0e-7
+    _check(got, want, 2e-5, max(5, int(0.1 * want["iterations"])))
+    assert relerr(got["x"], GOLD["csr20000_f32_x"]) < 2e-5
 
 
 @pytest.mark.parametrize("problem", ["ridge", "logistic", "svm", "nonneg_ls"])
@@ -288,7 +289,10 @@ def test_row_sharded_sparse_engine_matches_single_rank(dtype, world):
     with pogs.Solver(A, dtype=dtype) as s:
         one = s.solve(f, g)
     res, bounds = run_row_sharded(pogs, A.tocsr(), f, g, world, dtype)
-    tol = 1e-7 if dtype == np.float64 else 5e-4
+    # fp32: 2e-5 on the same trajectory, tolerance-sized when the inexact CGLS projections (whose
+    # A^T products are summed in another order across shards) stop the solves a few iterations apart
+    d_it = abs(int(res[0]["iterations"]) - int(one["iterations"]))
+    tol = 1e-7 if dtype == np.float64 else (2e-5 if d_it == 0 else min(5e-4, 1e-4 * (1 + d_it)))
     for r, out in enumerate(res):
         assert out["status"] == one["status"] == 0
         assert abs(int(out["iterations"]) - int(one["iterations"])) <= (1 if dtype == np.float64 else 5)
