@@ -999,6 +999,10 @@ int AdmmSolve(Operator<T> *A, Projector<T> *P, std::vector<FunctionObj<T>> f,
     converged = exact && nrm_r < eps_pri && nrm_s < eps_dua &&
                 (!arg.gap_stop || gap < eps_gap);                               // :379-380
 
+    static const bool trace = std::getenv("POGS_ORACLE_ITERTRACE") != nullptr;   // debugging aid
+    if (trace)
+      std::printf("T %5u rho %.9e r %.9e s %.9e gap %.9e epri %.9e edua %.9e\n", k, (double)rho, (double)nrm_r,
+                  (double)nrm_s, (double)gap, (double)eps_pri, (double)eps_dua);
     if (arg.verbose > 1 && (k % 100 == 0 || converged || (arg.verbose > 2 && k % 10 == 0)))
       std::printf("%5u : %.2e  %.2e  %.2e  %.2e  %.2e  %.2e\n", k, (double)nrm_r,
                   (double)eps_pri, (double)nrm_s, (double)eps_dua, (double)gap, (double)eps_gap);

@@ -1552,6 +1552,10 @@ class DenseSolver final : public SolverBase {
   // the reference's per-iteration line (pogs.cpp:382-388); every rank evaluates (the objective
   // sum is a collective on row shards), rank 0 prints
   void log_iteration(unsigned verbose) {
+    static const bool trace = std::getenv("POGS_AMD_ITERTRACE") != nullptr;   // debugging aid: every iteration, full precision
+    if (trace)
+      std::printf("T %5u rho %.9e r %.9e s %.9e gap %.9e epri %.9e edua %.9e\n", ctl_.k, (double)ctl_.rho, (double)ctl_.nrm_r,
+                  (double)ctl_.nrm_s, (double)ctl_.gap, (double)ctl_.eps_pri, (double)ctl_.eps_dua);
     if (!wants_iter_line(verbose, ctl_)) return;
     const double obj = eval_objective();
     if (ctx_.dist.rank() == 0) print_iter_line(ctl_, obj);

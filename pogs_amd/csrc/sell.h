@@ -90,6 +90,18 @@ __device__ __forceinline__ void sell_load(const E *p, E (&out)[N]) {   // N * si
   __builtin_memcpy(out, raw, BYTES);
 }
 
+// Read of the tile table at a wavefront-uniform index as a SCALAR load (s_load_dword through the
+// constant address space; the table is written by the build kernels of an earlier launch only).
+// As an ordinary global load it is a vector-memory instruction whose `s_waitcnt vmcnt(0)` also
+// waits for every batch load in flight -- it drained the ring at each tile boundary.
+__device__ __forceinline__ int sell_uniform_load(const int *p) {
+  typedef const int __attribute__((address_space(4))) *cptr;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return *(cptr)(p);
+#pragma clang diagnostic pop
+}
+
 // DIRECT (ncg == 1): the row functor runs here; otherwise part[cg * nrows + row] receives the
 // column group's partial sums.
 template <typename T, bool SQ, bool DIRECT, typename Op>
@@ -119,6 +131,7 @@ __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, cons
   const unsigned short *__restrict__ a_loc = A.loc;
   const unsigned short *__restrict__ a_rid = A.rid;
   const int *__restrict__ a_tu = A.tile_unit + static_cast<size_t>(rr) * A.ncb;   // this row range's tiles
+  auto tu = [&](int cb) { return sell_uniform_load(a_tu + cb); };
 
   auto fetch = [&](size_t e0, SellBatch<T> &B) {   // e0: first element of this lane's batch
     sell_load<T, UB>(a_val + e0, B.v);
@@ -130,15 +143,27 @@ __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, cons
     T xg[UB];
 #pragma unroll
     for (int j = 0; j < UB; ++j) xg[j] = s_x[B.c[j]];
+    // running sums in registers first; the row ends of the batch are then flushed with INDEPENDENT
+    // LDS accesses (all reads, then all writes).  A row belongs to one lane and ends once, so the
+    // (up to UB) sums a lane flushes here are distinct and nobody else touches them -- written as
+    // `s_y[r] += acc` inside the element loop the compiler must assume aliasing and the batch
+    // becomes UB dependent LDS round trips.
+    T fl[UB], old[UB];
+    bool en[UB];
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
       const T v = B.v[j];
       acc += (SQ ? v * v : v) * xg[j];
-      if (B.r[j] != kSellNoRow) {
-        s_y[B.r[j]] += acc;
-        acc = 0;
-      }
+      en[j] = B.r[j] != kSellNoRow;
+      fl[j] = acc;
+      acc = en[j] ? static_cast<T>(0) : acc;
     }
+#pragma unroll
+    for (int j = 0; j < UB; ++j)
+      if (en[j]) old[j] = s_y[B.r[j]];
+#pragma unroll
+    for (int j = 0; j < UB; ++j)
+      if (en[j]) s_y[B.r[j]] = old[j] + fl[j];
   };
 
   // column blocks of this group: an even split of the ncb blocks
@@ -151,13 +176,22 @@ __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, cons
   V xreg[XV];
   int x_cb = cb0 - 1, x_w = 0, x_c0 = 0;   // block whose slice is in xreg, its width and first column
   auto x_prefetch = [&]() {   // advance x_cb to the next non-empty tile and request its slice
-    do { ++x_cb; } while (x_cb < cb1 && a_tu[x_cb] == a_tu[x_cb + 1]);
+    do { ++x_cb; } while (x_cb < cb1 && tu(x_cb) == tu(x_cb + 1));
     if (x_cb >= cb1) return;
     const int c0 = x_cb * BW, w = min(BW, A.ncols - c0);
+    if (w >= VEC) {
+      // unconditional loads (a vector past the end re-reads the last whole one and is zeroed): no
+      // branch per vector, and the number of loads in flight stays a compile-time constant
+      const int c_last = w - VEC;
 #pragma unroll
-    for (int i = 0; i < XV; ++i) {
-      const int c = (i * kSellTpb + t) * VEC;
-      xreg[i] = (c + VEC <= w) ? *reinterpret_cast<const V *>(x + c0 + c) : dev_vzero<V>();
+      for (int i = 0; i < XV; ++i) {
+        const int c = (i * kSellTpb + t) * VEC;
+        const V v = *reinterpret_cast<const V *>(x + c0 + min(c, c_last));
+        xreg[i] = (c <= c_last) ? v : dev_vzero<V>();
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XV; ++i) xreg[i] = dev_vzero<V>();
     }
     x_w = w;
     x_c0 = c0;
@@ -184,15 +218,15 @@ __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, cons
   // last batch is requested again), so the number in flight is a compile-time constant and the
   // compiler waits with a counted vmcnt instead of draining the queue at every step.
   int tb = 0;   // batches of this wavefront over the whole group
-  for (int cb = cb0; cb < cb1; ++cb) tb += (a_tu[cb + 1] - a_tu[cb]) / (kSellWaves * UB);
+  for (int cb = cb0; cb < cb1; ++cb) tb += (tu(cb + 1) - tu(cb)) / (kSellWaves * UB);
   int f_cb = cb0 - 1, f_b = 0, f_nb = 0;
   size_t f_e0 = 0;
   auto f_next = [&](size_t &e0, bool &first) {
     if (f_b >= f_nb) {   // to the next non-empty tile, if there is one
       int nx = f_cb + 1;
-      while (nx < cb1 && a_tu[nx] == a_tu[nx + 1]) ++nx;
+      while (nx < cb1 && tu(nx) == tu(nx + 1)) ++nx;
       if (nx < cb1) {
-        const int u0 = a_tu[nx], u1 = a_tu[nx + 1];
+        const int u0 = tu(nx), u1 = tu(nx + 1);
         const int K = (u1 - u0) / kSellWaves;   // wave-rows per wavefront in this tile
         f_cb = nx;
         f_nb = K / UB;

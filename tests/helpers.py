@@ -65,7 +65,7 @@ def _fsum(fv, v):
     return float(np.sum(c * out + d * v + 0.5 * e * v * v))
 
 
-def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, **solve_kw):
+def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, count_collectives=False, **solve_kw):
     """Solves with `world` ranks inside this process: one thread + one Solver per rank, rows split
     evenly, joined by the engine's in-process test communicator ("POGSLOCAL:" unique id, see
     pogs_amd/csrc/dist.h).  Verifies the engine's own row-sharded decomposition on ONE GPU.
@@ -86,6 +86,15 @@ def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, **solve_kw):
             lo, hi = int(bounds[r]), int(bounds[r + 1])
             with pogs.Solver(A[lo:hi], dtype=dtype, dist=(r, world, m, uid), **(solver_kw or {})) as s:
                 results[r] = s.solve(f.slice(lo, hi), g, **solve_kw)
+                if count_collectives:
+                    # a second solve on the same handle (factorisation cached): its all-reduce calls
+                    # are the iteration loop's alone
+                    st0 = s.stats()
+                    again = s.solve(f.slice(lo, hi), g, **solve_kw)
+                    st1 = s.stats()
+                    results[r]["loop_collectives"] = dict(
+                        calls=st1["collectives"] - st0["collectives"], iterations=int(again["iterations"]) + 1,
+                        misses=int(st1["spec_misses"] - st0["spec_misses"]), hits=int(st1["spec_hits"] - st0["spec_hits"]))
         except Exception as e:  # pragma: no cover - surfaced below
             errors.append((r, e))
 

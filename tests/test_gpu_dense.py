@@ -669,8 +669,13 @@ def test_row_sharded_engine_matches_single_rank(dtype, world):
     f, g = pogs.graph.lasso_functions(b, 0.1, n)
     with pogs.Solver(A, dtype=dtype) as s:
         one = s.solve(f, g)
-    res, bounds = run_row_sharded(pogs, A, f, g, world, dtype)
+    res, bounds = run_row_sharded(pogs, A, f, g, world, dtype, count_collectives=True)
     tol = 1e-9 if dtype == np.float64 else _xtol32(res[0]["iterations"], one["iterations"], loose=2e-4)
+    # ONE all-reduce per iteration (a second one only when the speculation
+    # missed and the iteration needed its own pass), + the objective's at the end
+    lc = res[0]["loop_collectives"]
+    assert lc["hits"] > lc["misses"]
+    assert lc["calls"] <= lc["iterations"] + lc["misses"] + 2, lc
     for r, out in enumerate(res):
         assert out["status"] == one["status"] == 0
         if dtype == np.float64:
@@ -832,8 +837,9 @@ def test_degenerate_inputs_fp32_with_equilibration_shortcut():
         ("zero row and column, wide", Wz, 2500, 1e-4),
         ("rank one", np.outer(rng.standard_normal(800), rng.standard_normal(250)), 2500, 1e-2),
         ("duplicate columns", np.hstack([A, A]), 2500, 1e-4),
+        # (tolerance: see the note below the loop)
         ("sixteen decades of row / column scales",
-         A * np.exp(rng.uniform(-8, 8, (600, 1))) * np.exp(rng.uniform(-8, 8, (1, 300))), 2500, 1e-3),
+         A * np.exp(rng.uniform(-8, 8, (600, 1))) * np.exp(rng.uniform(-8, 8, (1, 300))), 2500, 2e-2),
     ]
     for tag, M, max_iter, tol in cases:
         m, n = M.shape
@@ -850,6 +856,21 @@ def test_degenerate_inputs_fp32_with_equilibration_shortcut():
                 lambda k: pogs.graph._solve_graph_form(M, f, g, 1e-4, 1e-4, k, 0, 1.0, dtype=np.float32),
                 lambda k: ob.oracle_solve(M, soa(f), soa(g), dtype=np.float32, max_iter=k))
             assert err < tol, tag
+            # both stop on the same criteria, so the objective at x (fp64, y = A x) agrees far below
+            # rel_tol whatever path the rho schedule took
+            obj = lambda x: 0.5 * float(np.sum((M @ x.astype(np.float64) - b) ** 2)) + 0.1 * float(np.abs(x).sum())  # noqa: E731
+            otol = 1e-2 if tag.startswith("sixteen") else 1e-4      # (measured there: 2.7e-3, the engine's the lower one)
+            assert abs(obj(got["x"]) - obj(want["x"])) <= otol * abs(obj(want["x"])), tag
+    # The sixteen-decade case runs ~770 iterations with the fp32 dual residual bound (a norm of
+    # DIFFERENCES of successive iterates, known to 1e-4 .. 2e-3 relative in fp32: measured per iteration
+    # for this engine's two iteration paths against the oracle, scripts/dbg_iter_trace.py) sitting
+    # within 0.3 % of the adaptive-rho threshold xi * eps_dua around iteration 630.  Whether that one
+    # comparison fires is decided by rounding: the one-pass iteration takes the rho update there, the
+    # three-pass one (POGS_AMD_FUSED=0), the oracle and the reference do not; until then all four agree
+    # to 5e-5 in x, afterwards the rho schedules differ, the run ends 4 iterations earlier and x -- on a
+    # problem this ill-conditioned -- lands 8e-3 away, its objective 2.7e-3 BELOW the oracle's (both
+    # satisfy the same stopping rule).  Hence 2e-2 on x and 1e-2 on the objective for this case;
+    # every other case keeps its 1e-4 / 1e-3 bound on x and 1e-4 on the objective.
 
 
 @pytest.mark.gpu
