@@ -25,8 +25,10 @@ from .graph import (  # noqa: F401
     solve_svm,
 )
 
+from .cvxpy import pogs_solve  # noqa: E402,F401  (reference: python/pogs/__init__.py:29)
+
 __version__ = "0.1.0"
 __all__ = [
     "solve_lasso", "solve_ridge", "solve_elastic_net", "solve_logistic", "solve_svm", "solve_huber",
-    "solve_nonneg_ls", "Function", "FunctionObj", "FunctionVector", "Ordering", "Solver",
+    "solve_nonneg_ls", "pogs_solve", "Function", "FunctionObj", "FunctionVector", "Ordering", "Solver",
 ]

@@ -88,3 +88,38 @@ def test_one_dense_solver_factory_per_streaming_shape_and_type():
         for tpb, nv in shapes:
             assert "make_dense_solver_%s_p%s_%s(" % (t, tpb, nv) in syms, (t, tpb, nv)
         assert "make_dense_solver_%s_xl(" % t in syms, t
+
+
+C_DRIVER = os.path.join(ROOT, "tests", "c_caller", "graph_form_driver.c")
+
+
+def build_c_driver(out_dir):
+    """gcc -std=c99 build of tests/c_caller/graph_form_driver.c against libpogs_amd.so -> path."""
+    import subprocess
+
+    exe = os.path.join(str(out_dir), "graph_form_driver")
+    lib_dir = os.path.join(ROOT, "pogs_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O2", "-I", os.path.join(ROOT, "include"),
+                        C_DRIVER, "-o", exe, "-L", lib_dir, "-lpogs_amd", "-Wl,-rpath," + lib_dir],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_caller_links(tmp_path):
+    """The boundary is a C ABI: include/pogs_amd.h compiles as strict C99 and as C++, and a C program
+    calling PogsD / PogsS / PogsSparseD the way examples/c/lasso.c:102-106 does links against
+    libpogs_amd.so with nothing but -lpogs_amd (no HIP, no C++ runtime on the caller's side).
+    (tests/test_gpu_boundary.py runs it.)"""
+    import subprocess
+
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c"],
+                ["g++", "-std=c++11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++"]):
+        r = subprocess.run(cmd + ["-I", inc, "-"], input='#include "pogs_amd.h"\nint main(void) { return (int)sizeof(PogsAmdStats) == 0; }\n',
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    exe = build_c_driver(tmp_path)
+    r = subprocess.run(["ldd", exe], capture_output=True, text=True)
+    assert "libpogs_amd.so" in r.stdout
+    assert subprocess.run([exe], capture_output=True).returncode == 2      # usage error, before any GPU call

@@ -176,3 +176,72 @@ def test_handle_keeps_its_device_and_leaves_the_callers_device_alone():
     assert got["r"]["status"] == 0 and np.array_equal(got["r"]["x"], want["x"])
     s.close()
     assert torch.cuda.current_device() == before
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dense64", "dense32", "colmajor64", "csr64"])
+def test_plain_c_caller_gets_the_python_bindings_answer(tmp_path, kind):
+    """tests/c_caller/graph_form_driver.c (gcc, C99, linked with -lpogs_amd only) calls PogsD /
+    PogsS / PogsSparseD like examples/c/lasso.c:102-106 on inputs written by this test; what it
+    prints must be what the python binding returns for the same arrays (same library, same
+    entry points: bit-identical) and within the usual tolerance of the oracle."""
+    import subprocess
+
+    import oracle_binding as ob
+    import scipy.sparse as sp
+    from test_abi import build_c_driver
+
+    pogs = _pogs()
+    m, n, lam = 600, 90, 0.3
+    rng = np.random.default_rng(77)
+    A = rng.standard_normal((m, n))
+    if kind == "csr64":
+        A *= rng.random((m, n)) < 0.25
+    b = rng.standard_normal(m)
+    data = tmp_path / "in.bin"
+    with open(data, "wb") as fh:
+        fh.write(np.ascontiguousarray(A, np.float64).tobytes())
+        fh.write(np.ascontiguousarray(b, np.float64).tobytes())
+    exe = build_c_driver(tmp_path)
+    r = subprocess.run([exe, kind, str(m), str(n), repr(lam), str(data)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-2000:]
+    out = {ln.split()[0]: np.array(ln.split()[1:], dtype=np.float64) for ln in r.stdout.splitlines() if ln.strip()}
+    assert int(out["status"][0]) == 0
+    dtype = np.float32 if kind == "dense32" else np.float64
+    Ain = sp.csr_matrix(A) if kind == "csr64" else (np.asfortranarray(A) if kind == "colmajor64" else A)
+    want = pogs.solve_lasso(Ain, b, lam, dtype=dtype)
+    assert int(out["final_iter"][0]) == want["iterations"]
+    assert np.array_equal(out["x"].astype(dtype), want["x"])
+    assert np.array_equal(out["y"].astype(dtype), want["y"])
+    assert np.array_equal(out["l"].astype(dtype), want["l"])
+    assert dtype(out["optval"][0]) == dtype(want["optval"])
+    f, g = pogs.graph.lasso_functions(b, lam, n)
+    soa = lambda fv: {k: getattr(fv, k) for k in "habcde"}  # noqa: E731
+    orc = ob.oracle_solve(Ain if kind == "csr64" else A, soa(f), soa(g), dtype=dtype)
+    assert orc["iterations"] == want["iterations"]
+    assert np.linalg.norm(out["x"] - orc["x"]) <= (2e-5 if dtype == np.float32 else 1e-9) * np.linalg.norm(orc["x"])
+
+
+@pytest.mark.gpu
+def test_cvxpy_front_end_runs_the_engine():
+    """pogs_amd.pogs_solve (reference: python/pogs/cvxpy.py:33-92) on stand-in CVXPY problems: the
+    detected lasso / ridge / non-negative least squares are solved by the HIP engine, the variable
+    receives x, and the returned value is the CVXPY objective (optimum scaled back by 2 s)."""
+    import cvxpy_standins as S
+
+    pogs = _pogs()
+    cases = S.cases()
+    A = cases["lasso"].objective.expr.args[0].args[0].args[0].args[0].value
+    b = -cases["lasso"].objective.expr.args[0].args[0].args[1].value
+    for name, objective in (("lasso", lambda x: np.sum((A @ x - b) ** 2) + 0.3 * np.abs(x).sum()),
+                            ("ridge", lambda x: 2 * np.sum((A @ x - b) ** 2) + 0.6 * np.sum(x * x)),
+                            ("nnls", lambda x: 0.5 * np.sum((A @ x - b) ** 2))):     # (reference quirk: 1/2 |.|^2, unscaled)
+        p = cases[name]
+        value = pogs.pogs_solve(p, abs_tol=1e-6, rel_tol=1e-6)
+        x = p.variables()[0].value
+        assert p._status == "optimal" and p._value == value and not p.fallback_calls, name
+        assert value == pytest.approx(objective(np.asarray(x, np.float64)), rel=1e-4), name
+        if name == "nnls":
+            assert np.all(x >= -1e-9)
+    want = pogs.solve_lasso(A, b, 0.15, abs_tol=1e-6, rel_tol=1e-6)
+    assert np.array_equal(cases["lasso"].variables()[0].value, want["x"])

@@ -11,6 +11,8 @@ import pytest
 import pogs_amd
 from pogs_amd import graph as G
 
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
 PL = np.load(os.path.join(os.path.dirname(__file__), "golden", "python_layer.npz"))
 A, b = PL["A"], PL["b"]
 lab = np.sign(b)
@@ -115,3 +117,67 @@ def test_bench_self_launches_one_rank_per_gpu(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "8")
     bench.maybe_spawn(types.SimpleNamespace(gpus=8))
     assert len(calls) == 1
+
+
+# ---- CVXPY front end (reference: python/pogs/cvxpy.py) ------------------------------------------
+
+def test_cvxpy_detection_matches_the_reference_detector():
+    """pogs_amd.cvxpy.detect_graph_form on the stand-in expression trees against what the
+    REFERENCE's _detect_graph_form returned for the same trees (tests/golden/cvxpy_detection.json,
+    generated by tests/golden/make_cvxpy_golden.py with the stand-ins installed as `cvxpy`):
+    same pattern, lambda, optimum scale, A and b -- and None for the same problems."""
+    import json
+
+    import cvxpy_standins as S
+    from pogs_amd import cvxpy as front
+
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "cvxpy_detection.json")))
+    problems = S.cases()
+    assert set(problems) == set(want) and sum(v is not None for v in want.values()) >= 7
+    for name, problem in problems.items():
+        got = front.detect_graph_form(problem)
+        if want[name] is None:
+            assert got is None, name
+            continue
+        kind, params = got
+        assert kind == want[name]["type"], name
+        assert params.get("lambd") == want[name]["lambd"], name          # same arithmetic: bit-equal
+        assert params.get("optval_scale") == want[name]["optval_scale"], name
+        assert np.array_equal(np.asarray(params["A"]), np.asarray(want[name]["A"])), name
+        assert np.array_equal(np.asarray(params["b"]), np.asarray(want[name]["b"])), name
+
+
+def test_pogs_solve_fills_in_the_problem_or_falls_through(monkeypatch):
+    """pogs_solve (python/pogs/cvxpy.py:33-92): on a detected pattern the variable value, status and
+    the SCALED optimum are set and returned; on no pattern or a failed solve the problem's own
+    solve() is called with the options.  (Solver calls are replaced here; the GPU suite runs them.)"""
+    import cvxpy_standins as S
+    from pogs_amd import cvxpy as front
+
+    calls = []
+
+    def fake(status):
+        def solve(A, b, *lam, **kw):
+            calls.append((A.shape, tuple(lam), kw))
+            return dict(x=np.arange(A.shape[1], dtype=float), optval=3.0, status=status, iterations=7)
+        return solve
+
+    monkeypatch.setattr(front, "solve_lasso", fake(0))
+    monkeypatch.setattr(front, "solve_ridge", fake(0))
+    monkeypatch.setattr(front, "solve_nonneg_ls", fake(3))       # max-iter: "failed"
+    cases = S.cases()
+    p = cases["ridge"]                                           # 2 |Ax-b|^2 + 0.6 |x|^2 -> lambda 0.3, scale 4
+    assert front.pogs_solve(p, max_iter=11, rho=2.0) == 12.0
+    assert p._status == "optimal" and p._value == 12.0 and np.array_equal(p.variables()[0].value, np.arange(5.0))
+    assert calls[-1][1] == (0.3,) and calls[-1][2]["max_iter"] == 11 and calls[-1][2]["rho"] == 2.0
+    assert calls[-1][2]["abs_tol"] == 1e-4 and calls[-1][2]["rel_tol"] == 1e-4 and calls[-1][2]["verbose"] == 0
+    assert not p.fallback_calls
+    p = cases["nnls"]                                            # solver reports status 3 -> default solver
+    front.pogs_solve(p, verbose=True)
+    assert p.fallback_calls == [dict(verbose=True)] and p.variables()[0].value is None
+    p = cases["plain_least_squares"]                             # no pattern -> default solver, options passed on
+    front.pogs_solve(p, eps=1e-9)
+    assert p.fallback_calls == [dict(verbose=False, eps=1e-9)]
+    import pogs_amd
+
+    assert pogs_amd.pogs_solve is front.pogs_solve               # exported like the reference's (__init__.py:29)
