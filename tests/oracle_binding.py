@@ -172,6 +172,19 @@ def oracle_solve(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4,
     return r
 
 
+def oracle_set_threads(n=None):
+    """OpenMP threads of the oracle port (its loops are `#pragma omp parallel for`): the container's
+    CPU quota by default -- the GPU box shows 256 hardware threads but grants 16 cores, and 256
+    OpenMP threads on 16 cores are several times slower than 16."""
+    n = int(n or cpu_quota())
+    os.environ["OMP_NUM_THREADS"] = str(n)
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(n)
+    except OSError:
+        pass
+    return n
+
+
 def ref_available():
     return os.path.exists(_REF_SO)
 
