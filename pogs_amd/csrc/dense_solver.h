@@ -886,10 +886,15 @@ class DenseSolver final : public SolverBase {
           // launch into the four slabs: 16384 rows per round where the K dimension is that long
           int chains = 1;
           while (chains < 4 && kdim >= 4 * kRows * chains * 2) chains *= 2;
-          int tile = 128;
+          // 256 x 256 workgroup tiles (half the operand bytes per product of the 128 tile; one
+          // accumulator set, i.e. a unit is ONE MFMA chain of up to 4096 rows) where the Gram matrix
+          // has enough of them to fill the chip; measured at C2 31.8 against 33.9 ms of kernel time,
+          // no difference at n = 5000 (C3).  Chain length: 1024 .. 16384 rows give the same 106
+          // iterations at C2 and x within 6e-7 of each other (scripts/gram_chain_probe.py), the
+          // same distance the native fp32 product is at.
+          int tile = k_ >= 8192 ? 256 : 128;
           if (const char *ev = std::getenv("POGS_AMD_GRAM_TILE")) tile = std::atoi(ev) == 256 ? 256 : 128;   // tuning aid
           if (const char *ev = std::getenv("POGS_AMD_GRAM_CHAINS")) chains = std::max(1, std::min(16, std::atoi(ev)));
-          if (tile == 256) chains = 1;
           const int urows = kRows * chains;
           const int nunits = (kdim + urows - 1) / urows;
           const int npad = static_cast<int>(round_up(k_, tile));
@@ -899,6 +904,8 @@ class DenseSolver final : public SolverBase {
           GramF16PArgs gp{H, L, npad, k_, reinterpret_cast<float *>(G), ld, 4, urows, slab, 0, g.tile_map, scale16};
           gp.tile = tile;
           gp.flush_rows = kRows;
+          if (const char *ev = std::getenv("POGS_AMD_GRAM_ABLATE")) gp.ablate = std::atoi(ev);   // measurement aid
+          if (const char *ev = std::getenv("POGS_AMD_GRAM_FLUSH")) gp.flush_rows = std::max(0, std::atoi(ev));   // tuning aid: 0 = one chain per unit
           DevBuf<int> tmap256;
           if (tile == 256) {
             gp.tile_map = nullptr;

@@ -41,6 +41,10 @@ struct GemmArgs {
   // optional tile order (device pointer, one entry (tile_i << 16 | tile_j) per computed tile):
   // workgroups that run together then share operand panels in L2 (see gram_tile_order)
   const int *tile_map = nullptr;
+  // ktri: a triangular operand's zero blocks are skipped (the products left out are exact zeros, so
+  // the result has the same bits).  1: op(B)(k, j) = 0 for k < j (lower-triangular B in (k, j)): a
+  // tile's K range starts at its first column.  2: op(A)(i, k) = 0 for k > i: it ends after its last row.
+  int ktri = 0;
 };
 
 // G += / = P^T P (lower 128 x 128 tiles) for a K-major fp32 operand P (K rows of N, leading
@@ -84,6 +88,7 @@ struct GramF16PArgs {
   float scale;
   int tile = 128;                 // workgroup tile: 128 (4 waves) or 256 (8 waves); tile_map must match
   int flush_rows = 0;             // 128 tile: rows per MFMA chain inside a unit (0: the whole kchunk)
+  int ablate = 0;                 // measurement aid: 1 = no MFMAs, 2 = no global->LDS copies (results are garbage)
 };
 void launch_gram_f16p(const GramF16PArgs &g, hipStream_t s);
 

@@ -126,8 +126,8 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
   const int ks = unit / ntiles;
   const int tile = unit % ntiles;
   const bool split = g.kchunk > 0;
-  const int kbeg = split ? (g.ks0 + ks) * g.kchunk : 0;
-  const int kend = split ? ((kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K) : g.K;
+  int kbeg = split ? (g.ks0 + ks) * g.kchunk : 0;
+  int kend = split ? ((kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K) : g.K;
   T *Cout = g.C + static_cast<size_t>(ks) * g.csplit_stride;
   int ti, tj;
   if (g.tile_map) {
@@ -145,6 +145,8 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
     tj = tile % tn_;
   }
   const int i0 = ti * BM, j0 = tj * BN;
+  if (g.ktri == 1) kbeg = max(kbeg, j0);              // BN is a multiple of BK
+  if (g.ktri == 2) kend = min(kend, i0 + BM);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int l15 = lane & 15, lk = lane >> 4;
@@ -709,8 +711,8 @@ __global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_
     // the stage about to be refilled has been read by all
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (i + 1 < nsteps) issue((i + 1) & 1, i + 1);
-    compute(i & 1);
+    if (i + 1 < nsteps && !(g.ablate & 2)) issue((i + 1) & 1, i + 1);
+    if (!(g.ablate & 1)) compute(i & 1);
     if (TWO && --until_flush == 0) {
       until_flush = fsteps;
 #pragma unroll
@@ -862,10 +864,12 @@ void trtri_lower(const T *L, size_t ldg, int n, T *W, size_t ldw, T *tmp, hipStr
       g1.strideA = static_cast<size_t>(2 * sz) * (ldg + 1);
       g1.strideB = static_cast<size_t>(2 * sz) * (ldw + 1);
       g1.strideC = g1.strideB;
+      g1.ktri = 1;   // W_aa is lower-triangular
       launch_gemm<T>(false, true, false, g1, s);
       GemmArgs<T> g2{nb, na, nb, Wbb, ldw, Tba, ldw, Wba, ldw, static_cast<T>(-1), static_cast<T>(0)};
       g2.batch = batch;
       g2.strideA = g2.strideB = g2.strideC = g1.strideB;
+      g2.ktri = 2;   // W_bb is lower-triangular
       launch_gemm<T>(false, true, false, g2, s);
     };
     if (full > 0) level(0, na, full);
