@@ -952,7 +952,19 @@ class DenseSolver final : public SolverBase {
       }
       if (ksplit > 1) POGS_HIP_CHECK(hipMemsetAsync(G + slab, 0, 3 * slab * sizeof(T), s));
       ctx_.sync();   // tmap is freed at scope exit
-      if (multi_) ctx_.dist.allreduce(G, slab, s);
+      if (multi_) {
+        // G = sum over the ranks of A_k^T A_k: only the lower block-triangle travels (half the bytes
+        // of the k x ld square), packed into the scratch slab, ONE all-reduce, unpacked in place
+        const size_t cnt = packed_lower_count(k_, ld);
+        if (ld % Vec16<T>::N == 0 && cnt <= slab) {
+          launch_pack_lower<T>(G, ld, k_, tmp, false, s);
+          ctx_.dist.allreduce(tmp, cnt, s);
+          launch_pack_lower<T>(G, ld, k_, tmp, true, s);
+          POGS_HIP_CHECK(hipMemsetAsync(tmp, 0, cnt * sizeof(T), s));
+        } else {
+          ctx_.dist.allreduce(G, slab, s);
+        }
+      }
       ctx_.stats.gram_ms = pt.stop_ms();
       ctx_.stats.gram_flops = static_cast<double>(kdim) * k_ * k_;
     }

@@ -133,6 +133,13 @@ void launch_sum_slabs(const T *in, size_t stride, int nslabs, T *out, size_t ld,
 template <typename T>
 void launch_zero_upper(T *G, size_t ldg, int n, hipStream_t s);
 
+// Lower block-triangle of an n x n matrix (rows of 128-row block b keep their first
+// min(ld, 128 (b + 1)) columns) <-> a contiguous buffer: what a row-sharded Gram matrix sums over
+// the ranks -- about half of the n x ld square.  Returns the element count.
+size_t packed_lower_count(int n, size_t ld);
+template <typename T>
+void launch_pack_lower(T *G, size_t ld, int n, T *packed, bool unpack, hipStream_t s);
+
 // G[i][i] += v
 template <typename T>
 void launch_add_diag(T *G, size_t ldg, int n, T v, hipStream_t s);

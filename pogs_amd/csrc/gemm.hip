@@ -893,6 +893,41 @@ void launch_zero_upper(T *G, size_t ldg, int n, hipStream_t s) {
   hipLaunchKernelGGL(zero_upper_kernel<T>, dim3((n + 255) / 256, n), dim3(256), 0, s, G, ldg, n);
 }
 
+namespace {
+__host__ __device__ inline size_t packed_lower_offset(int i, size_t ld, size_t *len) {
+  const size_t b = static_cast<size_t>(i) / BM;
+  const size_t L = (BM * (b + 1) < ld) ? BM * (b + 1) : ld;
+  *len = L;
+  return static_cast<size_t>(BM) * BM * (b * (b + 1) / 2) + (static_cast<size_t>(i) - BM * b) * L;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) pack_lower_kernel(T *G, size_t ld, int n, T *packed, bool unpack) {
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = Vec16<T>::N;
+  const int i = blockIdx.x;
+  size_t len;
+  const size_t off = packed_lower_offset(i, ld, &len);
+  T *row = G + static_cast<size_t>(i) * ld, *pk = packed + off;
+  for (size_t c = static_cast<size_t>(threadIdx.x) * VEC; c < len; c += 256 * VEC) {   // len, ld: multiples of VEC
+    if (unpack) *reinterpret_cast<V *>(row + c) = *reinterpret_cast<const V *>(pk + c);
+    else *reinterpret_cast<V *>(pk + c) = *reinterpret_cast<const V *>(row + c);
+  }
+}
+}  // namespace
+
+size_t packed_lower_count(int n, size_t ld) {
+  if (n <= 0) return 0;
+  size_t len;
+  const size_t off = packed_lower_offset(n - 1, ld, &len);
+  return off + len;
+}
+
+template <typename T>
+void launch_pack_lower(T *G, size_t ld, int n, T *packed, bool unpack, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(pack_lower_kernel<T>, dim3(n), dim3(256), 0, s, G, ld, n, packed, unpack);
+}
+
 template <typename T>
 void launch_add_diag(T *G, size_t ldg, int n, T v, hipStream_t s) {
   hipLaunchKernelGGL(add_diag_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, s, G, ldg, n, v);
@@ -905,6 +940,7 @@ void launch_add_diag(T *G, size_t ldg, int n, T v, hipStream_t s) {
   template void launch_transpose<T>(const T *, size_t, int, int, T *, size_t, hipStream_t);    \
   template void launch_sum_slabs<T>(const T *, size_t, int, T *, size_t, int, hipStream_t);       \
   template void launch_zero_upper<T>(T *, size_t, int, hipStream_t);                           \
+  template void launch_pack_lower<T>(T *, size_t, int, T *, bool, hipStream_t);                  \
   template void launch_add_diag<T>(T *, size_t, int, T, hipStream_t);
 POGS_INST(float)
 POGS_INST(double)

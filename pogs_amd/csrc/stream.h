@@ -438,6 +438,11 @@ struct StreamArgs2 {
   double *scalar_partials;   // [gridDim.x][Op::NS]
 };
 
+// (Measured and not kept: requesting the NEXT row tile before the current one is reduced, so that
+// the memory pipe does not idle through a slow row functor -- the logistic prox, one lane per row,
+// 0.35 us per step.  At the C3 shape the R * NV extra vector registers take the kernel from three
+// to two workgroups per CU and the pass from 0.692 to 0.715 ms: resident workgroups hide the
+// functor better than a prefetch does.)
 template <typename T, int TPB, int NV, int R, int ND, int NA, typename Op>
 __global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op op) {
   using V = typename Vec16<T>::type;
