@@ -66,7 +66,8 @@ struct StreamArgs {
 struct StreamPlan {
   int tpb = 0;   // threads per workgroup: 64, 256, 512 or 1024
   int nv = 0;    // 16-byte vectors per thread per row
-  int grid_max = 0;
+  int grid_max = 0;    // most workgroups any launch of this plan uses (sizes the partial-sum buffers)
+  int grid_dot = 0;    // single-dot kernels (stream_rows_kernel): the workgroups resident at once
   bool ok = false;
   // rows wider than one register tile: the pass is run window by window (tpb * nv vectors of
   // columns each) -- column sums window-wise, row dots as partial dots that a small kernel adds
@@ -123,11 +124,18 @@ inline StreamPlan make_stream_plan(int n_pad, int num_cu) {
   const char *xl_env = std::getenv("POGS_AMD_XL_LIMIT");
   const bool forced_xl = xl_env && vpr > std::atoi(xl_env);
   for (int nv : nv64)
-    if (!forced_xl && vpr <= 64 * nv) { p.tpb = 64; p.nv = nv; p.grid_max = num_cu * 8; p.ok = true; return p; }
+    if (!forced_xl && vpr <= 64 * nv) { p.tpb = 64; p.nv = nv; p.grid_max = p.grid_dot = num_cu * 8; p.ok = true; return p; }
   for (int nv : nv256)
-    if (!forced_xl && vpr <= 256 * nv) { p.tpb = 256; p.nv = nv; p.grid_max = num_cu * 2; p.ok = true; return p; }
+    if (!forced_xl && vpr <= 256 * nv) {
+      p.tpb = 256; p.nv = nv; p.grid_dot = num_cu * 2;
+      // at nv = 5 the one-pass iteration kernel takes two rows per step (stream2_rows_c), needs 167
+      // VGPRs and fits three workgroups per CU: a slow row functor (logistic prox) hides better
+      p.grid_max = num_cu * (nv == 5 ? 3 : 2);
+      p.ok = true;
+      return p;
+    }
   for (int nv : nv512)
-    if (!forced_xl && vpr <= 512 * nv) { p.tpb = 512; p.nv = nv; p.grid_max = num_cu; p.ok = true; return p; }
+    if (!forced_xl && vpr <= 512 * nv) { p.tpb = 512; p.nv = nv; p.grid_max = p.grid_dot = num_cu; p.ok = true; return p; }
   // POGS_AMD_XL_LIMIT=<vectors> (testing aid): rows wider than that take the windowed form below,
   // with small windows so that small test matrices span several of them
   int limit = 1024 * 8;
@@ -135,12 +143,12 @@ inline StreamPlan make_stream_plan(int n_pad, int num_cu) {
   if (const char *ev = std::getenv("POGS_AMD_XL_LIMIT")) { limit = std::atoi(ev); small_windows = true; }
   if (vpr <= limit) {
     for (int nv : nv1024)
-      if (vpr <= 1024 * nv) { p.tpb = 1024; p.nv = nv; p.grid_max = num_cu; p.ok = true; return p; }
+      if (vpr <= 1024 * nv) { p.tpb = 1024; p.nv = nv; p.grid_max = p.grid_dot = num_cu; p.ok = true; return p; }
   }
   p.xl = true;
   p.ok = true;
-  if (small_windows) { p.tpb = 64; p.nv = 2; p.grid_max = num_cu * 8; }
-  else { p.tpb = 256; p.nv = 8; p.grid_max = num_cu * 2; }
+  if (small_windows) { p.tpb = 64; p.nv = 2; p.grid_max = p.grid_dot = num_cu * 8; }
+  else { p.tpb = 256; p.nv = 8; p.grid_max = p.grid_dot = num_cu * 2; }
   return p;
 }
 
@@ -305,7 +313,7 @@ template <bool DOT, bool ACC>
 inline int stream_grid(const StreamPlan &p, int m) {
   const int R = (p.tpb == 1024) ? ((DOT && ACC) ? 1 : 2) : ((DOT && ACC) ? 2 : 4);
   const int nblk = (m + R - 1) / R;
-  return nblk < p.grid_max ? (nblk > 0 ? nblk : 1) : p.grid_max;
+  return nblk < p.grid_dot ? (nblk > 0 ? nblk : 1) : p.grid_dot;
 }
 
 // ---- windowed form for rows wider than one register tile (StreamPlan::xl) -------------------
@@ -587,7 +595,7 @@ inline bool stream2_supported(const StreamPlan &p) {
 // allows (4*NV*(R + 1 + 2) + ~70 VGPRs <= 256), so the per-row functor latency (one lane per
 // row) is amortised over R rows.
 constexpr int stream2_rows_c(int nd, int nv) {
-  return nd > 0 ? (nv <= 2 ? 8 : nv <= 4 ? 4 : nv <= 6 ? 3 : nv <= 8 ? 2 : 1) : (nv <= 4 ? 8 : nv <= 8 ? 4 : 2);
+  return nd > 0 ? (nv <= 2 ? 8 : nv <= 4 ? 4 : nv == 5 ? 2 : nv <= 6 ? 3 : nv <= 8 ? 2 : 1) : (nv <= 4 ? 8 : nv <= 8 ? 4 : 2);
 }
 template <int ND>
 inline int stream2_rows(const StreamPlan &p) { return stream2_rows_c(ND, p.nv); }
@@ -595,7 +603,8 @@ template <int ND>
 inline int stream2_grid(const StreamPlan &p, int m) {
   const int R = stream2_rows<ND>(p);
   const int nblk = (m + R - 1) / R;
-  return nblk < p.grid_max ? (nblk > 0 ? nblk : 1) : p.grid_max;
+  const int gmax = ND > 0 ? p.grid_max : p.grid_dot;   // (the column-sum-only form keeps the two-per-CU grid)
+  return nblk < gmax ? (nblk > 0 ? nblk : 1) : gmax;
 }
 
 template <typename T, int ND, int NA, typename Tag = AllPlans, typename Op>
