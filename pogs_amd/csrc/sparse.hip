@@ -812,7 +812,8 @@ class SparseSolver final : public SolverBase {
     // are summed by the launch that publishes the scalars, so they keep regions of their own
     sp_cgx_off_ = std::max<size_t>(sg * 4 + 64, vb * 3 + 64);
     sp_cgp_off_ = sp_cgx_off_ + static_cast<size_t>(vec_blocks(n_)) + 8;
-    ctx_.ensure_spart(sp_cgp_off_ + static_cast<size_t>(vec_blocks(n_)) + 8);
+    sp_pre_off_ = sp_cgp_off_ + static_cast<size_t>(vec_blocks(n_)) + 8;   // prox-step sums (deferred on one GPU)
+    ctx_.ensure_spart(sp_pre_off_ + vb * 3 + 8);
   }
 
   // y_i = op(sum_k val * x[ind]) over the rows of M; scalar sums land in S[slot..slot+NS)
@@ -1033,7 +1034,10 @@ class SparseSolver final : public SolverBase {
   // reference forms b = y0 - A x0 and r = b - A (x - x0) with two SpMVs (:65-68,
   // cgls.h:226-233); their sum is r = y0 - A x_warm, and inside the ADMM loop A x_warm is the
   // previous iteration's y (the projection always ends with y = A x), so both SpMVs vanish.
-  void cgls_project(const T *x0, const T *y0, T *x, T tol, const T *Ax_warm = nullptr) {
+  // `x_warm` (with Ax_warm): where the warm start is read from -- x itself by default; the ADMM
+  // loop passes the previous iterate, which saves the 2 MB device-to-device copy into x per
+  // iteration (30 us at C4 through the runtime's blit kernel).
+  void cgls_project(const T *x0, const T *y0, T *x, T tol, const T *Ax_warm = nullptr, const T *x_warm = nullptr) {
     hipStream_t s = ctx_.stream;
     const int bx = vec_blocks(n_);
     const double shift = 1.0;
@@ -1042,7 +1046,7 @@ class SparseSolver final : public SolverBase {
       // r = y0 - A x_warm ; x <- x - x0                                       (:62)
       hipLaunchKernelGGL(sub_norm_kernel<T>, dim3(vec_blocks(m_)), dim3(kVecTpb), 0, s, m_, y0, Ax_warm, cg_r_.p,
                          ctx_.spart.p);
-      hipLaunchKernelGGL(sub_norm_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, x, x0, x, ctx_.spart.p);
+      hipLaunchKernelGGL(sub_norm_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, x_warm ? x_warm : x, x0, x, ctx_.spart.p);
     } else {
       // x <- x - x0, |x|^2                                                    (:62)
       hipLaunchKernelGGL(sub_norm_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, x, x0, x, ctx_.spart.p);
@@ -1138,27 +1142,30 @@ class SparseSolver final : public SolverBase {
     pa.x12 = x12_.p; pa.y12 = y12_.p;
     pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
     pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
-    pa.partials = ctx_.spart.p;
+    pa.partials = ctx_.spart.p + sp_pre_off_;
     pa.blocks_x = vec_blocks(n_);
     launch_admm_pre<T>(pa, s);
     {
-      SumJob j[2] = {{ctx_.spart.p, pa.blocks_x, 3, ctx_.S.p + kGapX},
-                     {ctx_.spart.p + static_cast<size_t>(pa.blocks_x) * 3, vec_blocks(m_), 3, ctx_.S.p + kGapY}};
-      launch_sum_jobs(j, 2, s);
-      reduce_y_scalars(ctx_.S.p + kGapY, 3);
+      SumJob j[2] = {{pa.partials, pa.blocks_x, 3, ctx_.S.p + kGapX},
+                     {pa.partials + static_cast<size_t>(pa.blocks_x) * 3, vec_blocks(m_), 3, ctx_.S.p + kGapY}};
+      if (!multi_) {
+        // one GPU: summed by the launch that publishes the scalar block next (the first fetch of the
+        // projection); the partials have a region of their own until then
+        ctx_.queue_sum(j[0]);
+        ctx_.queue_sum(j[1]);
+      } else {
+        launch_sum_jobs(j, 2, s);
+        reduce_y_scalars(ctx_.S.p + kGapY, 3);
+      }
     }
     // warm start with the previous x (pogs.cpp:281), then CGLS
-    POGS_HIP_CHECK(hipMemcpyAsync(x_[nw].p, x_[cur_].p, n_ * sizeof(T), hipMemcpyDeviceToDevice, s));
-    cgls_project(xtemp_.p, ytemp_.p, x_[nw].p, ctl_.proj_tol(), y_[cur_].p);   // y_cur == A x_cur
+    cgls_project(xtemp_.p, ytemp_.p, x_[nw].p, ctl_.proj_tol(), y_[cur_].p, x_[cur_].p);   // y_cur == A x_cur
     // y = A x fused with the y-half bookkeeping; x-half element-wise        (projector_cgls.cpp:78)
     spmv<false>(A_, x_[nw].p, nullptr, SpTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p}, ctx_.S.p + kDYprev2, 0,
                 true);
     reduce_y_scalars(ctx_.S.p + kDYprev2, 2);
     launch_admm_tail<T>(n_, x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, ctx_.spart.p, s);
-    {
-      SumJob j{ctx_.spart.p, vec_blocks(n_), 2, ctx_.S.p + kDXprev2};
-      launch_sum_jobs(&j, 1, s);
-    }
+    ctx_.queue_sum(SumJob{ctx_.spart.p, vec_blocks(n_), 2, ctx_.S.p + kDXprev2});   // x side: no exchange; summed by the fetch below
     const double *S = ctx_.fetch_scalars();
     ctl_.set_pre(S);
     bool exact = false;
@@ -1248,7 +1255,7 @@ class SparseSolver final : public SolverBase {
   bool multi_ = false;
   DevBuf<T> tsum_;   // row shards: this rank's A^T partial sums before the all-reduce
   int spmv_grid_ = 2048;
-  size_t sp_cgx_off_ = 0, sp_cgp_off_ = 0;   // regions of ctx_.spart (alloc_state)
+  size_t sp_cgx_off_ = 0, sp_cgp_off_ = 0, sp_pre_off_ = 0;   // regions of ctx_.spart (alloc_state)
   unsigned long long timed_spmvs_ = 0;
   bool warm_pending_ = false;
   std::vector<T> warm_x_, warm_l_;

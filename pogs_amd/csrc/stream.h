@@ -301,6 +301,9 @@ __global__ void __launch_bounds__(TPB) stream_rows_kernel(StreamArgs<T> a, Op op
   }
 }
 
+// (Measured and not kept: one row per step for the dot + column-sum form at 256 x 10 -- 154 VGPRs,
+// three workgroups per CU.  The triangular W sweep stayed at 40.7 us, the full passes got slower
+// (Sinkhorn-Knopp pass 614 -> 653 us) and the second stage had 50 % more partials to add.)
 // Rows per workgroup step by mode and workgroup size (register budget: the row
 // tile costs 4*R*NV VGPRs, the x / column-sum vectors 4*NV each).
 template <bool DOT, bool ACC, int TPB>
