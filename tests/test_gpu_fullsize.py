@@ -439,6 +439,51 @@ def test_c2_solution_matches_compiled_reference():
         assert np.linalg.norm(live["x"].astype(np.float64) - x32) <= 2e-5 * np.linalg.norm(x32)
 
 
+def test_wide_10000x100000_solution_matches_compiled_reference():
+    """The m <= n path at full size (10000 x 100000 fp32 lasso, A A^T projector,
+    projector_direct_dense.cpp:128-135; the engine runs it on transposed storage with the mirrored
+    one-pass iteration) against the compiled reference's fp32 and fp64 solutions of the same problem
+    (tests/golden/make_wide_reference.py -> wide_reference.npz; the matrix is regenerated from its
+    seed and checked against the fixture's checksums).  Same bars as for C2."""
+    import os
+
+    from pogs_amd import synth
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "wide_reference.npz")
+    if not os.path.exists(path):
+        pytest.skip("wide_reference.npz not generated")
+    torch = _torch()
+    pogs = _pogs()
+    fx = np.load(path)
+    m, n = (int(v) for v in fx["shape"])
+    A_host, b, _ = synth.dense_lasso_rows(m, n, seed=int(fx["seed"]), density=0.01, chunk=500)
+    chk = np.array([float(A_host[::97].astype(np.float64).sum()), float(np.abs(A_host[:, ::1013]).astype(np.float64).sum()),
+                    float(np.linalg.norm(b)), float(b[::11].sum())])
+    np.testing.assert_allclose(chk, fx["checksums"], rtol=1e-12, err_msg="the generator no longer reproduces the fixture's inputs")
+    lam = float(fx["lam"])
+    f, gg = pogs.graph.lasso_functions(b, lam, n)
+    A = torch.from_numpy(A_host).to("cuda:0")
+    r = _engine_solve(pogs, A, f, gg, {})
+    x = r["x"].astype(np.float64)
+    x32, x64 = fx["x"].astype(np.float64), fx["x_fp64"].astype(np.float64)
+    it, it32, it64 = r["iterations"] + 1, int(fx["iterations"]) + 1, int(fx["iterations_fp64"]) + 1
+    rel32 = np.linalg.norm(x - x32) / np.linalg.norm(x32)
+    rel64 = np.linalg.norm(x - x64) / np.linalg.norm(x64)
+    print("wide vs reference: iterations %d (fp32 ref %d, fp64 ref %d), rel_x %.3e / %.3e, optval %.6f (%.6f / %.6f)"
+          % (it, it32, it64, rel32, rel64, r["optval"], float(fx["optval"]), float(fx["optval_fp64"])))
+    assert r["status"] == 0
+    assert rel32 <= 1e-4 and rel64 <= 1e-4
+    assert min(abs(it - it64), abs(it - it32)) <= max(3, it64 // 10) and it <= max(it32, it64) + max(3, it64 // 10)
+    y = np.concatenate([A_host[r0:r0 + 500].astype(np.float64) @ x for r0 in range(0, m, 500)])
+    obj = 0.5 * float(np.sum((y - b) ** 2)) + lam * float(np.abs(x).sum())
+    for key in ("objective_at_x", "objective_at_x_fp64"):
+        assert abs(obj - float(fx[key])) <= 1e-4 * float(fx[key]), (key, obj, float(fx[key]))
+    y64 = fx["y_fp64"].astype(np.float64)
+    assert np.linalg.norm(r["y"].astype(np.float64) - y64) <= 2e-4 * np.linalg.norm(y64)
+    if it == it64:
+        assert abs(r["optval"] - float(fx["optval_fp64"])) <= 1e-4 * float(fx["optval_fp64"])
+
+
 def test_c3_solution_matches_compiled_reference():
     """configs[2] at full size (200000 x 5000 logistic, logits with std 2) against the compiled
     reference on the same inputs (measured: ||dx|| / ||x|| = 2.3e-5, optval 7e-5, 188 vs 184 iterations)."""
