@@ -485,10 +485,12 @@ def test_every_solve_family_against_the_live_reference_at_60000x2000(family):
     soa = lambda fv: {k: getattr(fv, k) for k in "habcde"}  # noqa: E731
     max_iter = 300 if family == "svm" else 2500
     want_status = 3 if family == "svm" else 0
-    run32 = ob.ref_start(A, soa(f), soa(g), dtype=np.float32, threads=ob.ref_threads(), max_iter=max_iter)
+    half = max(1, ob.ref_threads() // 2)          # the two reference builds run side by side
+    run32 = ob.ref_start(A, soa(f), soa(g), dtype=np.float32, threads=half, max_iter=max_iter)
+    run64 = ob.ref_start(A.astype(np.float64), soa(f), soa(g), dtype=np.float64, threads=half, max_iter=max_iter)
     got = G._solve_graph_form(A, f, g, 1e-4, 1e-4, max_iter, 0, 1.0, dtype=np.float32)
     ref32 = run32.finish(timeout=900)
-    ref64 = ob.ref_solve(A.astype(np.float64), soa(f), soa(g), dtype=np.float64, threads=ob.ref_threads(), max_iter=max_iter, timeout=900)
+    ref64 = run64.finish(timeout=900)
     it, it32, it64 = got["iterations"] + 1, ref32["iterations"] + 1, ref64["iterations"] + 1
     x = got["x"].astype(np.float64)
     rel = lambda r: np.linalg.norm(x - r["x"].astype(np.float64)) / max(np.linalg.norm(r["x"].astype(np.float64)), 1e-300)  # noqa: E731
