@@ -510,6 +510,62 @@ def test_every_solve_family_against_the_live_reference_at_60000x2000(family):
         assert rel_o <= (1e-4 if it == it64 else 1e-2)
 
 
+@pytest.mark.parametrize("family", ["lasso", "ridge", "elastic_net", "logistic", "huber", "nonneg_ls"])
+def test_sparse_solve_families_against_the_live_reference_at_100000x20000(family):
+    """The sparse path (PogsSparseS: CSR + transposed copy, CGLS projector; matrix_sparse.cpp,
+    projector_cgls.cpp, cgls.h) for six solve_* families at 100000 x 20000, 2e6 non-zeros, fp32,
+    against the compiled reference's fp32 and fp64 builds run live (3-10 s each).  Same bars as the
+    dense family test; C4 itself is pinned to the OpenMP oracle above (the reference is
+    single-threaded on this path and needs tens of minutes at 1e8 non-zeros)."""
+    import oracle_binding as ob
+    from pogs_amd import synth
+
+    if not ob.ref_available():
+        pytest.skip("compiled reference not present (oracle/_ref is built in the build container)")
+    pogs = _pogs()
+    G = pogs.graph
+    m, n = 100000, 20000
+    A, b, xt = synth.csr_lasso(m, n, 20, seed=7, dtype=np.float32)
+    rng = np.random.default_rng(8)
+    if family == "logistic":
+        z = A.astype(np.float64) @ xt
+        b = 2.0 * (rng.random(m) < 1.0 / (1.0 + np.exp(-2.0 * z / z.std()))) - 1.0
+    elif family == "nonneg_ls":
+        b = A.astype(np.float64) @ np.abs(xt) + 0.1 * rng.standard_normal(m)
+    elif family == "huber":
+        b = b.copy()
+        b[rng.random(m) < 0.02] += 20.0
+    f, g = {"lasso": lambda: G.lasso_functions(b, 0.1 * float(np.max(np.abs(A.T @ b))), n),
+            "ridge": lambda: G.ridge_functions(b, 5.0, n),
+            "elastic_net": lambda: G.elastic_net_functions(b, 5.0, 2.0, n),
+            "logistic": lambda: G.logistic_functions(b, 0.01, n),
+            "huber": lambda: G.huber_functions(b, 1.0, 0.5, n),
+            "nonneg_ls": lambda: G.nonneg_ls_functions(b, n)}[family]()
+    soa = lambda fv: {k: getattr(fv, k) for k in "habcde"}  # noqa: E731
+    run32 = ob.ref_start(A, soa(f), soa(g), dtype=np.float32, threads=2)
+    run64 = ob.ref_start(A.astype(np.float64), soa(f), soa(g), dtype=np.float64, threads=2)
+    got = G._solve_graph_form(A, f, g, 1e-4, 1e-4, 2500, 0, 1.0, dtype=np.float32)
+    ref32, ref64 = run32.finish(timeout=900), run64.finish(timeout=900)
+    it, it32, it64 = got["iterations"] + 1, ref32["iterations"] + 1, ref64["iterations"] + 1
+    x = got["x"].astype(np.float64)
+    rel = lambda r: np.linalg.norm(x - r["x"].astype(np.float64)) / max(np.linalg.norm(r["x"].astype(np.float64)), 1e-300)  # noqa: E731
+    # (the CGLS projection is inexact by construction, tolerance 1e-2 sqrt(r): the fp32 and fp64 builds of
+    # the reference stop their inner loops at different points and can differ by more than rounding --
+    # ridge: 2.9e-5 in x, 2e-4 in optval between them; optval is held against the closer of the two)
+    rel_o = min(abs(got["optval"] - r["optval"]) / max(abs(r["optval"]), 1e-300) for r in (ref32, ref64))
+    line = ("sparse %s: iterations %d (ref fp32 %d, fp64 %d), rel_x %.2e / %.2e, optval %.8g (%.8g / %.8g), status %d / %d / %d"
+            % (family, it, it32, it64, rel(ref32), rel(ref64), got["optval"], ref32["optval"], ref64["optval"], got["status"], ref32["status"], ref64["status"]))
+    print(line)
+    if os.environ.get("POGS_AMD_PARITY_LOG"):
+        with open(os.environ["POGS_AMD_PARITY_LOG"], "a") as fh:
+            fh.write(line + "\n")
+    assert got["status"] == ref32["status"] == ref64["status"] == 0
+    slack = max(3, it64 // 10)
+    assert abs(it - it64) <= slack and it <= it32 + slack
+    assert rel(ref64) <= 1e-4 and rel(ref32) <= 1e-4
+    assert rel_o <= (1e-4 if it in (it32, it64) else 1e-2)
+
+
 def test_wide_10000x100000_solution_matches_compiled_reference():
     """The m <= n path at full size (10000 x 100000 fp32 lasso, A A^T projector,
     projector_direct_dense.cpp:128-135; the engine runs it on transposed storage with the mirrored
