@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--m", type=int, default=0, help="rows per GPU (default: the configuration's)")
     ap.add_argument("--n", type=int, default=0)
+    ap.add_argument("--projector", choices=["default", "cgls"], default="default",
+                    help="dense configurations: 'cgls' selects the matrix-free CGLS projector (the reference's "
+                         "ProjectorCgls on a dense matrix, src/cpu/projector/projector_cgls.cpp) instead of the direct one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=150.0, help="wall-clock allowance for the CPU baseline")
     ap.add_argument("--cpu-full", action="store_true",
@@ -302,8 +305,11 @@ def main():
     if sparse:
         solver = pogs_amd.Solver(A, dtype=np.float32, device=local, profile=True, dist=dist_arg)
     else:
+        from pogs_amd import _lib as L
+
         solver = pogs_amd.Solver(A.data_ptr(), dtype=np.float32, shape=(m, n), device_ptr=True, device=local,
-                                 profile=True, dist=dist_arg)
+                                 profile=True, dist=dist_arg,
+                                 projector=L.PROJ_CGLS if args.projector == "cgls" else L.PROJ_DEFAULT)
     init_s = time.time() - t0
     f, g = functions(cfg, G, b, n)
 
@@ -373,7 +379,17 @@ def main():
                         % (name, m, n, cfg["lambd"], cfg["cfg_index"],
                            "" if world == 1 else "; row-sharded %dx%d" % (m * world, n)))
             projector = "direct (MFMA Gram + Cholesky)"
-        traffic, traffic_src = pmc_traffic(args.config, kernel_key) if (m, n) == (cfg["m"], cfg["n"]) else (None, None)
+            if args.projector == "cgls":
+                passes = st["matvecs"] / max(steps_total, 1)
+                kernel = "stream_rows_kernel (every pass over A of the loop: A p, A^T r, A x of CGLS and the residual passes)"
+                kernel_key = "stream_rows_kernel<float"
+                iteration = {"bytes_model": "passes over A per iteration x 4 m n bytes (matrix-free CGLS projector)",
+                             "passes_over_A_per_iteration": passes, "cg_per_iteration": st["cg_iters"] / max(steps_total, 1),
+                             "bytes": passes * 4.0 * m * n, "frac": passes * 4.0 * m * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}
+                projector = "CGLS on the dense matrix (matrix-free)"
+                workload += " [--projector cgls]"
+        traffic, traffic_src = (pmc_traffic(args.config, kernel_key) if (m, n) == (cfg["m"], cfg["n"]) and args.projector == "default"
+                                else (None, None))
         line = {
             "metric": "admm_iterations_per_sec_%s_fp32 (per-GPU shard, summed over GPUs)" % cfg["kind"],
             "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -632,6 +632,19 @@ def test_c3_solution_matches_compiled_reference():
     soa = lambda fv: {k: getattr(fv, k) for k in "habcde"}  # noqa: E731
     run = ob.ref_start(A.cpu().numpy(), soa(f), soa(gg), dtype=np.float32, verbose=1)
     r = _engine_solve(pogs, A, f, gg, {})
+    # BASELINE.json words configs[2] "(... CGLS projector)": the reference's dense entry point only
+    # has the direct projector (src/interface_c/pogs_c.cpp:19-20), the engine offers both -- the
+    # matrix-free CGLS projector on the same matrix has to land on the same solution
+    from pogs_amd import _lib as L
+
+    with pogs.Solver(A.data_ptr(), dtype=np.float32, shape=(m, n), device_ptr=True, projector=L.PROJ_CGLS) as s:
+        rc = s.solve(f, gg)
     del A
     ref = run.finish(timeout=900)
     _assert_matches_reference(r, ref, "c3 defaults")
+    xr = ref["x"].astype(np.float64)
+    rel_c = np.linalg.norm(rc["x"].astype(np.float64) - xr) / np.linalg.norm(xr)
+    print("c3 with the CGLS projector: iterations %d (reference %d), rel_x %.2e" % (rc["iterations"] + 1, ref["iterations"] + 1, rel_c))
+    assert rc["status"] == 0
+    assert abs(rc["iterations"] - ref["iterations"]) <= max(3, (ref["iterations"] + 1) // 10)
+    assert rel_c <= 3e-4       # inexact projection (tolerance 1e-2 sqrt(r), pogs.cpp:287-290), cf. the dense-CGLS tests
