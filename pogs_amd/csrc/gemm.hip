@@ -140,6 +140,11 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
     while (ti * (ti + 1) / 2 > p) --ti;
     while ((ti + 1) * (ti + 2) / 2 <= p) ++ti;
     tj = p - ti * (ti + 1) / 2;
+  } else if (g.ktri == 2) {
+    // the K range grows with the tile row: consecutive units (= one XCD's share, see above) walk
+    // down a tile column, so every XCD gets short and long rows alike
+    ti = tile % tm_;
+    tj = tile / tm_;
   } else {
     ti = tile / tn_;
     tj = tile % tn_;
