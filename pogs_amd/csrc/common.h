@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -109,5 +111,23 @@ struct DeviceInfo {
   int device = 0;
   int num_cu = 256;
 };
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) holds for the CURRENT device only.  One table per
+// kernel instantiation (a function-local static of the caller) remembers what each device has been
+// granted, so a process that drives several GPUs raises the limit on each of them.
+constexpr int kMaxDevices = 64;
+struct SmemGrants {
+  std::atomic<size_t> bytes[kMaxDevices];   // zero-initialised as a static: nothing above the 48 KB default yet
+};
+inline void ensure_dynamic_smem(const void *fn, size_t want, SmemGrants &g) {
+  if (want <= 48 * 1024) return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::atomic<size_t> &slot = g.bytes[dev & (kMaxDevices - 1)];
+  if (want <= slot.load(std::memory_order_acquire)) return;
+  POGS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(want)));
+  size_t cur = slot.load(std::memory_order_relaxed);
+  while (cur < want && !slot.compare_exchange_weak(cur, want)) {}
+}
 
 }  // namespace pogs_amd

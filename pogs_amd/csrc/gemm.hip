@@ -772,12 +772,8 @@ static void launch_gram_f16p_cfg(const GramF16PArgs &g, hipStream_t s) {
   const int nunits = tm * (tm + 1) / 2 * g.nslabs;
   if (nunits <= 0) return;
   constexpr int kLds = 2 * 2 * 2 * 4 * TILE * 16;
-  static bool attr_set = false;
-  if (!attr_set) {
-    POGS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_f16p_kernel<WM, WN, TA, TB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    attr_set = true;
-  }
+  static SmemGrants grants;
+  ensure_dynamic_smem(reinterpret_cast<const void *>(gram_f16p_kernel<WM, WN, TA, TB>), kLds, grants);
   const int grid = (nunits + kNumXcd - 1) / kNumXcd * kNumXcd;
   hipLaunchKernelGGL((gram_f16p_kernel<WM, WN, TA, TB>), dim3(grid), dim3(WM * WN * 64), kLds, s, g);
 }

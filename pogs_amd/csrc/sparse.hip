@@ -831,14 +831,14 @@ class SparseSolver final : public SolverBase {
       constexpr size_t smem = (static_cast<size_t>(SellCfg<T>::BW) + SellCfg<T>::RR) * sizeof(T);
       const int g1 = M.nrr * M.ncg;
       if (M.ncg == 1) {
-        static const bool once = allow_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, SQ, true, Op>), smem);
-        (void)once;
+        static SmemGrants grants;
+        ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, SQ, true, Op>), smem, grants);
         hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, true, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
                            x_nrm2, op, static_cast<T *>(nullptr), ctx_.spart.p);
         grid = g1;
       } else {
-        static const bool once = allow_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, SQ, false, Op>), smem);
-        (void)once;
+        static SmemGrants grants;
+        ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, SQ, false, Op>), smem, grants);
         hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, false, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
                            x_nrm2, op, M.part.p, ctx_.spart.p);
         grid = std::max(1, std::min((M.nrows + 255) / 256, spmv_grid_));
@@ -880,10 +880,6 @@ class SparseSolver final : public SolverBase {
   // sums of a y-sized quantity: add the other ranks' rows
   void reduce_y_scalars(double *slot, int count) {
     if (multi_) ctx_.dist.allreduce(slot, count, ctx_.stream);
-  }
-  static bool allow_smem(const void *fn, size_t bytes) {
-    POGS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
-    return true;
   }
 
   // MatrixSparse::Equil (matrix_sparse.cpp:158-242): Sinkhorn-Knopp on the squared

@@ -619,14 +619,8 @@ void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, 
   if (p.tpb == TPB_ && p.nv == NV_) {                                                           \
     constexpr int R_ = stream2_rows_c(ND, NV_);                                                 \
     const size_t lds = (ND > 1) ? static_cast<size_t>(a.n_pad) * sizeof(T) : 0;                 \
-    static std::atomic<size_t> attr_bytes{48 * 1024};   /* concurrent solvers share it */       \
-    if (lds > attr_bytes.load(std::memory_order_acquire)) {                                     \
-      POGS_HIP_CHECK(hipFuncSetAttribute(                                                       \
-          reinterpret_cast<const void *>(&stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>),   \
-          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));                  \
-      size_t cur = attr_bytes.load(std::memory_order_relaxed);                                  \
-      while (cur < lds && !attr_bytes.compare_exchange_weak(cur, lds)) {}                       \
-    }                                                                                           \
+    static SmemGrants grants;   /* per device; concurrent solvers share it */                   \
+    ensure_dynamic_smem(reinterpret_cast<const void *>(&stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>), lds, grants); \
     hipLaunchKernelGGL((stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>), dim3(grid),         \
                        dim3(TPB_), lds, s, a, op);                                              \
     return;                                                                                     \

@@ -182,6 +182,44 @@ def test_c4_solution_matches_openmp_oracle_at_full_size():
     assert abs(want["optval"] - ow) <= 5e-3 * ow
 
 
+def test_c4_solution_matches_compiled_reference_fixture():
+    """configs[3] at full size against the REFERENCE ITSELF: PogsSparseS (single-threaded on this path,
+    the better part of an hour in the build container) solved pogs_amd.synth.csr_lasso(2000000, 500000,
+    50, seed=4) once (tests/golden/make_c4_reference.py -> c4_reference.npz); the matrix is regenerated
+    here from the seed (numpy PCG64) and checked against the fixture's checksums."""
+    import os
+
+    from pogs_amd import synth
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "c4_reference.npz")
+    if not os.path.exists(path):
+        pytest.skip("c4_reference.npz not generated")
+    pogs = _pogs()
+    fx = np.load(path)
+    m, n, k = (int(v) for v in fx["shape"])
+    A, b, _ = synth.csr_lasso(m, n, k, seed=int(fx["seed"]), dtype=np.float32)
+    chk = np.array([float(A.nnz), float(A.data[::1009].astype(np.float64).sum()), float(A.indices[::1013].astype(np.float64).sum()),
+                    float(np.linalg.norm(b)), float(b[::101].sum())])
+    np.testing.assert_allclose(chk, fx["checksums"], rtol=1e-12, err_msg="the generator no longer reproduces the fixture's inputs")
+    lam = float(fx["lam"])
+    got = pogs.solve_lasso(A, b, lam, dtype=np.float32)
+    it, itr = got["iterations"] + 1, int(fx["iterations"]) + 1
+    x, xr = got["x"].astype(np.float64), fx["x"].astype(np.float64)
+    rel_x = np.linalg.norm(x - xr) / np.linalg.norm(xr)
+    obj = 0.5 * float(np.sum((A.astype(np.float64) @ x - b) ** 2)) + lam * float(np.abs(x).sum())
+    print("c4 vs the reference: iterations %d / %d, rel_x %.3e, objective at x %.6f / %.6f, optval %.4f / %.4f"
+          % (it, itr, rel_x, obj, float(fx["objective_at_x"]), got["optval"], float(fx["optval"])))
+    assert got["status"] == int(fx["status"]) == 0
+    assert abs(it - itr) <= max(3, itr // 10)
+    assert rel_x <= 1e-4
+    assert abs(obj - float(fx["objective_at_x"])) <= 1e-4 * float(fx["objective_at_x"])
+    yh = fx["y_head"].astype(np.float64)
+    assert np.linalg.norm(got["y"][:len(yh)].astype(np.float64) - yh) <= 2e-4 * np.linalg.norm(yh)
+    assert np.linalg.norm(got["y"].astype(np.float64)) == pytest.approx(float(fx["y_norm"]), rel=1e-4)
+    # (optval: the reference adds its 2.5e6 function values in fp32 -- 1e-3 off, see the oracle test above)
+    assert abs(got["optval"] - float(fx["optval"])) <= 5e-3 * float(fx["optval"])
+
+
 def test_c3_dense_logistic_200000x5000_kkt():
     """configs[2]: dense fp32 logistic regression 200000 x 5000, lambda = 0.01 (labels from a
     planted model with logit std 2)."""
