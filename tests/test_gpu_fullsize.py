@@ -470,6 +470,23 @@ def test_c2_solution_matches_compiled_reference():
     # (closed-form Sinkhorn-Knopp tail, fp16-split Gram) do not move the solution
     xd, xf = default["x"].astype(np.float64), full["x"].astype(np.float64)
     assert np.linalg.norm(xd - xf) <= 2e-5 * np.linalg.norm(xf)
+    # the same problem ROW-SHARDED over two ranks (both ranks on this GPU, joined
+    # by the in-process test communicator -- the decomposition, the packed all-reduce per iteration and
+    # the lower-triangle Gram exchange at full size): same solution, same iteration count
+    from helpers import run_row_sharded
+
+    del A
+    res, bounds = run_row_sharded(pogs, A_host, f, gg, 2, np.float32)
+    for rk, out in enumerate(res):
+        assert out["status"] == 0
+        assert abs(int(out["iterations"]) + 1 - it64) <= max(3, it64 // 10), ("sharded", out["iterations"])
+        xs = out["x"].astype(np.float64)
+        assert np.linalg.norm(xs - x64) <= 1e-4 * np.linalg.norm(x64)
+        lo, hi = int(bounds[rk]), int(bounds[rk + 1])
+        assert np.linalg.norm(out["y"].astype(np.float64) - default["y"][lo:hi]) <= 2e-4 * np.linalg.norm(default["y"][lo:hi])
+    assert np.array_equal(res[0]["x"], res[1]["x"])
+    print("c2 row-sharded x2: iterations %d, rel_x vs fp64 reference %.2e" % (
+        res[0]["iterations"] + 1, np.linalg.norm(res[0]["x"].astype(np.float64) - x64) / np.linalg.norm(x64)))
     if os.environ.get("POGS_AMD_LIVE_REF") == "1":
         import oracle_binding as ob
 
