@@ -220,6 +220,65 @@ def test_c4_solution_matches_compiled_reference_fixture():
     assert abs(got["optval"] - float(fx["optval"])) <= 5e-3 * float(fx["optval"])
 
 
+def test_c5_shape_eight_row_shards_on_one_gpu():
+    """configs[4] (800000 x 10000 fp32, eight row shards of 100000) with all eight ranks on THIS GPU:
+    threads + the in-process test communicator instead of eight processes + RCCL, device-resident
+    shards exactly as bench.py hands them over.  Checks what can be checked without a node: the
+    eight-rank decomposition at the real shape (rank arithmetic, packed all-reduce of 2 x 10000 + 6
+    doubles per iteration, lower-triangle Gram exchange) reproduces the unsharded solve of the same
+    32 GB matrix -- same iteration count, x within the fp32 tolerance, y shard by shard."""
+    import threading
+
+    torch = _torch()
+    pogs = _pogs()
+    free, _total = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip("needs ~130 GB of HBM")
+    os.environ["POGS_AMD_TEST_TRANSPORT"] = "1"
+    world, ml, n = 8, 100000, 10000
+    m = world * ml
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(55)
+    A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float32)
+    xt = torch.randn(n, generator=g, device=dev) * (torch.rand(n, generator=g, device=dev) < 0.1)
+    b = (A @ xt + 0.1 * torch.randn(m, generator=g, device=dev)).double().cpu().numpy()
+    torch.cuda.synchronize()
+    f, gg = pogs.graph.lasso_functions(b, LAM, n)
+    with pogs.Solver(A.data_ptr(), dtype=np.float32, shape=(m, n), device_ptr=True) as s:
+        one = s.solve(f, gg)
+    assert one["status"] == 0
+    uid = (b"POGSLOCAL:" + os.urandom(8).hex().encode()).ljust(128, b"\0")
+    results, errors = [None] * world, []
+
+    def work(r):
+        try:
+            lo, hi = r * ml, (r + 1) * ml
+            with pogs.Solver(A[lo:hi].data_ptr(), dtype=np.float32, shape=(ml, n), device_ptr=True, dist=(r, world, m, uid)) as s:
+                results[r] = s.solve(f.slice(lo, hi), gg)
+                results[r]["collectives"] = s.stats()["collectives"]
+        except Exception as e:  # pragma: no cover - surfaced below
+            errors.append((r, e))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(900)
+    assert not errors, errors
+    x1 = one["x"].astype(np.float64)
+    for r, out in enumerate(results):
+        assert out is not None and out["status"] == 0
+        assert abs(int(out["iterations"]) - int(one["iterations"])) <= max(3, one["iterations"] // 10)
+        assert np.array_equal(out["x"], results[0]["x"])                       # replicated state, identical decisions
+        lo, hi = r * ml, (r + 1) * ml
+        assert np.linalg.norm(out["y"].astype(np.float64) - one["y"][lo:hi]) <= 2e-4 * np.linalg.norm(one["y"][lo:hi])
+    rel = np.linalg.norm(results[0]["x"].astype(np.float64) - x1) / np.linalg.norm(x1)
+    print("c5 shape, 8 in-process ranks: iterations %d (unsharded %d), rel_x %.2e, all-reduce calls per rank %d"
+          % (results[0]["iterations"] + 1, one["iterations"] + 1, rel, results[0]["collectives"]))
+    assert rel <= 1e-4
+
+
 def test_c3_dense_logistic_200000x5000_kkt():
     """configs[2]: dense fp32 logistic regression 200000 x 5000, lambda = 0.01 (labels from a
     planted model with logit std 2)."""
