@@ -8,6 +8,8 @@ Tolerances (SURVEY.md section 8(c) "parity definition"):
     iteration count within +-10% (+-3); fp64 small problems follow the oracle's
     trajectory, so there the bar is 1e-6 and the same iteration count +-2.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -42,6 +44,12 @@ def _relerr_same_iteration(got, want, solve_engine, solve_oracle):
     w2 = want if wi < gi else solve_oracle(k)
     assert int(g2["iterations"]) == int(w2["iterations"]) == k - 1
     return relerr(g2["x"], w2["x"])
+
+
+def _one_pass_forced_off():
+    """The suite is also run with POGS_AMD_FUSED=0 and with POGS_AMD_XL_LIMIT=<n> as regression sweeps
+    over the three-pass and the windowed code paths; assertions ABOUT the one-pass iteration step aside."""
+    return os.environ.get("POGS_AMD_FUSED") == "0" or bool(os.environ.get("POGS_AMD_XL_LIMIT"))
 
 
 def _xtol32(got_iters, want_iters, loose=3e-4):
@@ -573,6 +581,8 @@ def test_512_thread_plan_one_pass_iteration(dtype, shape, monkeypatch):
     tall fp32.  The oracle needs a minute at these sizes, so the one-pass solve is held against
     the two-pass path of the same engine (POGS_AMD_FUSED=0, itself pinned to the oracle at small
     sizes) and the operator / projection against numpy."""
+    if _one_pass_forced_off():
+        pytest.skip("one-pass iteration switched off by the environment")
     pogs = _pogs()
     from pogs_amd import synth
 
@@ -674,6 +684,8 @@ def test_row_sharded_engine_matches_single_rank(dtype, world):
     # ONE all-reduce per iteration (a second one only when the speculation
     # missed and the iteration needed its own pass), + the objective's at the end
     lc = res[0]["loop_collectives"]
+    if _one_pass_forced_off():
+        return     # (regression sweeps with POGS_AMD_FUSED=0 / POGS_AMD_XL_LIMIT: the three-pass iteration exchanges more)
     assert lc["hits"] > lc["misses"]
     assert lc["calls"] <= lc["iterations"] + lc["misses"] + 2, lc
     for r, out in enumerate(res):
