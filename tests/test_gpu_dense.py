@@ -984,3 +984,41 @@ def test_fp16_split_gram_is_as_exact_as_the_fp32_product(shape, monkeypatch):
     assert rb["status"] == rf["status"] == 0
     assert abs(int(rb["iterations"]) - int(rf["iterations"])) <= max(3, rf["iterations"] // 10)
     assert relerr(rb["x"], rf["x"]) < _xtol32(rb["iterations"], rf["iterations"], loose=5e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(9))
+def test_random_mixed_function_problems_follow_the_oracle(seed):
+    """Randomised problems with a DIFFERENT function type per element of f and g (all 16 `h`, random
+    a, b, c >= 0, d, e >= 0 -- FunctionObj, prox_lib.h:42-70), random shapes either side of m = n, dense
+    and CSR, 60 iterations with the stopping rule out of the way: the engine's iterate must follow the
+    oracle's (fp64: 1e-8; the per-element general prox path, not the uniform-h fast paths the solve_*
+    families take)."""
+    import scipy.sparse as sp
+
+    pogs = _pogs()
+    G = pogs.graph
+    rng = np.random.default_rng(9000 + seed)
+    m, n = int(rng.integers(40, 400)), int(rng.integers(30, 300))
+    A = rng.standard_normal((m, n))
+    sparse = seed % 3 == 2
+    if sparse:
+        A = sp.csr_matrix(A * (rng.random((m, n)) < 0.15))
+
+    def functions(k):
+        return G.FunctionVector(k, h=rng.integers(0, 16, k), a=rng.choice([-1.0, 1.0], k) * rng.uniform(0.5, 2.0, k),
+                                b=rng.standard_normal(k), c=rng.uniform(0.1, 2.0, k) * (rng.random(k) < 0.9),
+                                d=0.3 * rng.standard_normal(k), e=rng.uniform(0.0, 1.0, k) * (rng.random(k) < 0.5))
+
+    f, g = functions(m), functions(n)
+    kw = dict(abs_tol=1e-12, rel_tol=1e-12, max_iter=60)
+    got = G._solve_graph_form(A, f, g, kw["abs_tol"], kw["rel_tol"], kw["max_iter"], 0, 1.0, dtype=np.float64)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float64, **kw)
+    assert got["status"] == want["status"]
+    assert got["iterations"] == want["iterations"]
+    for key in ("x", "y", "l"):
+        a, b = np.asarray(got[key], np.float64), np.asarray(want[key], np.float64)
+        assert np.array_equal(np.isfinite(a), np.isfinite(b)), key
+        fin = np.isfinite(b)
+        if fin.any():
+            assert np.linalg.norm(a[fin] - b[fin]) <= 1e-8 * max(np.linalg.norm(b[fin]), 1.0), (key, seed, m, n, sparse)
