@@ -883,12 +883,16 @@ class DenseSolver final : public SolverBase {
         if (presplit) {
           // four K ranges at a time are split into two fp16 images in operand order (168 MB at C2,
           // 60 us), which the product kernel copies straight into LDS (gemm.h)
-          // units of up to four 1024-row chains (summed in registers), four units per tile and
-          // launch into the four slabs: 16384 rows per round where the K dimension is that long
-          int chains = 1;
-          while (chains < 4 && kdim >= 4 * kRows * chains * 2) chains *= 2;
+          // four units per tile and launch into the four slabs; the K dimension is cut into equal units
+          // of at most ~12800 rows (C2: 2 launches x 4 units of 12512 rows): long units pay the
+          // accumulator read-add-write, the prologue and the first-copy latency less often, equal ones
+          // leave no mostly-empty unit at the end -- measured at C2, rows per unit -> Gram phase:
+          // 4096 -> 33.9 ms, 6272 -> 31.8, 8352 -> 31.4, 12512 -> 30.9, 25024 -> 31.0 (scripts/gram_urows_probe.sh)
+          constexpr int kUnitCap = 12800;
+          const int launches = (kdim + 4 * kUnitCap - 1) / (4 * kUnitCap);
+          int chains = 0;   // (env only)
           // 256 x 256 workgroup tiles (half the operand bytes per product of the 128 tile; one
-          // accumulator set, i.e. a unit is ONE MFMA chain of up to 4096 rows) where the Gram matrix
+          // accumulator set, i.e. a unit is ONE MFMA chain) where the Gram matrix
           // has enough of them to fill the chip; measured at C2 31.8 against 33.9 ms of kernel time,
           // no difference at n = 5000 (C3).  Chain length: 1024 .. 16384 rows give the same 106
           // iterations at C2 and x within 6e-7 of each other (scripts/gram_chain_probe.py), the
@@ -896,7 +900,9 @@ class DenseSolver final : public SolverBase {
           int tile = k_ >= 8192 ? 256 : 128;
           if (const char *ev = std::getenv("POGS_AMD_GRAM_TILE")) tile = std::atoi(ev) == 256 ? 256 : 128;   // tuning aid
           if (const char *ev = std::getenv("POGS_AMD_GRAM_CHAINS")) chains = std::max(1, std::min(16, std::atoi(ev)));
-          const int urows = kRows * chains;
+          int urows = static_cast<int>(round_up(static_cast<size_t>((kdim + 4 * launches - 1) / (4 * launches)), 32));
+          if (chains > 0) urows = kRows * chains;
+          if (const char *ev = std::getenv("POGS_AMD_GRAM_UROWS")) urows = static_cast<int>(round_up(static_cast<size_t>(std::max(32, std::atoi(ev))), 32));   // tuning aid
           const int nunits = (kdim + urows - 1) / urows;
           const int npad = static_cast<int>(round_up(k_, tile));
           DevBuf<unsigned char> img(static_cast<size_t>(2) * (4 * urows) * npad * 2);
