@@ -130,7 +130,7 @@ inline StreamPlan make_stream_plan(int n_pad, int num_cu) {
       p.tpb = 256; p.nv = nv; p.grid_dot = num_cu * 2;
       // at nv = 5 the one-pass iteration kernel takes two rows per step (stream2_rows_c), needs 167
       // VGPRs and fits three workgroups per CU: a slow row functor (logistic prox) hides better
-      p.grid_max = num_cu * (nv == 5 ? 3 : 2);
+      p.grid_max = num_cu * ((nv == 5 || nv <= 2) ? 3 : 2);   // (nv <= 2: 8 rows per step, 158 VGPRs; 500000 x 2000: 0.694 -> 0.657 ms)
       p.ok = true;
       return p;
     }
