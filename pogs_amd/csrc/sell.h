@@ -6,10 +6,10 @@
 // request per non-zero and that request rate, not the bytes, bounds a CSR kernel (~1 TB/s at
 // C4).  So the gather is served from LDS:
 //
-//   * the matrix is cut into TILES of RR rows x BW columns (fp32: <= 12288 x 24576).  A workgroup
+//   * the matrix is cut into TILES of RR rows x BW columns (fp32: <= 16384 x 18432).  A workgroup
 //     (512 threads, one per CU) owns one row range: it keeps the RR row sums in LDS, walks the
 //     column blocks of its column group, and for each tile puts that block's slice of x into LDS
-//     (96 KB) and gathers from there.  The row sums never leave LDS between column blocks: no
+//     (72 KB) and gathers from there.  The row sums never leave LDS between column blocks: no
 //     per-(block, row) partial sums travel through HBM.  (Only when a matrix has too few row
 //     ranges to fill the chip are the column blocks split into a few column GROUPS, whose partial
 //     row sums -- groups x rows values, not blocks x rows -- a second kernel adds in group order.)
@@ -45,7 +45,7 @@ constexpr int kSellUB = 4;              // elements per lane and batch (a tile's
 constexpr int kSellNB = 8;              // batches in flight per wavefront (3 x 16- / 8-byte loads each)
 constexpr int kSellLmax = 32;           // sort classes: row lengths 1..32 each, longer rows together
 template <typename T> struct SellCfg;
-template <> struct SellCfg<float> { static constexpr int BW = 24576, RR = 12288; };   // 96 KB + 48 KB of LDS
+template <> struct SellCfg<float> { static constexpr int BW = 18432, RR = 16384; };   // 72 KB + 64 KB of LDS (measured at C4 against 24576 x 12288, 20480 x 16384, 22528 x 16384, 14336 x 16384: 165 / 155 / 163 / 155 us, this one 152; 16384 x 16384 -- every x slice on a 64 KB boundary -- 237)
 template <> struct SellCfg<double> { static constexpr int BW = 12288, RR = 6144; };   // 96 KB + 48 KB
 constexpr unsigned short kSellNoRow = 0xFFFF;
 constexpr int kSellOffBits = 23;        // plan: stream offset of a row inside its tile (9 bits of stream above it)

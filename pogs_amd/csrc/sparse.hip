@@ -723,22 +723,28 @@ class SparseSolver final : public SolverBase {
     const long long want = static_cast<long long>(M.nrows) * ncb / (2LL * ctx_.num_cu);
     int rr_rows = static_cast<int>(round_up(static_cast<size_t>(std::max<long long>(512, std::min<long long>(RRMAX, want))), 64));
     rr_rows = std::min(rr_rows, RRMAX);
-    const int nrr = (M.nrows + rr_rows - 1) / rr_rows;
-    const long long ntiles = static_cast<long long>(nrr) * ncb;
-    const long long nq = ntiles * rr_rows;
-    if (ntiles >= (1LL << 30) || nq >= (1LL << 31)) return;
     // column groups: the count that fills whole rounds of workgroups (one per CU) best, with the
-    // column blocks split evenly; ties go to fewer groups (fewer partial sums)
+    // column blocks split evenly; ties go to fewer groups (fewer partial sums).  How well the launch
+    // fills its rounds decides the SpMV time beyond its bytes -- C4, BW x RR -> workgroups -> SpMV:
+    // 18432 x 16384 -> 246 (A) / 248 (A^T), one round each -> 152 us; 24576 x 12288 -> 489, two
+    // rounds -> 165 us; 22528 x 14336 -> 420, 0.82 of two rounds -> 225 us.  (A joint search over
+    // the row-range height and the group count by this fill model alone picked many small groups
+    // -- 17 rounds of 28 groups -- and was slower, 250 us: partial sums and per-tile costs are not
+    // in the model.  Left at the LDS-limit height.)
     int ncg = 1;
     double best = -1;
     for (int g = 1; g <= std::min(ncb, 32); ++g) {
-      const long long nwg = static_cast<long long>(nrr) * g;
+      const long long nwg = static_cast<long long>((M.nrows + rr_rows - 1) / rr_rows) * g;
       const long long rounds = (nwg + ctx_.num_cu - 1) / ctx_.num_cu;
       const double fill = static_cast<double>(nwg) / static_cast<double>(rounds * ctx_.num_cu);
       const double even = (static_cast<double>(ncb) / g) / static_cast<double>((ncb + g - 1) / g);
       const double eff = fill * even;
       if (eff > best + 1e-9) { best = eff; ncg = g; }
     }
+    const int nrr = (M.nrows + rr_rows - 1) / rr_rows;
+    const long long ntiles = static_cast<long long>(nrr) * ncb;
+    const long long nq = ntiles * rr_rows;
+    if (ntiles >= (1LL << 30) || nq >= (1LL << 31)) return;
     M.rr_rows = rr_rows; M.nrr = nrr; M.ncb = ncb; M.ncg = ncg;
     const SellDims D = M.sdims();
     M.scnt.alloc(nq); M.ssoff.alloc(nq);
