@@ -741,6 +741,43 @@ class SparseSolver final : public SolverBase {
       const double eff = fill * even;
       if (eff > best + 1e-9) { best = eff; ncg = g; }
     }
+    // Second look with a byte model of ONE workgroup's path (the launch takes rounds x that):
+    //   matrix bytes rr * blocks * (nnz per row and block) * 8  +  x slices blocks * BW * s * 0.15 (they
+    //   mostly hit L2)  +  partial sums rr * 8 (written, then read by reduce_parts) when there are groups.
+    // Candidates are built to fill k rounds of ~250 workgroups exactly: for g groups, nrr = k * 250 / g
+    // row ranges of rows / nrr rows each (shorter than the LDS limit).  Calibrated on C4 (forced
+    // configurations, scripts/sell_cfg_probe.sh: 8128 rows x 1 group +1.9 %, 12288 x 3 +9 %, A^T 8064 x 4
+    // +4 %, 16384 x 16 +3 % against the 16384 x 2 / x 8 the rule above picks there); a candidate replaces
+    // that choice only when the model sees more than 5 % in it -- matrices whose row count leaves the
+    // LDS-limit height with many groups (1.4e6 rows: 14 groups, 1204 workgroups; 4157 GB/s).
+    {
+      const double d = static_cast<double>(M.nnz) / static_cast<double>(M.nrows) / ncb;
+      auto path_bytes = [&](int rr, int g) {
+        const long long nwg = static_cast<long long>((M.nrows + rr - 1) / rr) * g;
+        const long long rounds = (nwg + ctx_.num_cu - 1) / ctx_.num_cu;
+        const double cbg = static_cast<double>((ncb + g - 1) / g);
+        return static_cast<double>(rounds) * (rr * cbg * d * 8.0 + cbg * BW * sizeof(T) * 0.15 + (g > 1 ? rr * 8.0 : 0.0));
+      };
+      const double base = path_bytes(rr_rows, ncg);
+      double best_c = base * 0.95;
+      const int rr_hi = rr_rows, cap = std::max(1, ctx_.num_cu - 6);
+      for (int g = 1; g <= std::min(ncb, 32); ++g)
+        for (int k = 1; k <= 8; ++k) {
+          const long long nrr_t = static_cast<long long>(k) * cap / g;
+          if (nrr_t < 1) continue;
+          const int rr = std::max(512, static_cast<int>(round_up(static_cast<size_t>((M.nrows + nrr_t - 1) / nrr_t), 64)));
+          if (rr > rr_hi) continue;
+          const double c = path_bytes(rr, g);
+          if (c < best_c * (1 - 1e-3)) { best_c = c; rr_rows = rr; ncg = g; }
+        }
+    }
+    {   // tuning aids: POGS_AMD_SELL_RR_TALL / _NCG_TALL for the copy with more rows than columns, _WIDE for the other
+      const bool tall = M.nrows >= M.ncols;
+      if (const char *ev = std::getenv(tall ? "POGS_AMD_SELL_RR_TALL" : "POGS_AMD_SELL_RR_WIDE"))
+        rr_rows = std::min(RRMAX, static_cast<int>(round_up(static_cast<size_t>(std::max(64, std::atoi(ev))), 64)));
+      if (const char *ev = std::getenv(tall ? "POGS_AMD_SELL_NCG_TALL" : "POGS_AMD_SELL_NCG_WIDE"))
+        ncg = std::max(1, std::min(ncb, std::atoi(ev)));
+    }
     const int nrr = (M.nrows + rr_rows - 1) / rr_rows;
     const long long ntiles = static_cast<long long>(nrr) * ncb;
     const long long nq = ntiles * rr_rows;
