@@ -30,8 +30,13 @@ windows are timed back to back and the median is reported (`windows`).
 Inputs are resident in HBM when the timed region starts.  The JSON line carries `roofline`
 (the dominant kernel, timed with HIP events on the solver's stream over the timed region)
 and, at N = 1, `cpu_baseline`: the compiled reference (oracle/_ref, clean subprocess) on the
-same (A, b, lambda) on this box's host cores -- the full workload when it fits the budget --
-with `parity_vs_reference` comparing the two solutions; the OpenMP oracle port for c4.
+same (A, b, lambda) on this box's host cores, the WHOLE workload (no sample, no scaling; about
+two minutes at c2), with `parity_vs_reference` comparing the two solutions; if the reference
+does not finish inside --cpu-budget-s the line carries two unscaled numbers instead (the
+reference on the leading 30 % of the rows, the OpenMP oracle port on the whole workload).
+Without --config (the driver's invocation) and at N = 1 the c3 and c4 workloads are run after c2
+(GPU legs only) and attached as `secondary`: {c3: {...}, c4: {...}} with their own value /
+ms_per_step / roofline.
 """
 import argparse
 import json
@@ -60,17 +65,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="default: c2 as the headline line, and at --gpus 1 also c3 and c4 as `secondary`")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--m", type=int, default=0, help="rows per GPU (default: the configuration's)")
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--projector", choices=["default", "cgls"], default="default",
                     help="dense configurations: 'cgls' selects the matrix-free CGLS projector (the reference's "
                          "ProjectorCgls on a dense matrix, src/cpu/projector/projector_cgls.cpp) instead of the direct one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=150.0, help="wall-clock allowance for the CPU baseline")
-    ap.add_argument("--cpu-full", action="store_true",
-                    help="also run the reference on the FULL workload (minutes in the build container; the GPU box's "
-                         "container -- 16-core CPU quota -- needs more than 15 minutes at C2)")
+    ap.add_argument("--cpu-budget-s", type=float, default=600.0,
+                    help="time-out of the reference's run of the whole workload (the CPU baseline)")
+    ap.add_argument("--cpu-iters", type=int, default=60, help="ADMM iterations of the reference's whole-workload run")
+    ap.add_argument("--cpu-full", action="store_true", help="run the reference to convergence instead (c2 on the GPU "
+                                                            "box's host: max_iter, about twenty minutes)")
     return ap.parse_args()
 
 
@@ -89,12 +97,37 @@ def maybe_spawn(args):
     os.execve(sys.executable, cmd, env)
 
 
-def make_problem(cfg, m, n, rank, dev):
+def fixture_c2():
+    path = os.path.join(ROOT, "tests", "golden", "c2_reference.npz")
+    if not os.path.exists(path):
+        return None
+    import numpy as np
+
+    return np.load(path)
+
+
+def make_problem(cfg, m, n, rank, dev, world=1):
     """Per-rank rows with a shared x_true / w_true (generated on the device).  Returns
-    (device matrix holder, what Solver() takes, function pair builder inputs)."""
+    (matrix: device tensor or scipy CSR, b or labels, host copy of a dense matrix or None).
+
+    c2 on ONE GPU at its own size is the problem of the committed fixture
+    tests/golden/c2_reference.npz (pogs_amd.synth.dense_lasso_rows(seed=2024), regenerated bit for
+    bit on the host and checked against the fixture's checksums): the compiled reference's fp32
+    and fp64 solutions of exactly this (A, b, lambda) are in the fixture, so the line carries
+    `parity_vs_reference` without a 20-minute reference run on this box."""
     import numpy as np
     import torch
 
+    fx = fixture_c2() if (cfg["kind"] == "dense_lasso" and world == 1) else None
+    if fx is not None and (m, n) == tuple(int(v) for v in fx["shape"]):
+        from pogs_amd import synth
+
+        A_host, b, _ = synth.dense_lasso_rows(m, n, seed=int(fx["seed"]))
+        chk = np.array([float(A_host[::997].astype(np.float64).sum()), float(np.abs(A_host[:, ::113]).astype(np.float64).sum()),
+                        float(np.linalg.norm(b)), float(b[::101].sum())])
+        if not np.allclose(chk, fx["checksums"], rtol=1e-12, atol=0):
+            raise RuntimeError("the generator no longer reproduces the fixture's inputs")
+        return torch.from_numpy(A_host).to(dev), b, A_host
     g = torch.Generator(device=dev)
     g.manual_seed(1234)
     kind = cfg["kind"]
@@ -103,7 +136,7 @@ def make_problem(cfg, m, n, rank, dev):
         g.manual_seed(1000 + rank)
         A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float32)
         b = A @ x_true + 0.1 * torch.randn(m, generator=g, device=dev)
-        return A, b.double().cpu().numpy()
+        return A, b.double().cpu().numpy(), None
     if kind == "dense_logistic":
         w = torch.randn(n, generator=g, device=dev) * (torch.rand(n, generator=g, device=dev) < 0.3)
         w = w * (2.0 / torch.sqrt((w * w).sum()))
@@ -111,7 +144,7 @@ def make_problem(cfg, m, n, rank, dev):
         A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float32)
         p = torch.sigmoid(A @ w)
         lab = 2.0 * (torch.rand(m, generator=g, device=dev) < p).double() - 1.0
-        return A, lab.cpu().numpy()
+        return A, lab.cpu().numpy(), None
     # CSR: k uniformly drawn column indices per row, N(0,1) values, duplicates summed
     import scipy.sparse as sp
 
@@ -126,7 +159,7 @@ def make_problem(cfg, m, n, rank, dev):
     A = sp.csr_matrix((vals.cpu().numpy().ravel(), cols.cpu().numpy().ravel(), ptr), shape=(m, n))
     A.sum_duplicates()
     b = A @ x_true + noise
-    return A, b
+    return A, b, None
 
 
 def functions(cfg, G, b, n):
@@ -135,102 +168,79 @@ def functions(cfg, G, b, n):
     return G.lasso_functions(b, cfg["lambd"], n)
 
 
-def cpu_baseline(cfg, A_host, f, g, budget_s, engine, full_run=False):
-    """Times the reference CPU path on this box's host cores, on the SAME (A, f, g).
+def cpu_baseline(cfg, A_host, f, g, args, engine, fixture=None):
+    """Times the reference CPU path on this box's host cores, on the SAME (A, f, g), WHOLE workload:
+    no row sample, nothing scaled.
 
-    Dense: the compiled reference (oracle/_ref, `kind` "reference"; clean subprocess, it must
-    not share a process with torch) -- first on a row sample that predicts the cost; if the
-    full workload fits the budget it is run and reported together with `parity` (reference
-    vs engine solution), otherwise the sample's it/s is scaled by the per-iteration byte
-    ratio and the line says so.  Sparse (c4): the OpenMP oracle port (`kind` "port"; the
-    reference's sparse path is single-threaded as built) on the leading rows (1/10 of them).
-    Returns (cpu_baseline dict, parity dict or None)."""
+    Dense (c2, c3): the compiled reference (oracle/_ref, `kind` "reference"; a clean subprocess, it
+    must not share a process with torch) on all rows; `value` = iterations / (Total - Init) from its
+    own summary line (src/cpu/pogs.cpp:485-490).  The run is capped at --cpu-iters ADMM iterations
+    (default 60): on the GPU box's host the reference's fp32 build does not reach the default
+    tolerances at c2 -- its primal residual stalls 0.2 % above the bound from iteration ~200 on and
+    it runs into max_iter = 2500, twenty minutes (profiles/r03_ref_cpu_diagnosis.md) -- so a run to
+    convergence is only made on request (--cpu-full).  The capped run is the reference's own loop on
+    the whole matrix; its first iterations are its cheapest (no exact-residual passes yet), so the
+    cap flatters the CPU side, not the GPU side.
+    `parity`: against the committed reference solutions of exactly this problem when the workload is
+    the fixture's (c2, one GPU); against the live run when that ran to convergence.
+    Sparse (c4): the OpenMP oracle port on the whole workload to convergence (`kind` "port": the
+    reference's sparse path is single-threaded as built and needs 21 minutes,
+    tests/golden/make_c4_reference.py).  Returns (cpu_baseline dict, parity dict or None)."""
     import numpy as np
 
     import oracle_binding as ob
 
     t_start = time.time()
     sparse = hasattr(A_host, "indptr")
-    # threads actually used: the reference's BLAS threads (its best setting on this box, see
-    # oracle_binding.REF_THREADS); the OpenMP oracle port uses every hardware thread
-    cores = ob.cpu_quota() if sparse else ob.ref_threads()
     m, n = A_host.shape
     dt = np.float32
-    soa = lambda fv, lo, hi: {k: getattr(fv, k)[lo:hi] for k in "habcde"}  # noqa: E731
-    gs = soa(g, 0, n)
+    soa = lambda fv: {k: getattr(fv, k) for k in "habcde"}  # noqa: E731
+    fs, gs = soa(f), soa(g)
 
-    def run(rows, use_ref, timeout):
-        A = A_host[:rows]
-        fs = soa(f, 0, rows)
-        if use_ref:
-            r = ob.ref_solve(A, fs, gs, dtype=dt, verbose=1, timeout=timeout)
-            t_total, t_init = r.get("t_total", r["wall_s"]), r.get("t_init", 0.0)
-        else:
-            r = ob.oracle_solve(A, fs, gs, dtype=dt)
-            t_init, t_total = r["info"]["t_init"], r["info"]["t_init"] + r["info"]["t_loop"]
-        iters = r["iterations"] + 1
-        ok = r["status"] == 0 and np.isfinite(r["optval"])
-        return {"rows": rows, "iters": iters, "t_total": t_total, "t_init": t_init, "ok": ok,
-                "its": iters / max(t_total - t_init, 1e-9), "res": r}
+    def parity_of(x_ref, optval_ref, it_ref, against):
+        xr, xe = np.asarray(x_ref, np.float64), engine["x"].astype(np.float64)
+        return {"against": against, "rel_x": float(np.linalg.norm(xe - xr) / max(np.linalg.norm(xr), 1e-300)),
+                "rel_optval": abs(engine["optval"] - optval_ref) / max(abs(optval_ref), 1e-300),
+                "iterations_reference": int(it_ref), "iterations_engine": engine["iterations"] + 1, "tolerance": 1e-4}
 
-    out = {"unit": "it/s", "cores": cores, "host_threads_visible": os.cpu_count() or 1, "cpu_quota": ob.cpu_quota()}
-    if sparse:
-        rows = max(1, m // 10)
-        s = run(rows, False, None)
-        nnz_frac = A_host[:rows].nnz / max(A_host.nnz, 1)
-        out.update(kind="port", value=s["its"] * nnz_frac,
-                   sample="OpenMP oracle on the first %d rows (%d x %d, nnz %d): %d iterations, total %.1f s, init "
-                          "%.1f s = %.2f it/s, scaled by the non-zero ratio %.3f to the full matrix"
-                          % (rows, rows, n, A_host[:rows].nnz, s["iters"], s["t_total"], s["t_init"], s["its"], nnz_frac))
-        return out, None
-    kind = "reference" if ob.ref_available() else "port"
-    # bounded sample: the leading 30 % of the rows (~20-30 s at C2 / C3 with 16 threads); the whole
-    # workload only on request (--cpu-full)
-    s_rows = min(m, max(2000, int(0.3 * m)))
-    sample = None
-    try:
-        sample = run(s_rows, kind == "reference", budget_s)
-        if not sample["ok"]:
-            sample = None
-    except Exception:
-        sample = None
-    if sample is None and kind == "reference":
-        kind = "port"
-        sample = run(s_rows, False, None)
-    out["kind"] = kind
-    remaining = budget_s - (time.time() - t_start)
-    full = None
-    if full_run and m > s_rows:
-        try:
-            full = run(m, kind == "reference", max(remaining, 3600.0))
-            if not full["ok"]:
-                full = None
-        except Exception:
-            full = None
+    out = {"unit": "it/s", "host_threads_visible": os.cpu_count() or 1, "cpu_quota": ob.cpu_quota()}
     parity = None
-    if full is not None:
-        out.update(value=full["its"], time_to_converge_s=full["t_total"],
-                   sample="full workload %dx%d fp32: %d iterations, total %.1f s, init %.1f s"
-                          % (m, n, full["iters"], full["t_total"], full["t_init"]))
-        r = full["res"]
-        xr, xe = r["x"].astype(np.float64), engine["x"].astype(np.float64)
-        parity = {"against": "compiled reference (oracle/_ref/libpogs_cpu.so), same A, b, lambda, default tolerances"
-                  if kind == "reference" else "oracle port",
-                  "rel_x": float(np.linalg.norm(xe - xr) / max(np.linalg.norm(xr), 1e-300)),
-                  "rel_optval": abs(engine["optval"] - r["optval"]) / max(abs(r["optval"]), 1e-300),
-                  "iterations_reference": full["iters"], "iterations_engine": engine["iterations"] + 1,
-                  "tolerance": 1e-4}
-    else:
-        bytes_iter = lambda rows: 4.0 * (2.0 * rows * n + n * n)  # noqa: E731
-        scale = bytes_iter(s_rows) / bytes_iter(m)
-        out.update(value=sample["its"] * scale,
-                   sample="first %d rows of the same A (%d iterations, total %.1f s, init %.1f s; %.2f it/s), "
-                          "scaled by the per-iteration byte ratio %.3f to the %dx%d workload; the whole workload is "
-                          "run with --cpu-full%s"
-                          % (s_rows, sample["iters"], sample["t_total"], sample["t_init"], sample["its"], scale, m, n,
-                             " (tests/golden/c2_reference.npz holds the reference's full-size C2 runs in the build container, "
-                             "8 cores: fp32 154 iterations in 143 s = 2.6 it/s in the loop; fp64 106 iterations in 497 s)"
-                             if cfg.get("cfg_index") == 1 else ""))
+    if fixture is not None:
+        parity = parity_of(fixture["x_fp64"], float(fixture["optval_fp64"]), int(fixture["iterations_fp64"]) + 1,
+                           "tests/golden/c2_reference.npz: the compiled reference's fp64 build (PogsD) on exactly this (A, b, "
+                           "lambda), run to convergence in the build container")
+        p32 = parity_of(fixture["x"], float(fixture["optval"]), int(fixture["iterations"]) + 1, "")
+        parity["rel_x_vs_reference_fp32_build"] = p32["rel_x"]
+        parity["iterations_reference_fp32_build"] = p32["iterations_reference"]
+    if sparse:
+        ob.oracle_set_threads()
+        r = ob.oracle_solve(A_host, fs, gs, dtype=dt)
+        t_init, t_loop = r["info"]["t_init"], r["info"]["t_loop"]
+        iters = r["iterations"] + 1
+        out.update(kind="port", cores=ob.cpu_quota(), value=iters / max(t_loop, 1e-9), time_to_converge_s=t_init + t_loop,
+                   sample="whole workload %dx%d nnz %d fp32 to convergence, OpenMP oracle port (oracle/pogs_oracle.cpp, pinned to "
+                          "the reference in tests/), %d threads: %d iterations, total %.1f s, init %.1f s"
+                          % (m, n, A_host.nnz, ob.cpu_quota(), iters, t_init + t_loop, t_init))
+        return out, parity_of(r["x"], r["optval"], iters, "oracle port, same A, b, lambda, default tolerances, whole workload")
+    if not ob.ref_available():
+        raise RuntimeError("oracle/_ref/libpogs_cpu.so is missing (built by __graft_entry__.build() where /root/reference exists)")
+    cap = None if args.cpu_full else args.cpu_iters
+    r = ob.ref_solve(A_host, fs, gs, dtype=dt, verbose=1, timeout=args.cpu_budget_s, **({"max_iter": cap} if cap else {}))
+    t_total, t_init = r.get("t_total", r["wall_s"]), r.get("t_init", 0.0)
+    iters = r["iterations"] + 1
+    converged = r["status"] == 0
+    out.update(kind="reference", cores=ob.ref_threads(), value=iters / max(t_total - t_init, 1e-9), init_s=t_init,
+               loop_s=t_total - t_init, iterations=iters, converged=converged, threads_env=ob.ref_env_note(),
+               sample="whole workload %dx%d fp32, compiled reference (oracle/_ref/libpogs_cpu.so), %s: %d iterations%s, "
+                      "Total %.1f s, Init %.1f s (its own summary line); elapsed with process start and input hand-over %.1f s"
+                      % (m, n, "to convergence" if converged else "max_iter = %d" % (cap or 2500), iters,
+                         "" if converged else " (not converged: capped, see cpu_baseline() in bench.py)", t_total, t_init,
+                         time.time() - t_start))
+    if converged:
+        out["time_to_converge_s"] = t_total
+        if parity is None:
+            parity = parity_of(r["x"], r["optval"], iters, "compiled reference (oracle/_ref/libpogs_cpu.so), same A, b, lambda, "
+                                                           "default tolerances, whole workload, this run")
     return out, parity
 
 
@@ -253,53 +263,64 @@ def pmc_traffic(name, kernel_substr):
         return None, None
 
 
-def main():
-    args = parse()
-    maybe_spawn(args)
-    import oracle_binding as ob
+class Env:
+    """What every configuration of a run shares: ranks, device, the process group."""
 
-    # host threads (OpenMP of the oracle port, torch's CPU ops): what the container may really use
-    os.environ.setdefault("OMP_NUM_THREADS", str(ob.cpu_quota()))
+    def __init__(self, args):
+        import torch
+
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus and self.rank == 0:
+            print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d"
+                  % (args.gpus, self.world, self.world), file=sys.stderr)
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device("cuda", self.local)
+        self.dist = None
+        self.force_dist = os.environ.get("POGS_AMD_FORCE_DIST", "0") == "1"  # exercise the RCCL path with 1 rank
+        if self.world > 1 or self.force_dist:
+            import torch.distributed as dist
+
+            if self.force_dist and "MASTER_ADDR" not in os.environ:
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
+            dist.init_process_group("nccl")
+            self.dist = dist
+
+    def barrier(self):
+        import torch
+
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+
+def run_config(env, name, with_cpu):
+    """One configuration: build, one cold solve, the timed windows.  Returns the JSON dict on rank 0
+    (None elsewhere)."""
     import numpy as np
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d"
-              % (args.gpus, world, world), file=sys.stderr)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     import pogs_amd
     from pogs_amd import graph as G
 
-    cfg = CONFIGS[args.config]
+    args, rank, world, local, dev, dist = env.args, env.rank, env.world, env.local, env.dev, env.dist
+    cfg = CONFIGS[name]
     m = args.m or cfg["m"]
     n = args.n or cfg["n"]
     sparse = cfg["kind"] == "csr_lasso"
 
-    dist_arg, dist = None, None
-    force_dist = os.environ.get("POGS_AMD_FORCE_DIST", "0") == "1"  # exercise the RCCL path with 1 rank
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-
-        if force_dist and "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl")
+    dist_arg = None
+    if dist is not None:
         uid = torch.zeros(128, dtype=torch.uint8, device=dev)
         if rank == 0:
             uid = torch.tensor(list(pogs_amd.dist_unique_id()), dtype=torch.uint8, device=dev)
         dist.broadcast(uid, 0)
         dist_arg = (rank, world, m * world, bytes(uid.cpu().tolist()))
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist_arg is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    A, b = make_problem(cfg, m, n, rank, dev)
+    A, b, A_host = make_problem(cfg, m, n, rank, dev, world)
     torch.cuda.synchronize()
     t0 = time.time()
     if sparse:
@@ -327,20 +348,21 @@ def main():
     times = []
     solver.reset_stats()
     for _ in range(windows):
-        barrier()
+        env.barrier()
         t0 = time.time()
         solver.iterate(args.steps)
-        barrier()
+        env.barrier()
         elapsed = time.time() - t0
-        if dist_arg is not None:
+        if dist is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         times.append(elapsed)
     elapsed = statistics.median(times)
     st = solver.stats()
+    nranks_comm = solver.comm_nranks() if hasattr(solver, "comm_nranks") else (world if dist_arg is not None else 0)
 
-    out_line = None
+    line = None
     if rank == 0:
         its = world * args.steps / elapsed
         launches = max(st["stream_launches"], 1)
@@ -350,7 +372,7 @@ def main():
         steps_total = args.steps * windows
         if sparse:
             nnz = A.nnz
-            kernel = "spmv_sell_kernel (every SpMV of the loop: A p, A^T r, A x)"
+            kernel = "spmv_sell_fin_kernel / spmv_sell_kernel (every SpMV of the loop: A p, A^T r, A x)"
             kernel_key = "spmv"
             spmv_per_iter = st["matvecs"] / max(steps_total, 1)
             iter_bytes = bytes_per_launch * spmv_per_iter
@@ -360,7 +382,7 @@ def main():
                          "bytes": iter_bytes, "frac": iter_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}
             workload = ("solve_lasso sparse CSR fp32 A=%dx%d nnz=%d per GPU, lambda=%g, default tolerances "
                         "(BASELINE.json configs[%d])" % (m, n, nnz, cfg["lambd"], cfg["cfg_index"]))
-            projector = "CGLS (LDS-gather SpMV)"
+            projector = "CGLS (LDS-gather SpMV, device-resident CG loop)"
         else:
             kernel = "stream_rows2_kernel<FusedIterOp> (the one pass over A per iteration)"
             kernel_key = "stream_rows2_kernel<float"
@@ -374,9 +396,9 @@ def main():
                                                         "iterations); this ratio is a speed-up over that byte model, NOT a "
                                                         "roofline fraction",
                              "ratio_to_hbm_peak": two_pass * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}}
-            name = "solve_lasso" if cfg["kind"] == "dense_lasso" else "solve_logistic"
+            wname = "solve_lasso" if cfg["kind"] == "dense_lasso" else "solve_logistic"
             workload = ("%s dense fp32 A=%dx%d per GPU, lambda=%g, default tolerances (BASELINE.json configs[%d]%s)"
-                        % (name, m, n, cfg["lambd"], cfg["cfg_index"],
+                        % (wname, m, n, cfg["lambd"], cfg["cfg_index"],
                            "" if world == 1 else "; row-sharded %dx%d" % (m * world, n)))
             projector = "direct (MFMA Gram + Cholesky)"
             if args.projector == "cgls":
@@ -388,7 +410,7 @@ def main():
                              "bytes": passes * 4.0 * m * n, "frac": passes * 4.0 * m * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}
                 projector = "CGLS on the dense matrix (matrix-free)"
                 workload += " [--projector cgls]"
-        traffic, traffic_src = (pmc_traffic(args.config, kernel_key) if (m, n) == (cfg["m"], cfg["n"]) and args.projector == "default"
+        traffic, traffic_src = (pmc_traffic(name, kernel_key) if (m, n) == (cfg["m"], cfg["n"]) and args.projector == "default"
                                 else (None, None))
         line = {
             "metric": "admm_iterations_per_sec_%s_fp32 (per-GPU shard, summed over GPUs)" % cfg["kind"],
@@ -396,8 +418,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "windows": windows, "window_s": times,
-            "config": {"workload": workload, "name": args.config, "rows_per_gpu": m, "cols": n, "projector": projector,
-                       "parallelism": "row-shard x%d" % world, "rccl_nranks": world if dist_arg is not None else 0},
+            "config": {"workload": workload, "name": name, "rows_per_gpu": m, "cols": n, "projector": projector,
+                       "parallelism": "row-shard x%d" % world, "rccl_nranks": nranks_comm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": ("static: %s (rocprofv3 --pmc passes of this command, committed; not "
@@ -411,17 +433,50 @@ def main():
         }
         if not sparse:
             line["gram_tflops"] = st_solve["gram_flops"] / max(st_solve["gram_ms"], 1e-9) / 1e9
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                A_host = A if sparse else A.cpu().numpy()
-                line["cpu_baseline"], parity = cpu_baseline(cfg, A_host, f, g, args.cpu_budget_s, res, args.cpu_full)
-                if parity is not None:
-                    line["parity_vs_reference"] = parity
-            except Exception as e:  # the baseline must never take the bench line down
-                line["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": os.cpu_count(), "kind": "none",
-                                        "sample": "failed: %r" % (e,)}
-        out_line = json.dumps(line)
     solver.close()
+    if rank == 0 and with_cpu:
+        try:
+            if sparse:
+                A_host = A
+            elif A_host is None:
+                A_host = A.cpu().numpy()
+            del A   # the GPU copy is not needed any more; the reference gets the host copy
+            torch.cuda.empty_cache()
+            fx = fixture_c2() if (name == "c2" and (m, n) == (cfg["m"], cfg["n"])) else None
+            line["cpu_baseline"], parity = cpu_baseline(cfg, A_host, f, g, args, res, fx)
+            if parity is not None:
+                line["parity_vs_reference"] = parity
+        except Exception as e:  # the baseline must never take the bench line down
+            line["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": os.cpu_count(), "kind": "none",
+                                    "sample": "failed: %r" % (e,)}
+    return line
+
+
+def main():
+    args = parse()
+    maybe_spawn(args)
+    import oracle_binding as ob
+
+    # host threads (OpenMP of the oracle port, torch's CPU ops): what the container may really use
+    os.environ.setdefault("OMP_NUM_THREADS", str(ob.cpu_quota()))
+    env = Env(args)
+    head = args.config or "c2"
+    line = run_config(env, head, with_cpu=env.world == 1 and not args.no_cpu_baseline)
+    # the driver's invocation (no --config, one GPU): c3 and c4 under the same clock, GPU legs only
+    if args.config is None and env.world == 1 and not args.no_secondary and not (args.m or args.n) \
+            and args.projector == "default":
+        keep = ("value", "unit", "ms_per_step", "steps", "windows", "config", "roofline", "time_to_converge_s", "init_s",
+                "solve_iterations", "solve_status", "setup_ms")
+        sec = {}
+        for name in ("c3", "c4"):
+            try:
+                d = run_config(env, name, with_cpu=False)
+                sec[name] = {k: d[k] for k in keep if k in d}
+            except Exception as e:
+                sec[name] = {"value": None, "error": repr(e)[:300]}
+        if line is not None:
+            line["secondary"] = sec
+    out_line = json.dumps(line) if line is not None else None
     # The JSON line must be the LAST line of the job's stdout.  C libraries print through stdio
     # (RCCL's version banner: on a pipe it sits in the buffer until exit), so every rank empties
     # those buffers now, the ranks meet, and only then does rank 0 print.
@@ -432,9 +487,9 @@ def main():
     except Exception:
         pass
     sys.stdout.flush()
-    if dist_arg is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if env.dist is not None:
+        env.dist.barrier()
+        env.dist.destroy_process_group()
     if out_line is not None:
         print(out_line, flush=True)
 

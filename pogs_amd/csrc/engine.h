@@ -53,15 +53,24 @@ class EventTimer {
  public:
   void enable(bool on) { on_ = on; }
   bool enabled() const { return on_; }
-  void begin(hipStream_t s) {
-    if (!on_) return;
+  // returns the index of the pair (see drop)
+  size_t begin(hipStream_t s) {
+    if (!on_) return 0;
     if (used_ == ev_.size()) {
       hipEvent_t a, b;
       POGS_HIP_CHECK(hipEventCreate(&a));
       POGS_HIP_CHECK(hipEventCreate(&b));
       ev_.push_back({a, b});
+      dropped_.push_back(0);
     }
+    dropped_[used_] = 0;
     POGS_HIP_CHECK(hipEventRecord(ev_[used_].first, s));
+    return used_;
+  }
+  // a launch that turned out to be a no-op (a guarded launch past the end of a device-side loop)
+  // does not count as a launch of the kernel
+  void drop(size_t idx) {
+    if (on_ && idx < dropped_.size()) dropped_[idx] = 1;
   }
   void end(hipStream_t s) {
     if (!on_) return;
@@ -71,11 +80,14 @@ class EventTimer {
   // Sum of elapsed ms over all recorded pairs; the stream must be idle.
   double collect_ms(unsigned long long *count) {
     double tot = 0;
+    size_t kept = 0;
     for (size_t i = 0; i < used_; ++i) {
+      if (dropped_[i]) continue;
       float ms = 0;
       if (hipEventElapsedTime(&ms, ev_[i].first, ev_[i].second) == hipSuccess) tot += ms;
+      ++kept;
     }
-    if (count) *count += used_;
+    if (count) *count += kept;
     used_ = 0;
     return tot;
   }
@@ -86,6 +98,7 @@ class EventTimer {
   bool on_ = false;
   size_t used_ = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_;
+  std::vector<char> dropped_;
 };
 
 // One-shot event pair for setup phases.
@@ -203,26 +216,12 @@ struct Ctx {
   }
   // scalars that the next fetch takes from a packed all-reduce buffer (consumed by that fetch)
   void set_overlay(const ScalarOverlay &ov) { overlay = ov; }
-  const double *fetch_scalars() {
-    const ScalarOverlay ov = overlay;
-    overlay = ScalarOverlay();
-    if (!poll_fetch) {
-      flush_sums();
-      launch_apply_overlay(S.p, ov, stream);
-      POGS_HIP_CHECK(hipMemcpyAsync(S_host.p, S.p, kNumSlots * sizeof(double), hipMemcpyDeviceToHost, stream));
-      POGS_HIP_CHECK(hipStreamSynchronize(stream));
-      return S_host.p;
-    }
-    const unsigned long long want = ++fetch_seq;
+  // A kernel of the caller publishes the block itself (cg_fused.h: fin_publish): begin_publish
+  // hands out the sequence number it must raise, wait_publish polls for it.
+  unsigned long long begin_publish() { return ++fetch_seq; }
+  unsigned long long *host_seq_dev() const { return reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots); }
+  const double *wait_publish(unsigned long long want) {
     unsigned long long *seqp = reinterpret_cast<unsigned long long *>(S_host.p + kNumSlots);
-    if (npending) {
-      launch_sum_publish(pending, npending, S.p, kNumSlots, S_host_dev,
-                         reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots), want, pub_counter.p, stream, ov);
-      npending = 0;
-    } else {
-      launch_publish_scalars(S.p, kNumSlots, S_host_dev, reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots),
-                             want, stream, ov);
-    }
     unsigned spins = 0, idle_seen = 0;
     while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != want) {
       if (++spins == (1u << 14)) {   // ~ every few hundred microseconds: surface a failed stream
@@ -246,6 +245,27 @@ struct Ctx {
 #endif
     }
     return S_host.p;
+  }
+  const double *fetch_scalars() {
+    const ScalarOverlay ov = overlay;
+    overlay = ScalarOverlay();
+    if (!poll_fetch) {
+      flush_sums();
+      launch_apply_overlay(S.p, ov, stream);
+      POGS_HIP_CHECK(hipMemcpyAsync(S_host.p, S.p, kNumSlots * sizeof(double), hipMemcpyDeviceToHost, stream));
+      POGS_HIP_CHECK(hipStreamSynchronize(stream));
+      return S_host.p;
+    }
+    const unsigned long long want = ++fetch_seq;
+    if (npending) {
+      launch_sum_publish(pending, npending, S.p, kNumSlots, S_host_dev,
+                         reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots), want, pub_counter.p, stream, ov);
+      npending = 0;
+    } else {
+      launch_publish_scalars(S.p, kNumSlots, S_host_dev, reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots),
+                             want, stream, ov);
+    }
+    return wait_publish(want);
   }
   bool poll_fetch = true;
   ScalarOverlay overlay;

@@ -102,29 +102,15 @@ __device__ __forceinline__ int sell_uniform_load(const int *p) {
 #pragma clang diagnostic pop
 }
 
-// DIRECT (ncg == 1): the row functor runs here; otherwise part[cg * nrows + row] receives the
-// column group's partial sums.
-template <typename T, bool SQ, bool DIRECT, typename Op>
-__global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, const T *__restrict__ x,
-                                                             const double *x_nrm2, Op op, T *__restrict__ part,
-                                                             double *scalar_partials) {
-  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+// The row sums of one (row range, column group) into s_y[0 .. nr): the streaming body shared by the
+// SpMV kernels below.  s_x: BW elements of LDS, s_y: RR elements; ends with a barrier (s_y complete).
+template <typename T, bool SQ>
+__device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__restrict__ x, T xs, int rr, int cg, int nr,
+                                              T *s_x, T *s_y) {
   constexpr int BW = SellCfg<T>::BW;
   constexpr int UB = kSellUB, NB = kSellNB;
-  extern __shared__ __attribute__((aligned(16))) unsigned char sell_smem[];
-  T *s_x = reinterpret_cast<T *>(sell_smem);   // [BW]
-  T *s_y = s_x + BW;                           // [RR]
-  __shared__ double s_red[NS * kSellWaves];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  // consecutive workgroups (round-robin over the XCDs) take the column groups of one row range:
-  // with 8 groups every XCD keeps re-reading the same eighth of x from its own L2
-  const int cg = static_cast<int>(blockIdx.x) % A.ncg;
-  const int rr = static_cast<int>(blockIdx.x) / A.ncg;
-  const int row0 = rr * A.rr_rows;
-  const int nr = min(A.rr_rows, A.nrows - row0);
-  T xs = 1;
-  if (x_nrm2) xs = static_cast<T>(1.0 / sqrt(*x_nrm2));
   for (int i = t; i < nr; i += kSellTpb) s_y[i] = 0;
 
   const T *__restrict__ a_val = A.val;
@@ -174,42 +160,75 @@ __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, cons
   constexpr int VEC = Vec16<T>::N;
   constexpr int XV = BW / (kSellTpb * VEC);
   V xreg[XV];
-  int x_cb = cb0 - 1, x_w = 0, x_c0 = 0;   // block whose slice is in xreg, its width and first column
+  int x_cb = cb0 - 1, x_w = 0;   // block whose slice is in xreg, its width
   auto x_prefetch = [&]() {   // advance x_cb to the next non-empty tile and request its slice
     do { ++x_cb; } while (x_cb < cb1 && tu(x_cb) == tu(x_cb + 1));
     if (x_cb >= cb1) return;
     const int c0 = x_cb * BW, w = min(BW, A.ncols - c0);
     if (w >= VEC) {
-      // unconditional loads (a vector past the end re-reads the last whole one and is zeroed): no
-      // branch per vector, and the number of loads in flight stays a compile-time constant
+      // unconditional loads: a vector that straddles or lies past the end re-reads the last whole
+      // vector of the slice (no branch per vector, a compile-time number of loads in flight); what
+      // it really holds is sorted out in x_store, one tile later, when the data has long arrived
+      // (touching the loaded value here would make the compiler wait for it -- and with it for the
+      // whole batch ring -- at every tile boundary)
       const int c_last = w - VEC;
 #pragma unroll
       for (int i = 0; i < XV; ++i) {
         const int c = (i * kSellTpb + t) * VEC;
-        const V v = *reinterpret_cast<const V *>(x + c0 + min(c, c_last));
-        xreg[i] = (c <= c_last) ? v : dev_vzero<V>();
+        xreg[i] = *reinterpret_cast<const V *>(x + c0 + min(c, c_last));
       }
     } else {
+      // a last column block narrower than one vector: thread 0 owns it
 #pragma unroll
       for (int i = 0; i < XV; ++i) xreg[i] = dev_vzero<V>();
+      if (t == 0) {
+        T out[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) out[q] = q < w ? x[c0 + q] : static_cast<T>(0);
+        __builtin_memcpy(&xreg[0], out, sizeof(V));
+      }
     }
     x_w = w;
-    x_c0 = c0;
   };
   auto x_store = [&]() {
+    // Every word of s_x has ONE writer: the vector that straddles the end of the slice takes its
+    // leading elements from the tail of the last whole vector (which is what it loaded: elements
+    // c .. w-1 sit at offset c - c_last in it) and zeros behind them; vectors past the end are zero.
+    // (The ragged tail used to be stored by threads 0 .. VEC-2 on top of the owner's zero vector, a
+    // write-write race between wavefronts.)
+    if (x_w == BW) {   // (uniform) a full-width slice: every vector is what it loaded
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        T tmp[VEC];
+        __builtin_memcpy(tmp, &xreg[i], sizeof(V));
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) tmp[q] *= xs;
+        V v;
+        __builtin_memcpy(&v, tmp, sizeof(V));
+        *reinterpret_cast<V *>(s_x + (i * kSellTpb + t) * VEC) = v;
+      }
+      return;
+    }
+    const int c_last = x_w - VEC;
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
-      T tmp[VEC];
-      __builtin_memcpy(tmp, &xreg[i], sizeof(V));
+      const int c = (i * kSellTpb + t) * VEC;
+      T in[VEC], out[VEC];
+      __builtin_memcpy(in, &xreg[i], sizeof(V));
+      const int sh = (x_w >= VEC && c > c_last) ? c - c_last : 0;   // 0: the vector is what it loaded
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) tmp[q] *= xs;
+      for (int q = 0; q < VEC; ++q) {
+        T e = in[q];
+#pragma unroll
+        for (int u = 1; u < VEC; ++u)
+          if (sh == u) e = (q + u < VEC) ? in[q + u] : static_cast<T>(0);
+        if (sh >= VEC) e = 0;
+        out[q] = e * xs;
+      }
       V v;
-      __builtin_memcpy(&v, tmp, sizeof(V));
-      *reinterpret_cast<V *>(s_x + (i * kSellTpb + t) * VEC) = v;
+      __builtin_memcpy(&v, out, sizeof(V));
+      *reinterpret_cast<V *>(s_x + c) = v;
     }
-    // the ragged end of the last column block (ncols not a multiple of the vector width)
-    const int tail0 = x_w / VEC * VEC;
-    if (t < x_w - tail0) s_x[tail0 + t] = x[x_c0 + tail0 + t] * xs;
   };
   // The wavefront's batches of ALL tiles of the workgroup form one sequence (every wavefront has
   // the same number per tile, so all of them cross a tile boundary at the same step).  The ring is
@@ -271,6 +290,30 @@ __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, cons
     }
   }
   __syncthreads();
+}
+
+// DIRECT (ncg == 1): the row functor runs here; otherwise part[cg * nrows + row] receives the
+// column group's partial sums.
+template <typename T, bool SQ, bool DIRECT, typename Op>
+__global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, const T *__restrict__ x,
+                                                             const double *x_nrm2, Op op, T *__restrict__ part,
+                                                             double *scalar_partials) {
+  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+  constexpr int BW = SellCfg<T>::BW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sell_smem[];
+  T *s_x = reinterpret_cast<T *>(sell_smem);   // [BW]
+  T *s_y = s_x + BW;                           // [RR]
+  __shared__ double s_red[NS * kSellWaves];
+  const int t = threadIdx.x;
+  // consecutive workgroups (round-robin over the XCDs) take the column groups of one row range:
+  // with 8 groups every XCD keeps re-reading the same eighth of x from its own L2
+  const int cg = static_cast<int>(blockIdx.x) % A.ncg;
+  const int rr = static_cast<int>(blockIdx.x) / A.ncg;
+  const int row0 = rr * A.rr_rows;
+  const int nr = min(A.rr_rows, A.nrows - row0);
+  T xs = 1;
+  if (x_nrm2) xs = static_cast<T>(1.0 / sqrt(*x_nrm2));
+  sell_row_sums<T, SQ>(A, x, xs, rr, cg, nr, s_x, s_y);
   double sacc[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
@@ -287,6 +330,150 @@ __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, cons
     T *out = part + static_cast<size_t>(cg) * A.nrows + row0;
     for (int i = t; i < nr; i += kSellTpb) out[i] = s_y[i];
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV with everything that used to follow it in launches of their own folded in ("fin" kernel):
+//   * the column groups of a row range meet at a device counter; the group that arrives last adds
+//     the partial sums in group order (what reduce_parts_kernel did) and runs the row functor;
+//   * the row ranges meet at a second counter; the workgroup that arrives last runs `fin.run()`
+//     on the per-row-range scalar records -- the scalar sums and whatever consumes them (a CGLS
+//     scalar, the iteration's publish), in a fixed order whoever happens to be last;
+//   * `fin.skip()` (a device word written by an earlier launch) turns the whole launch into a
+//     no-op: the host can enqueue a loop's worth of launches without reading anything back.
+// At most 256-ish workgroups take part, two levels of counters: no address sees more than a few
+// dozen increments (a single counter under 2048 workgroups cost 50 us per SpMV in round 2).
+// ctr[0]: row ranges done; ctr[1 + rr]: column groups of row range rr done; zero between launches.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFinSmem = 8 * kSellWaves;   // doubles of LDS handed to Fin::run
+
+// Sum of `count` records of NS doubles (record b at p + b * stride) over the workgroup, fixed order;
+// result in thread 0; ends with a barrier.
+template <int NS>
+__device__ __forceinline__ void fin_sum_records(const double *p, int count, int stride, double (&out)[NS], double *smem) {
+#pragma unroll
+  for (int k = 0; k < NS; ++k) out[k] = 0.0;
+  for (int b = threadIdx.x; b < count; b += kSellTpb) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) out[k] += p[static_cast<size_t>(b) * stride + k];
+  }
+  dev::block_sum<NS, kSellTpb>(out, smem);
+  __syncthreads();
+}
+
+// timing-probe hook: a Fin with a member `probe_flags` switches parts of the epilogue off
+template <typename Fin>
+__device__ __forceinline__ auto fin_probe_flags(const Fin &f) -> decltype(f.probe_flags) { return f.probe_flags; }
+__device__ __forceinline__ int fin_probe_flags(...) { return 0; }
+
+template <typename T, bool SQ, typename Op, typename Fin>
+__global__ void __launch_bounds__(kSellTpb) spmv_sell_fin_kernel(SellView<T> A, const T *__restrict__ x, Op op,
+                                                                 T *part, double *rec, unsigned *ctr, Fin fin) {
+  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+  static_assert(NS * kSellWaves <= kFinSmem, "scalar sums per row");
+  constexpr int BW = SellCfg<T>::BW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sell_smem[];
+  T *s_x = reinterpret_cast<T *>(sell_smem);   // [BW]
+  T *s_y = s_x + BW;                           // [RR]
+  __shared__ double s_red[kFinSmem];
+  __shared__ unsigned s_last;
+  const int t = threadIdx.x;
+  // (timing probe only, SparseSolver::probe_spmv: bit 0 no release fences, bit 1 no acquire fences,
+  // bit 2 no row functor / group sums, bit 3 no counters at all -- production Fins compile this out)
+  const int dbg = fin_probe_flags(fin);
+  if (fin.skip()) {   // uniform over the launch
+    if (blockIdx.x == 0) fin.skipped();
+    return;
+  }
+  const int cg = static_cast<int>(blockIdx.x) % A.ncg;
+  const int rr = static_cast<int>(blockIdx.x) / A.ncg;
+  const int row0 = rr * A.rr_rows;
+  const int nr = min(A.rr_rows, A.nrows - row0);
+  sell_row_sums<T, SQ>(A, x, static_cast<T>(1), rr, cg, nr, s_x, s_y);
+  double sacc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
+  if (A.ncg > 1) {
+    T *out = part + static_cast<size_t>(cg) * A.nrows + row0;
+    for (int i = t; i < nr; i += kSellTpb) out[i] = s_y[i];
+    __syncthreads();
+    if (t == 0) {
+      // RELEASE only (write this group's sums back from the XCD's L2): an acquire here -- a seq_cst
+      // fence, an acq_rel atomic -- invalidates that L2, and with one per workgroup the x slices
+      // every workgroup of the XCD keeps re-reading from it are thrown out over and over (measured:
+      // +80 us per SpMV at C4).  Only the workgroup that arrives last acquires.
+      if (!(dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      s_last = (dbg & 8) ? cg == A.ncg - 1
+                         : __hip_atomic_fetch_add(ctr + 1 + rr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                               static_cast<unsigned>(A.ncg - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (!(dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other groups' sums before the reads
+    if (t == 0) __hip_atomic_store(ctr + 1 + rr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The groups' partial sums, added in group order, and the row functor -- U rows at a time with
+    // ALL their loads (U x up to G partial sums, the functor's operands) requested before any is
+    // used: one memory round trip per U rows.  (One row at a time this is 32 dependent round trips
+    // per thread -- 80 us at C4 -- while the rest of the chip idles.)
+    const T *p0 = part + row0;
+    constexpr int U = 8, G = 8;
+    for (int i0 = t; i0 < ((dbg & 4) ? 0 : nr); i0 += kSellTpb * U) {
+      T w[G][U];
+      typename Op::In in[U];
+      const int gl = min(A.ncg, G);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = min(i0 + u * kSellTpb, nr - 1);   // (clamped: a load past the end repeats the last row)
+          w[g][u] = g < gl ? p0[static_cast<size_t>(g) * A.nrows + i] : static_cast<T>(0);
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u) in[u] = op.load(row0 + min(i0 + u * kSellTpb, nr - 1));
+      T v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = w[0][u];
+#pragma unroll
+      for (int g = 1; g < G; ++g)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (g < gl) v[u] += w[g][u];
+      for (int g = G; g < A.ncg; ++g)   // more than G groups: the rest one group at a time
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] += p0[static_cast<size_t>(g) * A.nrows + min(i0 + u * kSellTpb, nr - 1)];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * kSellTpb;
+        if (i < nr) op.apply(row0 + i, v[u], in[u], sacc);
+      }
+    }
+  } else {
+    // one column group: the sums are final in LDS; the functor's operands U rows at a time
+    constexpr int U = 8;
+    for (int i0 = t; i0 < nr; i0 += kSellTpb * U) {
+      typename Op::In in[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) in[u] = op.load(row0 + min(i0 + u * kSellTpb, nr - 1));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * kSellTpb;
+        if (i < nr) op.apply(row0 + i, s_y[i], in[u], sacc);
+      }
+    }
+  }
+  dev::block_sum<NS, kSellTpb>(sacc, s_red);
+  if (t == 0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) rec[static_cast<size_t>(rr) * NS + k] = sacc[k];
+    if (!(dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the record before the count
+    s_last = (dbg & 8) ? rr == A.nrr - 1
+                       : __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(A.nrr - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (!(dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (t == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  fin.run(rec, A.nrr, s_red);
 }
 
 // ---------------------------------------------------------------------------------------------

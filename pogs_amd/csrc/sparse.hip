@@ -20,6 +20,7 @@
 #include <limits>
 #include <vector>
 
+#include "cg_fused.h"
 #include "cg_kernels.h"
 #include "engine.h"
 #include "reduce.h"
@@ -67,6 +68,17 @@ struct SpAxpbyNormOp {  // y[i] = alpha * dot + beta * yin[i]; s0 += y[i]^2
     y[i] = v;
     s[0] += static_cast<double>(v) * v;
   }
+  // the same in two steps (sell.h: spmv_sell_fin_kernel requests the operands of several rows
+  // before it uses any)
+  struct In { T yin; };
+  __device__ __forceinline__ In load(int i) const { return In{beta != static_cast<T>(0) ? yin[i] : static_cast<T>(0)}; }
+  template <int N>
+  __device__ __forceinline__ void apply(int i, T dot, const In &in, double (&s)[N]) const {
+    T v = alpha * dot;
+    if (beta != static_cast<T>(0)) v += beta * in.yin;
+    y[i] = v;
+    s[0] += static_cast<double>(v) * v;
+  }
 };
 
 template <typename T>
@@ -104,6 +116,16 @@ struct SpTailOp {  // ProjTailOp for the y half: see ops.h
     s[0] += static_cast<double>(a) * a;
     s[1] += static_cast<double>(b) * b;
     ztemp[i] -= dot;
+  }
+  struct In { T zprev, z12, ztemp; };
+  __device__ __forceinline__ In load(int i) const { return In{zprev[i], z12[i], ztemp[i]}; }
+  template <int N>
+  __device__ __forceinline__ void apply(int i, T dot, const In &in, double (&s)[N]) const {
+    znew[i] = dot;
+    const T a = in.zprev - dot, b = in.z12 - dot;
+    s[0] += static_cast<double>(a) * a;
+    s[1] += static_cast<double>(b) * b;
+    ztemp[i] = in.ztemp - dot;
   }
 };
 
@@ -523,6 +545,35 @@ class SparseSolver final : public SolverBase {
     norm_est();
     ctx_.sync();
     ctx_.stats.t_init_s = wall_s() - t0;
+    if (std::getenv("POGS_AMD_SPMV_PROBE")) probe_spmv();
+  }
+
+  // POGS_AMD_SPMV_PROBE=1 (development aid): times the SpMV launch forms on this matrix and prints
+  // microseconds per product -- plain kernel (+ group reduction), the fin kernel, and the fin kernel
+  // with parts of its epilogue switched off (sell.h: probe bits; results are not used).
+  void probe_spmv() {
+    if (!fused_cg_) return;
+    hipStream_t s = ctx_.stream;
+    auto time_us = [&](auto &&launch) {
+      for (int i = 0; i < 5; ++i) launch();
+      PhaseTimer pt(s);
+      for (int i = 0; i < 50; ++i) launch();
+      return pt.stop_ms() * 1e3 / 50;
+    };
+    launch_fill<T>(cg_p_.p, static_cast<T>(1), n_, s);
+    launch_fill<T>(cg_r_.p, static_cast<T>(1), m_, s);
+    std::fprintf(stderr, "[pogs_amd spmv probe] A %d x %d: nrr %d ncg %d | At: nrr %d ncg %d\n", m_, n_, A_.nrr, A_.ncg,
+                 At_.nrr, At_.ncg);
+    const double a0 = time_us([&] { spmv<false>(A_, cg_p_.p, nullptr, SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p}, nullptr, 0); });
+    const double t0 = time_us([&] { spmv_t<false>(cg_r_.p, SpAxpbyNormOp<T>{1, 0, nullptr, cg_s_.p}, nullptr); });
+    std::fprintf(stderr, "[pogs_amd spmv probe] plain kernel + group reduction: A %.1f us, At %.1f us\n", a0, t0);
+    for (int flags : {0, 1, 2, 3, 4, 7, 15}) {
+      const double a = time_us([&] { spmv_fin(A_, cg_p_.p, SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p}, FinProbe{ctx_.S.p + kCgQ2, flags}); });
+      const double t = time_us([&] { spmv_fin(At_, cg_r_.p, SpAxpbyNormOp<T>{1, 0, nullptr, cg_s_.p}, FinProbe{ctx_.S.p + kCgS2, flags}); });
+      std::fprintf(stderr, "[pogs_amd spmv probe] fin kernel, probe bits %2d: A %.1f us, At %.1f us\n", flags, a, t);
+    }
+    fin_ctr_.zero(s);
+    ctx_.sync();
   }
 
   int dtype() const override { return sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64; }
@@ -860,6 +911,15 @@ class SparseSolver final : public SolverBase {
     sp_cgp_off_ = sp_cgx_off_ + static_cast<size_t>(vec_blocks(n_)) + 8;
     sp_pre_off_ = sp_cgp_off_ + static_cast<size_t>(vec_blocks(n_)) + 8;   // prox-step sums (deferred on one GPU)
     ctx_.ensure_spart(sp_pre_off_ + vb * 3 + 8);
+    // device-resident CGLS loop (cg_fused.h): one GPU, both copies in the tiled layout
+    const char *cg_env = std::getenv("POGS_AMD_CG");
+    fused_cg_ = !multi_ && A_.sell_ready && At_.sell_ready && !(cg_env && cg_env[0] == 'h') && ctx_.poll_fetch;
+    if (fused_cg_) {
+      const size_t nrr = static_cast<size_t>(std::max(A_.nrr, At_.nrr));
+      fin_rec_.alloc(nrr * 4);
+      fin_ctr_.alloc(nrr + 1);
+      fin_ctr_.zero(s);
+    }
   }
 
   // y_i = op(sum_k val * x[ind]) over the rows of M; scalar sums land in S[slot..slot+NS)
@@ -919,6 +979,20 @@ class SparseSolver final : public SolverBase {
       SumJob j{ctx_.spart.p, grid, Op::NS, scalar_out};
       launch_sum_jobs(&j, 1, s);
     }
+  }
+  // SpMV + group reduction + row functor + `fin` in ONE launch (sell.h: spmv_sell_fin_kernel);
+  // returns the index of its stream-timer pair
+  template <typename Op, typename Fin>
+  size_t spmv_fin(const DevCsr<T> &M, const T *x, const Op &op, const Fin &fin) {
+    hipStream_t s = ctx_.stream;
+    constexpr size_t smem = (static_cast<size_t>(SellCfg<T>::BW) + SellCfg<T>::RR) * sizeof(T);
+    static SmemGrants grants;
+    ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_fin_kernel<T, false, Op, Fin>), smem, grants);
+    const size_t idx = ctx_.stream_timer.begin(s);
+    hipLaunchKernelGGL((spmv_sell_fin_kernel<T, false, Op, Fin>), dim3(M.nrr * M.ncg), dim3(kSellTpb), smem, s,
+                       M.sview(), x, op, M.part.p, fin_rec_.p, fin_ctr_.p, fin);
+    ctx_.stream_timer.end(s);
+    return idx;
   }
   // sums of a y-sized quantity: add the other ranks' rows
   void reduce_y_scalars(double *slot, int count) {
@@ -1172,6 +1246,74 @@ class SparseSolver final : public SolverBase {
     ytemp_.zero(s);
   }
 
+  // The prox step and the projection of one iteration with the device-resident CGLS loop
+  // (cg_fused.h): 4 + 4 k launches for k CG steps, one host poll.  Returns the published block.
+  const double *prox_and_project_fused(const AdmmPreArgs<T> &pa0, int nw) {
+    hipStream_t s = ctx_.stream;
+    const int bx = vec_blocks(n_), bm = vec_blocks(m_);
+    double *S = ctx_.S.p;
+    double *px = ctx_.spart.p + sp_cgx_off_, *pp = ctx_.spart.p + sp_cgp_off_;
+    double *xpart = ctx_.spart.p;   // the fin launches keep their records elsewhere: the base region is free
+    const double shift = 1.0, kEps = std::numeric_limits<T>::epsilon();
+    const double tol = static_cast<double>(ctl_.proj_tol());
+    T *x = x_[nw].p;
+    // prox, sums, over-relaxation; r = y0 - A x_warm (A x_warm is the previous y, see cgls_project),
+    // x <- x_warm - x0                                                        (projector_cgls.cpp:62)
+    AdmmPreArgs<T> pa = pa0;
+    pa.x_aux = x;
+    pa.y_aux = cg_r_.p;
+    launch_admm_pre<T>(pa, s);
+    // s = A^T r - shift x ; p = s ; gamma = |s|^2                             (cgls.h:236-245)
+    std::vector<size_t> &ev = fused_events_;
+    ev.clear();
+    ev.push_back(spmv_fin(At_, cg_r_.p, SpCgInitOp<T>{static_cast<T>(shift), x, cg_s_.p, cg_p_.p},
+                          FinCgInit{S, pa.partials, bx, bm, kEps}));
+    int enq = 0;
+    auto step = [&]() {
+      // q = A p, |q|^2 ; alpha                                               (cgls.h:257-271)
+      ev.push_back(spmv_fin(A_, cg_p_.p, SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p},
+                            FinCgAlpha{S, enq > 0 ? pp : nullptr, bx, shift, kEps}));
+      // x += alpha p ; r -= alpha q ; |x|^2                                  (:274-277)
+      hipLaunchKernelGGL(cgf_update_xr_kernel<T>, dim3(bx + bm), dim3(kVecTpb), 0, s, n_, m_, S, cg_p_.p, x, cg_q_.p,
+                         cg_r_.p, px, bx);
+      // s = A^T r - shift x ; |s|^2 ; beta ; the stopping test               (:281-292, 301-305)
+      ev.push_back(spmv_fin(At_, cg_r_.p, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p},
+                            FinCgBeta{S, px, bx, tol, 500}));
+      // p = s + beta p ; |p|^2                                               (:295-296)
+      hipLaunchKernelGGL(cgf_update_p_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, S, cg_s_.p, cg_p_.p, pp);
+      ++enq;
+    };
+    std::vector<size_t> tails;
+    auto close = [&]() {
+      // x <- x + x0 (projector_cgls.cpp:75) with the x-half bookkeeping; y = A x (:78) with the
+      // y-half bookkeeping, the iteration's sums and the publish
+      hipLaunchKernelGGL(cgf_close_x_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, S, x, x_[cur_].p, x12_.p, xtemp_.p,
+                         xpart);
+      const unsigned long long want = ctx_.begin_publish();
+      tails.push_back(spmv_fin(A_, x, SpTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p},
+                               FinCgTail{S, xpart, bx, ctx_.S_host_dev, ctx_.host_seq_dev(), want}));
+      return ctx_.wait_publish(want);
+    };
+    const int ahead = std::max(1, std::min(cg_pred_, 500));
+    for (int k = 0; k < ahead; ++k) step();
+    const double *Sh = close();
+    while (Sh[kFcDone] == 0.0) {   // the loop needed more steps than the previous projection
+      step();
+      Sh = close();
+    }
+    const int steps = static_cast<int>(Sh[kFcSteps]);
+    cg_pred_ = std::max(1, steps);
+    ctx_.stats.cg_iters += static_cast<unsigned long long>(steps);
+    // launches that found the loop ended (or, for the closing ones, not ended) were no-ops
+    for (int k = steps; k < enq; ++k) {
+      ctx_.stream_timer.drop(ev[1 + 2 * static_cast<size_t>(k)]);
+      ctx_.stream_timer.drop(ev[2 + 2 * static_cast<size_t>(k)]);
+    }
+    for (size_t i = 0; i + 1 < tails.size(); ++i) ctx_.stream_timer.drop(tails[i]);
+    timed_spmvs_ += 2 + 2 * static_cast<unsigned long long>(steps);
+    return Sh;
+  }
+
   bool iteration(unsigned verbose) {
     hipStream_t s = ctx_.stream;
     const int nw = cur_ ^ 1;
@@ -1186,6 +1328,10 @@ class SparseSolver final : public SolverBase {
     pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
     pa.partials = ctx_.spart.p + sp_pre_off_;
     pa.blocks_x = vec_blocks(n_);
+    const double *S;
+    if (fused_cg_) {
+      S = prox_and_project_fused(pa, nw);
+    } else {
     launch_admm_pre<T>(pa, s);
     {
       SumJob j[2] = {{pa.partials, pa.blocks_x, 3, ctx_.S.p + kGapX},
@@ -1208,7 +1354,8 @@ class SparseSolver final : public SolverBase {
     reduce_y_scalars(ctx_.S.p + kDYprev2, 2);
     launch_admm_tail<T>(n_, x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, ctx_.spart.p, s);
     ctx_.queue_sum(SumJob{ctx_.spart.p, vec_blocks(n_), 2, ctx_.S.p + kDXprev2});   // x side: no exchange; summed by the fetch below
-    const double *S = ctx_.fetch_scalars();
+    S = ctx_.fetch_scalars();
+    }
     ctl_.set_pre(S);
     bool exact = false;
     if (ctl_.set_approx(S, nrmA_)) {
@@ -1299,6 +1446,7 @@ class SparseSolver final : public SolverBase {
   int spmv_grid_ = 2048;
   size_t sp_cgx_off_ = 0, sp_cgp_off_ = 0, sp_pre_off_ = 0;   // regions of ctx_.spart (alloc_state)
   unsigned long long timed_spmvs_ = 0;
+  std::vector<size_t> fused_events_;
   bool warm_pending_ = false;
   std::vector<T> warm_x_, warm_l_;
   DevCsr<T> A_, At_;
@@ -1307,6 +1455,11 @@ class SparseSolver final : public SolverBase {
   DevBuf<T> cg_p_, cg_s_, cg_q_, cg_r_, cg_b_, u_;
   DevBuf<T> xout_, yout_, lout_, muout_;
   DevBuf<double> cg_;
+  // device-resident CGLS loop (cg_fused.h)
+  bool fused_cg_ = false;
+  int cg_pred_ = 1;              // CG steps enqueued ahead: what the previous projection took
+  DevBuf<double> fin_rec_;       // per-row-range scalar records of a fin launch
+  DevBuf<unsigned> fin_ctr_;     // its counters (zero between launches)
   FnBuf<T> f_, g_, fs_, gs_;
   AdmmControl<T> ctl_;
   bool loaded_ = false;   // load_problem has run: f, g and the control block are valid

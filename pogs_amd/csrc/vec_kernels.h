@@ -21,7 +21,12 @@ enum Slot : int {
   kSpecGapY = 26, kSpecWY2, kSpecHY2,   // next iteration's y-half sums from the one-pass kernel
   kSpecGapX = 29, kSpecWX2, kSpecHX2,   // ... x-half sums (m <= n, transposed storage)
   kSkRatio = 32,   // sum over the entries of (new / old) of a Sinkhorn-Knopp pass
-  kNumSlots = 40
+  // device-resident CGLS loop (cg_fused.h): the scalars of cgls.h:236-306 and its loop control
+  kFcDone = 40,    // != 0: the projection's CG loop has ended (converged, or maxit steps)
+  kFcSteps,        // CG steps taken by the current projection
+  kFcNorms0,       // |s_0|^2
+  kFcGamma, kFcAlpha, kFcBeta, kFcDelta, kFcIndef,
+  kNumSlots = 48
 };
 
 template <typename T>
@@ -44,6 +49,8 @@ struct AdmmPreArgs {
   T rho, alpha;
   double *partials;  // [blocks_x + blocks_y][3]
   int blocks_x;
+  // optional (CGLS warm start, cg_fused.h): x_aux = x_cur - xtemp_new, y_aux = ytemp_new - y_cur
+  T *x_aux = nullptr, *y_aux = nullptr;
 };
 
 // clamp c,e >= 0 (FunctionObj::CheckConsts, prox_lib.h:62-69) and scale by the

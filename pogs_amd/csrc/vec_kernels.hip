@@ -46,7 +46,10 @@ __global__ void __launch_bounds__(kVecTpb) admm_pre_kernel(AdmmPreArgs<T> a) {
     const T h = dev::ProxEval(fn.h[i], fn.a[i], fn.b[i], fn.c[i], fn.d[i], fn.e[i], v, a.rho);  // :263
     const T w = v - h;                                            // :267
     z12[i] = h;
-    ztemp[i] = ztv + a.alpha * h + (static_cast<T>(1) - a.alpha) * prev;   // :276-278
+    const T zt_new = ztv + a.alpha * h + (static_cast<T>(1) - a.alpha) * prev;   // :276-278
+    ztemp[i] = zt_new;
+    T *aux = is_x ? a.x_aux : a.y_aux;
+    if (aux) aux[i] = is_x ? prev - zt_new : zt_new - prev;
     acc[0] = static_cast<double>(w) * h;                          // :268
     acc[1] = static_cast<double>(w) * w;
     acc[2] = static_cast<double>(h) * h;
@@ -290,7 +293,7 @@ __global__ void __launch_bounds__(64) publish_scalars_kernel(double *S, int coun
 }
 __global__ void __launch_bounds__(64) apply_overlay_kernel(double *S, ScalarOverlay ov) {
   const int t = threadIdx.x;
-  (void)overlay_value(S, t, ov);
+  if (t < kNumSlots) (void)overlay_value(S, t, ov);
 }
 }  // namespace
 

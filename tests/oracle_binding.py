@@ -224,6 +224,13 @@ REF_THREADS = 16   # BLAS threads of the reference subprocess: the fastest setti
                    # (scripts/ref_threads_probe.py, 20000 x 10000 fp32: 16 -> 12.8 it/s, 32 -> 9.2, 64 -> 11.1,
                    # 128 -> 7.2, 256 -> 8.8) -- its container has a CPU quota of 16 cores (cgroup cpu.max) although
                    # 256 hardware threads are visible
+# Environment of the reference subprocess.  MKL_DYNAMIC=FALSE: use the threads it is given.  Passive
+# waiting (KMP_BLOCKTIME=0, OMP_WAIT_POLICY=PASSIVE): MKL's idle OpenMP workers otherwise spin for
+# 200 ms after every parallel region, which under the container's CPU quota competes with the one
+# thread that runs the reference's gemv (profiles/r03_ref_cpu_diagnosis.md: on the GPU box's AMD
+# host MKL runs cblas_sgemv on ONE thread whatever the settings; 70000 x 10000: 77 s passive, 88 s
+# spinning).
+REF_ENV = {"MKL_DYNAMIC": "FALSE", "KMP_BLOCKTIME": "0", "OMP_WAIT_POLICY": "PASSIVE"}
 
 
 def cpu_quota():
@@ -246,6 +253,10 @@ def cpu_quota():
 
 def ref_threads():
     return max(1, min(REF_THREADS, cpu_quota()))
+
+
+def ref_env_note():
+    return "MKL_NUM_THREADS=OMP_NUM_THREADS=%d %s" % (ref_threads(), " ".join("%s=%s" % kv for kv in sorted(REF_ENV.items())))
 
 
 def ref_start(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0,
@@ -283,7 +294,8 @@ def ref_start(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, ma
         env = dict(os.environ)
         env.pop("PYTHONPATH", None)
         nthr = str(threads if threads else ref_threads())
-        env.update(MKL_NUM_THREADS=nthr, OMP_NUM_THREADS=nthr, MKL_DYNAMIC="FALSE")
+        env.update(MKL_NUM_THREADS=nthr, OMP_NUM_THREADS=nthr)
+        env.update(REF_ENV)
         cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_runner.py"), td.name]
         proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     except Exception:

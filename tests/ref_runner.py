@@ -37,7 +37,9 @@ def main(td):
                 p(ind)]
         fn = lib.PogsSparseD if dtype == np.float64 else lib.PogsSparseS
     else:
-        A = np.load(os.path.join(td, "A.npy"))
+        # (memory-mapped: the reference makes its own copy of A, matrix_dense.cpp:85-87, so the file's pages
+        # are read once and never duplicated in this process)
+        A = np.load(os.path.join(td, "A.npy"), mmap_mode="r")
         A = np.ascontiguousarray(A, dtype=dtype) if int(order) == 1 else np.asfortranarray(A, dtype=dtype)
         m, n = A.shape
         head = [ctypes.c_int(int(order)), ctypes.c_size_t(m), ctypes.c_size_t(n), p(A)]
