@@ -3,30 +3,73 @@
 // Reference: ProjectorCgls::Project (src/cpu/projector/projector_cgls.cpp:52-88) -> cgls::Solve
 // (src/cpu/include/cgls.h:200-323).  The reference's loop reads three scalars per step (alpha,
 // beta, the stopping test); round 2 formed alpha and beta on the device but still polled the host
-// once per step for the stopping test and spent ~9 launches per step.  Here a CG step is four
+// once per step for the stopping test and spent ~9 launches per step.  Here a CG step is six
 // launches that never involve the host:
 //
-//   L1  q = A p            spmv_sell_fin_kernel<SpAxpbyNormOp, FinAlpha>: |q|^2, |p|^2 -> alpha
-//   U1  x += alpha p, r -= alpha q, partial |x|^2          (cgf_update_xr_kernel)
-//   L2  s = A^T r - x      spmv_sell_fin_kernel<SpAxpbyNormOp, FinBeta>: |s|^2, |x|^2 -> beta,
-//                          gamma, step count, the stopping test of cgls.h:301-305 -> S[kFcDone]
-//   U2  p = s + beta p, partial |p|^2                      (cgf_update_p_kernel)
+//   L1  q~ = A p           spmv_sell_kernel (partial sums per column group)
+//   R1  q = sum of groups, partial |q|^2                                   cgf_reduce_kernel
+//   U1  alpha (every block adds up R1's and U2's records itself, in one fixed order);
+//       x += alpha p, r -= alpha q, y_new += alpha q, partial |x|^2        cgf_step_a_kernel
+//   L2  s~ = A^T r         spmv_sell_kernel
+//   R2  s = sum of groups - x, partial |s|^2                               cgf_reduce_kernel
+//   U2  beta, gamma, the stopping test of cgls.h:301-305 -> S[kFcDone];
+//       p = s + beta p, partial |p|^2                                      cgf_step_b_kernel
 //
-// every one of which starts by reading S[kFcDone] and returns at once when the loop has ended.
-// The host enqueues as many steps as the previous projection took, then the closing launches
-// (x += x0 with the x-half bookkeeping; y = A x with the y-half bookkeeping, whose last
-// workgroup also publishes the scalar block to the host) -- which run only if S[kFcDone] is set --
-// and polls ONCE per ADMM iteration; if the loop had not ended it enqueues one more step and the
-// closing launches again.
+// "Every block adds up the records itself": a scalar that needs a sum over the whole vector is
+// formed by EACH block of the consuming launch from the <= 512 per-block records the producing
+// launch left behind (4 KB from L2, the same order in every block, so all blocks hold the same
+// bits); block 0 also stores it for the host and for later launches.  No atomics, no fences, no
+// "last block" -- an in-kernel finaliser behind a device counter was built first and measured:
+// its agent-scope release / acquire fences (L2 write-back / invalidate on a multi-XCD part) cost
+// 19 us per SpMV and its one-workgroup-per-row-range functor tail 10 us more.
+//
+// Every launch of the loop starts by reading S[kFcDone] (written by an earlier launch) and returns
+// at once when the loop has ended.  The host enqueues as many steps as the previous projection
+// took, then the closing launch -- which runs only if S[kFcDone] is set -- and the iteration's
+// publish, and polls ONCE per ADMM iteration; if the loop had not ended it enqueues one more step
+// and the closing launches again.
+//
+// y = A x without the product (projector_cgls.cpp:78): x_new = x_warm + sum_k alpha_k p_k, so
+// A x_new = y_warm + sum_k alpha_k q_k with the q_k = A p_k the loop has already formed (y_warm =
+// A x_warm is the previous iteration's y, see SparseSolver::cgls_project).  U1 accumulates it; the
+// explicit product is still taken every POGS_AMD_YSYNC-th iteration (default 16), which bounds the
+// rounding drift of the recurrence.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "reduce.h"
-#include "sell.h"
 #include "vec_kernels.h"
 
 namespace pogs_amd {
 namespace {
+
+constexpr int kCgfTpb = 256;
+constexpr int kCgfBlocks = 512;   // upper bound on the blocks (= scalar records) of the loop's vector launches
+
+inline int cgf_blocks(int n) { return std::max(1, std::min(kCgfBlocks, (n + kCgfTpb - 1) / kCgfTpb)); }
+
+// Sum of `count` records of NS doubles (record b at p + b * NS): every thread of the block gets
+// the totals, and every block that runs this on the same records gets the same bits (per-thread
+// strided partial sums, wavefront butterfly, the four wavefront totals in order).
+template <int NS>
+__device__ __forceinline__ void cgf_sum(const double *p, int count, double (&out)[NS], double *smem /* [NS * 4] */) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) out[k] = 0.0;
+  for (int b = t; b < count; b += kCgfTpb) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) out[k] += p[static_cast<size_t>(b) * NS + k];
+  }
+  __syncthreads();   // smem may still be read from a previous call
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double w = dev::wave_sum(out[k]);
+    if (lane == 0) smem[k * 4 + wave] = w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NS; ++k) out[k] = (smem[k * 4 + 0] + smem[k * 4 + 1]) + (smem[k * 4 + 2] + smem[k * 4 + 3]);
+}
 
 // s_j = (A^T r)_j - shift xcg_j ; p_j = s_j ; |s|^2                        (cgls.h:236-245)
 template <typename T>
@@ -36,12 +79,7 @@ struct SpCgInitOp {
   const T *x;
   T *s, *p;
   template <int N>
-  __device__ __forceinline__ void row(int j, T dot, double (&acc)[N]) const {
-    const T v = dot - shift * x[j];
-    s[j] = v;
-    p[j] = v;
-    acc[0] += static_cast<double>(v) * v;
-  }
+  __device__ __forceinline__ void row(int j, T dot, double (&acc)[N]) const { apply(j, dot, load(j), acc); }
   struct In { T x; };
   __device__ __forceinline__ In load(int j) const { return In{x[j]}; }
   template <int N>
@@ -53,208 +91,229 @@ struct SpCgInitOp {
   }
 };
 
-// gamma = |s_0|^2, loop state reset; and the sums of the prox step's partials (admm_pre_kernel),
-// which nobody needs before the iteration's publish
-struct FinCgInit {
-  double *S;
-  const double *pre;   // [bx + by][3]
-  int bx, by;
-  double eps;
-  __device__ __forceinline__ bool skip() const { return false; }
-  __device__ __forceinline__ void skipped() const {}
-  __device__ __forceinline__ void run(const double *rec, int nrec, double *smem) const {
-    double g[1], sx[3], sy[3];
-    fin_sum_records<1>(rec, nrec, 1, g, smem);
-    fin_sum_records<3>(pre, bx, 3, sx, smem);
-    fin_sum_records<3>(pre + static_cast<size_t>(bx) * 3, by, 3, sy, smem);
-    if (threadIdx.x == 0) {
-      S[kFcGamma] = g[0];
-      S[kFcNorms0] = g[0];
-      S[kCgS2] = g[0];
-      S[kCgP2] = g[0];
-      S[kFcIndef] = 0.0;
-      S[kFcSteps] = 0.0;
-      S[kFcDone] = (sqrt(g[0]) < eps) ? 1.0 : 0.0;   // flag 1 (cgls.h:247-252): nothing to do
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        S[kGapX + k] = sx[k];
-        S[kGapY + k] = sy[k];
-      }
-    }
-  }
-};
-
-// alpha = gamma / (|q|^2 + shift |p|^2)                                    (cgls.h:262-271)
-struct FinCgAlpha {
-  double *S;
-  const double *pp;   // partial |p|^2 of the preceding U2 (nullptr: first step, |p|^2 = |s_0|^2)
-  int bp;
-  double shift, eps;
-  __device__ __forceinline__ bool skip() const { return S[kFcDone] != 0.0; }
-  __device__ __forceinline__ void skipped() const {}
-  __device__ __forceinline__ void run(const double *rec, int nrec, double *smem) const {
-    double q2[1], p2[1];
-    fin_sum_records<1>(rec, nrec, 1, q2, smem);
-    if (pp) fin_sum_records<1>(pp, bp, 1, p2, smem);
-    if (threadIdx.x == 0) {
-      const double normp2 = pp ? p2[0] : S[kCgP2];
-      S[kCgP2] = normp2;
-      S[kCgQ2] = q2[0];
-      double delta = q2[0] + shift * normp2;
-      if (delta <= 0.0) S[kFcIndef] = 1.0;
-      if (delta == 0.0) delta = eps;
-      S[kFcDelta] = delta;
-      S[kFcAlpha] = S[kFcGamma] / delta;
-    }
-  }
-};
-
-// beta = |s|^2 / gamma, gamma = |s|^2 (cgls.h:288-292); the stopping test (:301-305)
-struct FinCgBeta {
-  double *S;
-  const double *px;   // partial |x|^2 of the preceding U1
-  int bx;
-  double tol;
-  int maxit;
-  __device__ __forceinline__ bool skip() const { return S[kFcDone] != 0.0; }
-  __device__ __forceinline__ void skipped() const {}
-  __device__ __forceinline__ void run(const double *rec, int nrec, double *smem) const {
-    double g[1], x2[1];
-    fin_sum_records<1>(rec, nrec, 1, g, smem);
-    fin_sum_records<1>(px, bx, 1, x2, smem);
-    if (threadIdx.x == 0) {
-      const double g1 = S[kFcGamma];
-      S[kFcGamma] = g[0];
-      S[kFcBeta] = g[0] / g1;
-      S[kCgS2] = g[0];
-      S[kCgX2] = x2[0];
-      const double steps = S[kFcSteps] + 1.0;
-      S[kFcSteps] = steps;
-      const double norms = sqrt(g[0]), norms0 = sqrt(S[kFcNorms0]), normx = sqrt(x2[0]);
-      const bool converged = (norms <= norms0 * tol) || (normx * tol >= 1.0);
-      if (converged || steps >= static_cast<double>(maxit)) S[kFcDone] = 1.0;
-    }
-  }
-};
-
-// (timing probe, SparseSolver::probe_spmv) a finaliser that only adds the records up
-struct FinProbe {
-  double *out;
-  int probe_flags;
-  __device__ __forceinline__ bool skip() const { return false; }
-  __device__ __forceinline__ void skipped() const {}
-  __device__ __forceinline__ void run(const double *rec, int nrec, double *smem) const {
-    double g[1];
-    fin_sum_records<1>(rec, nrec, 1, g, smem);
-    if (threadIdx.x == 0) out[0] = g[0];
-  }
-};
-
-// copies the scalar block to the host-mapped mirror and raises the sequence word (the body of
-// publish_scalars_kernel); every thread of the workgroup calls it
-__device__ __forceinline__ void fin_publish(double *S, double *host_S, unsigned long long *host_seq,
-                                            unsigned long long seq) {
-  __syncthreads();   // thread 0's stores into S
-  const int t = threadIdx.x;
-  if (t < kNumSlots) host_S[t] = __hip_atomic_load(S + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __threadfence_system();
-  __syncthreads();
-  if (t == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+// guard convention of the loop's launches: run_if_done = 0 -> return when S[kFcDone] != 0 (the CG
+// steps), 1 -> return when S[kFcDone] == 0 (the closing launches), -1 -> always run
+__device__ __forceinline__ bool cgf_skip(const double *S, int run_if_done) {
+  if (run_if_done < 0) return false;
+  return (S[kFcDone] != 0.0) != (run_if_done != 0);
 }
 
-// closing launch y = A x: the y-half sums, the x-half sums left by cgf_close_x_kernel, publish.
-// Runs only when the CG loop has ended; otherwise it just publishes (the host sees kFcDone == 0).
-struct FinCgTail {
-  double *S;
-  const double *xpart;   // [bx][2]
-  int bx;
-  double *host_S;        // nullptr: no publish (the host copies the block itself)
-  unsigned long long *host_seq;
-  unsigned long long seq;
-  __device__ __forceinline__ bool skip() const { return S[kFcDone] == 0.0; }
-  __device__ __forceinline__ void skipped() const {
-    if (host_S) fin_publish(S, host_S, host_seq, seq);
-  }
-  __device__ __forceinline__ void run(const double *rec, int nrec, double *smem) const {
-    double sy[2], sx[2];
-    fin_sum_records<2>(rec, nrec, 2, sy, smem);
-    fin_sum_records<2>(xpart, bx, 2, sx, smem);
-    if (threadIdx.x == 0) {
-      S[kDYprev2] = sy[0];
-      S[kDY12] = sy[1];
-      S[kDXprev2] = sx[0];
-      S[kDX12] = sx[1];
-      __threadfence();
+// R: row r = sum of its ncg partial sums in group order (what reduce_parts_kernel does), the row
+// functor, one scalar record per block.  U rows x ncg loads are requested before any is used.
+template <typename T, typename Op>
+__global__ void __launch_bounds__(kCgfTpb) cgf_reduce_kernel(const T *__restrict__ part, int nrows, int ncg, Op op,
+                                                             double *rec, const double *S, int run_if_done) {
+  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+  __shared__ double s_red[NS * (kCgfTpb / 64)];
+  if (cgf_skip(S, run_if_done)) return;
+  double sacc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
+  constexpr int U = 4;
+  const int stride = gridDim.x * kCgfTpb;
+  for (int r0 = blockIdx.x * kCgfTpb + threadIdx.x; r0 < nrows; r0 += stride * U) {
+    T v[U];
+    typename Op::In in[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = min(r0 + u * stride, nrows - 1);   // (clamped: past the end the last row again, not applied)
+      v[u] = part[r];
+      in[u] = op.load(r);
     }
-    if (host_S) fin_publish(S, host_S, host_seq, seq);
+    for (int g = 1; g < ncg; ++g) {
+      T w[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) w[u] = part[static_cast<size_t>(g) * nrows + min(r0 + u * stride, nrows - 1)];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] += w[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + u * stride;
+      if (r < nrows) op.apply(r, v[u], in[u], sacc);
+    }
   }
-};
+  dev::block_sum<NS, kCgfTpb>(sacc, s_red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) rec[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
+  }
+}
 
-// U1: x += alpha p (n);  r -= alpha q (m);  partial |x|^2      (cgls.h:274-277, 298)
 template <typename T>
-__global__ void __launch_bounds__(kVecTpb) cgf_update_xr_kernel(int n, int m, const double *S, const T *p, T *x,
-                                                                const T *q, T *r, double *partials, int blocks_x) {
-  __shared__ double s_red[kVecTpb / 64];
-  if (S[kFcDone] != 0.0) return;
-  const T alpha = static_cast<T>(S[kFcAlpha]);
-  const T neg_alpha = static_cast<T>(-S[kFcAlpha]);
-  double acc[1] = {0.0};
-  if (static_cast<int>(blockIdx.x) < blocks_x) {
-    const int i = blockIdx.x * kVecTpb + threadIdx.x;
-    if (i < n) {
-      const T v = x[i] + alpha * p[i];
-      x[i] = v;
-      acc[0] = static_cast<double>(v) * v;
-    }
+struct CgfStepA {
+  int n, m;
+  double *S;
+  int first;                 // step 0: gamma = |s_0|^2 from rec_s0 (and |p|^2 = gamma), else gamma from S
+  int gslot;                 // gamma slot to read (not first)
+  const double *rec_s0; int nrec_s0;
+  const double *rec_p; int nrec_p;
+  const double *rec_q; int nrec_q;
+  double shift, eps;
+  const T *p; T *x;
+  const T *q; T *r;
+  const T *ycur; T *ynew;    // ynew == nullptr: the y recurrence is off (explicit product at the end)
+  double *rec_x;             // [blocks]
+};
+// U1: alpha = gamma / (|q|^2 + shift |p|^2) (cgls.h:262-271); x += alpha p, r -= alpha q (:274-277),
+// y_new = (first ? y_warm : y_new) + alpha q; partial |x|^2 (:298)
+template <typename T>
+__global__ void __launch_bounds__(kCgfTpb) cgf_step_a_kernel(CgfStepA<T> a) {
+  __shared__ double s_sum[8];
+  __shared__ double s_red[kCgfTpb / 64];
+  if (cgf_skip(a.S, 0)) return;
+  double gamma, p2;
+  if (a.first) {
+    double g[1];
+    cgf_sum<1>(a.rec_s0, a.nrec_s0, g, s_sum);
+    gamma = g[0];
+    p2 = g[0];
   } else {
-    const int i = (blockIdx.x - blocks_x) * kVecTpb + threadIdx.x;
-    if (i < m) r[i] += neg_alpha * q[i];
+    double g[1];
+    cgf_sum<1>(a.rec_p, a.nrec_p, g, s_sum);
+    gamma = a.S[kFcGamma0 + a.gslot];
+    p2 = g[0];
+  }
+  if (a.first && sqrt(gamma) < a.eps) {   // flag 1 (cgls.h:247-252): nothing to do, x stays
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      a.S[kFcGamma0] = gamma;
+      a.S[kFcNorms0] = gamma;
+      a.S[kFcDone] = 1.0;   // (a block that starts after this store returns at the guard: same outcome)
+    }
     return;
   }
-  dev::block_sum<1, kVecTpb>(acc, s_red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
-}
-
-// U2: p = s + beta p; partial |p|^2      (cgls.h:295-296)
-template <typename T>
-__global__ void __launch_bounds__(kVecTpb) cgf_update_p_kernel(int n, const double *S, const T *s, T *p,
-                                                               double *partials) {
-  __shared__ double s_red[kVecTpb / 64];
-  if (S[kFcDone] != 0.0) return;
-  const T beta = static_cast<T>(S[kFcBeta]);
-  const int i = blockIdx.x * kVecTpb + threadIdx.x;
-  double acc[1] = {0.0};
-  if (i < n) {
-    const T v = s[i] + beta * p[i];
-    p[i] = v;
-    acc[0] = static_cast<double>(v) * v;
+  double q2[1];
+  cgf_sum<1>(a.rec_q, a.nrec_q, q2, s_sum);
+  double delta = q2[0] + a.shift * p2;
+  const bool indef = delta <= 0.0;
+  if (delta == 0.0) delta = a.eps;
+  const double alpha_d = gamma / delta;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // (slots nobody reads in this launch)
+    if (a.first) {
+      a.S[kFcGamma0] = gamma;
+      a.S[kFcNorms0] = gamma;
+      a.S[kFcIndef] = 0.0;
+    }
+    if (indef) a.S[kFcIndef] = 1.0;
+    a.S[kCgQ2] = q2[0];
+    a.S[kCgP2] = p2;
+    a.S[kFcDelta] = delta;
+    a.S[kFcAlpha] = alpha_d;
   }
-  dev::block_sum<1, kVecTpb>(acc, s_red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+  const T alpha = static_cast<T>(alpha_d), neg_alpha = static_cast<T>(-alpha_d);
+  const int stride = gridDim.x * kCgfTpb, t0 = blockIdx.x * kCgfTpb + threadIdx.x;
+  double acc[1] = {0.0};
+  for (int i = t0; i < a.n; i += stride) {
+    const T v = a.x[i] + alpha * a.p[i];
+    a.x[i] = v;
+    acc[0] += static_cast<double>(v) * v;
+  }
+  if (a.ynew) {
+    const T *ysrc = a.first ? a.ycur : a.ynew;
+    for (int i = t0; i < a.m; i += stride) {
+      const T qi = a.q[i];
+      a.r[i] += neg_alpha * qi;
+      a.ynew[i] = ysrc[i] + alpha * qi;
+    }
+  } else {
+    for (int i = t0; i < a.m; i += stride) a.r[i] += neg_alpha * a.q[i];
+  }
+  dev::block_sum<1, kCgfTpb>(acc, s_red);
+  if (threadIdx.x == 0) a.rec_x[blockIdx.x] = acc[0];
 }
 
-// closing launch for the x half: x <- x + x0 (projector_cgls.cpp:75) and the element-wise
-// projection tail (admm_tail_kernel): sums of (x_prev - x)^2, (x12 - x)^2, xtemp <- x0 - x
 template <typename T>
-__global__ void __launch_bounds__(kVecTpb) cgf_close_x_kernel(int n, const double *S, T *x, const T *xprev,
-                                                              const T *x12, T *xtemp, double *partials) {
+struct CgfStepB {
+  int n;
+  double *S;
+  int k;                     // step index: gamma is read from slot k & 1 and written to the other
+  const double *rec_s; int nrec_s;
+  const double *rec_x; int nrec_x;
+  double tol;
+  int maxit;
+  const T *s; T *p;
+  double *rec_p;             // [blocks]
+};
+// U2: beta = |s|^2 / gamma, gamma = |s|^2 (cgls.h:288-292); the stopping test (:301-305);
+// p = s + beta p, partial |p|^2 (:295-296)
+template <typename T>
+__global__ void __launch_bounds__(kCgfTpb) cgf_step_b_kernel(CgfStepB<T> a) {
+  __shared__ double s_sum[8];
+  __shared__ double s_red[kCgfTpb / 64];
+  if (cgf_skip(a.S, 0)) return;
+  double g[1], x2[1];
+  cgf_sum<1>(a.rec_s, a.nrec_s, g, s_sum);
+  cgf_sum<1>(a.rec_x, a.nrec_x, x2, s_sum);
+  const double g1 = a.S[kFcGamma0 + (a.k & 1)];
+  const double beta_d = g[0] / g1;
+  const double norms = sqrt(g[0]), norms0 = sqrt(a.S[kFcNorms0]), normx = sqrt(x2[0]);
+  const bool converged = (norms <= norms0 * a.tol) || (normx * a.tol >= 1.0);
+  const bool done = converged || a.k + 1 >= a.maxit;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.S[kFcGamma0 + ((a.k + 1) & 1)] = g[0];
+    a.S[kFcBeta] = beta_d;
+    a.S[kCgS2] = g[0];
+    a.S[kCgX2] = x2[0];
+    a.S[kFcSteps] = static_cast<double>(a.k + 1);
+    if (done) a.S[kFcDone] = 1.0;   // (a block that starts after this store returns at the guard: same outcome)
+  }
+  if (done) return;                 // p is not needed any more
+  const T beta = static_cast<T>(beta_d);
+  const int stride = gridDim.x * kCgfTpb;
+  double acc[1] = {0.0};
+  for (int i = blockIdx.x * kCgfTpb + threadIdx.x; i < a.n; i += stride) {
+    const T v = a.s[i] + beta * a.p[i];
+    a.p[i] = v;
+    acc[0] += static_cast<double>(v) * v;
+  }
+  dev::block_sum<1, kCgfTpb>(acc, s_red);
+  if (threadIdx.x == 0) a.rec_p[blockIdx.x] = acc[0];
+}
+
+template <typename T>
+struct CgfClose {
+  int n, m;
+  const double *S;
+  T *x; const T *xprev, *x12; T *xtemp;           // x <- x + x0 (x0 = xtemp), the x-half bookkeeping
+  T *ynew; const T *yprev, *y12; T *ytemp;        // y half (the recurrence's y_new); ynew == nullptr: skip
+  double *part;                                    // [blocks_x + blocks_y][2]
+  int blocks_x;
+};
+// closing launch: x <- x + x0 (projector_cgls.cpp:75) and the element-wise projection tail of both
+// halves (admm_tail_kernel / SpTailOp): sums of (z_prev - z)^2, (z12 - z)^2, ztemp <- ztemp - z.
+// Zero CG steps: y_new is y_warm.
+template <typename T>
+__global__ void __launch_bounds__(kVecTpb) cgf_close_kernel(CgfClose<T> a) {
   __shared__ double s_red[2 * (kVecTpb / 64)];
-  if (S[kFcDone] == 0.0) return;
-  const int i = blockIdx.x * kVecTpb + threadIdx.x;
+  if (a.S[kFcDone] == 0.0) return;
   double acc[2] = {0.0, 0.0};
-  if (i < n) {
-    const T x0 = xtemp[i];
-    const T zn = x[i] + x0;   // the reference: x <- 1 * x0 + x (blas_axpy)
-    x[i] = zn;
-    const T a = xprev[i] - zn, b = x12[i] - zn;
-    acc[0] = static_cast<double>(a) * a;
-    acc[1] = static_cast<double>(b) * b;
-    xtemp[i] = x0 - zn;
+  if (static_cast<int>(blockIdx.x) < a.blocks_x) {
+    const int i = blockIdx.x * kVecTpb + threadIdx.x;
+    if (i < a.n) {
+      const T x0 = a.xtemp[i];
+      const T zn = a.x[i] + x0;   // the reference: x <- 1 * x0 + x (blas_axpy)
+      a.x[i] = zn;
+      const T d1 = a.xprev[i] - zn, d2 = a.x12[i] - zn;
+      acc[0] = static_cast<double>(d1) * d1;
+      acc[1] = static_cast<double>(d2) * d2;
+      a.xtemp[i] = x0 - zn;
+    }
+  } else {
+    const int i = (blockIdx.x - a.blocks_x) * kVecTpb + threadIdx.x;
+    if (i < a.m) {
+      const T yp = a.yprev[i];
+      const T zn = (a.S[kFcSteps] == 0.0) ? yp : a.ynew[i];
+      a.ynew[i] = zn;
+      const T d1 = yp - zn, d2 = a.y12[i] - zn;
+      acc[0] = static_cast<double>(d1) * d1;
+      acc[1] = static_cast<double>(d2) * d2;
+      a.ytemp[i] -= zn;
+    }
   }
   dev::block_sum<2, kVecTpb>(acc, s_red);
   if (threadIdx.x == 0) {
-    partials[static_cast<size_t>(blockIdx.x) * 2 + 0] = acc[0];
-    partials[static_cast<size_t>(blockIdx.x) * 2 + 1] = acc[1];
+    a.part[static_cast<size_t>(blockIdx.x) * 2 + 0] = acc[0];
+    a.part[static_cast<size_t>(blockIdx.x) * 2 + 1] = acc[1];
   }
 }
 

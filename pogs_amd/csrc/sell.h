@@ -293,11 +293,14 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
 }
 
 // DIRECT (ncg == 1): the row functor runs here; otherwise part[cg * nrows + row] receives the
-// column group's partial sums.
+// column group's partial sums.  `guard` (may be null): a device word written by an EARLIER launch;
+// non-zero turns this launch into a no-op (the device-resident CG loop, cg_fused.h: the host
+// enqueues a loop's worth of launches without reading anything back).
 template <typename T, bool SQ, bool DIRECT, typename Op>
 __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, const T *__restrict__ x,
                                                              const double *x_nrm2, Op op, T *__restrict__ part,
-                                                             double *scalar_partials) {
+                                                             double *scalar_partials, const double *guard) {
+  if (guard && *guard != 0.0) return;
   constexpr int NS = Op::NS > 0 ? Op::NS : 1;
   constexpr int BW = SellCfg<T>::BW;
   extern __shared__ __attribute__((aligned(16))) unsigned char sell_smem[];
@@ -330,150 +333,6 @@ __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, cons
     T *out = part + static_cast<size_t>(cg) * A.nrows + row0;
     for (int i = t; i < nr; i += kSellTpb) out[i] = s_y[i];
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// SpMV with everything that used to follow it in launches of their own folded in ("fin" kernel):
-//   * the column groups of a row range meet at a device counter; the group that arrives last adds
-//     the partial sums in group order (what reduce_parts_kernel did) and runs the row functor;
-//   * the row ranges meet at a second counter; the workgroup that arrives last runs `fin.run()`
-//     on the per-row-range scalar records -- the scalar sums and whatever consumes them (a CGLS
-//     scalar, the iteration's publish), in a fixed order whoever happens to be last;
-//   * `fin.skip()` (a device word written by an earlier launch) turns the whole launch into a
-//     no-op: the host can enqueue a loop's worth of launches without reading anything back.
-// At most 256-ish workgroups take part, two levels of counters: no address sees more than a few
-// dozen increments (a single counter under 2048 workgroups cost 50 us per SpMV in round 2).
-// ctr[0]: row ranges done; ctr[1 + rr]: column groups of row range rr done; zero between launches.
-// ---------------------------------------------------------------------------------------------
-constexpr int kFinSmem = 8 * kSellWaves;   // doubles of LDS handed to Fin::run
-
-// Sum of `count` records of NS doubles (record b at p + b * stride) over the workgroup, fixed order;
-// result in thread 0; ends with a barrier.
-template <int NS>
-__device__ __forceinline__ void fin_sum_records(const double *p, int count, int stride, double (&out)[NS], double *smem) {
-#pragma unroll
-  for (int k = 0; k < NS; ++k) out[k] = 0.0;
-  for (int b = threadIdx.x; b < count; b += kSellTpb) {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) out[k] += p[static_cast<size_t>(b) * stride + k];
-  }
-  dev::block_sum<NS, kSellTpb>(out, smem);
-  __syncthreads();
-}
-
-// timing-probe hook: a Fin with a member `probe_flags` switches parts of the epilogue off
-template <typename Fin>
-__device__ __forceinline__ auto fin_probe_flags(const Fin &f) -> decltype(f.probe_flags) { return f.probe_flags; }
-__device__ __forceinline__ int fin_probe_flags(...) { return 0; }
-
-template <typename T, bool SQ, typename Op, typename Fin>
-__global__ void __launch_bounds__(kSellTpb) spmv_sell_fin_kernel(SellView<T> A, const T *__restrict__ x, Op op,
-                                                                 T *part, double *rec, unsigned *ctr, Fin fin) {
-  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
-  static_assert(NS * kSellWaves <= kFinSmem, "scalar sums per row");
-  constexpr int BW = SellCfg<T>::BW;
-  extern __shared__ __attribute__((aligned(16))) unsigned char sell_smem[];
-  T *s_x = reinterpret_cast<T *>(sell_smem);   // [BW]
-  T *s_y = s_x + BW;                           // [RR]
-  __shared__ double s_red[kFinSmem];
-  __shared__ unsigned s_last;
-  const int t = threadIdx.x;
-  // (timing probe only, SparseSolver::probe_spmv: bit 0 no release fences, bit 1 no acquire fences,
-  // bit 2 no row functor / group sums, bit 3 no counters at all -- production Fins compile this out)
-  const int dbg = fin_probe_flags(fin);
-  if (fin.skip()) {   // uniform over the launch
-    if (blockIdx.x == 0) fin.skipped();
-    return;
-  }
-  const int cg = static_cast<int>(blockIdx.x) % A.ncg;
-  const int rr = static_cast<int>(blockIdx.x) / A.ncg;
-  const int row0 = rr * A.rr_rows;
-  const int nr = min(A.rr_rows, A.nrows - row0);
-  sell_row_sums<T, SQ>(A, x, static_cast<T>(1), rr, cg, nr, s_x, s_y);
-  double sacc[NS];
-#pragma unroll
-  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
-  if (A.ncg > 1) {
-    T *out = part + static_cast<size_t>(cg) * A.nrows + row0;
-    for (int i = t; i < nr; i += kSellTpb) out[i] = s_y[i];
-    __syncthreads();
-    if (t == 0) {
-      // RELEASE only (write this group's sums back from the XCD's L2): an acquire here -- a seq_cst
-      // fence, an acq_rel atomic -- invalidates that L2, and with one per workgroup the x slices
-      // every workgroup of the XCD keeps re-reading from it are thrown out over and over (measured:
-      // +80 us per SpMV at C4).  Only the workgroup that arrives last acquires.
-      if (!(dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      s_last = (dbg & 8) ? cg == A.ncg - 1
-                         : __hip_atomic_fetch_add(ctr + 1 + rr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                               static_cast<unsigned>(A.ncg - 1);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (!(dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other groups' sums before the reads
-    if (t == 0) __hip_atomic_store(ctr + 1 + rr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // The groups' partial sums, added in group order, and the row functor -- U rows at a time with
-    // ALL their loads (U x up to G partial sums, the functor's operands) requested before any is
-    // used: one memory round trip per U rows.  (One row at a time this is 32 dependent round trips
-    // per thread -- 80 us at C4 -- while the rest of the chip idles.)
-    const T *p0 = part + row0;
-    constexpr int U = 8, G = 8;
-    for (int i0 = t; i0 < ((dbg & 4) ? 0 : nr); i0 += kSellTpb * U) {
-      T w[G][U];
-      typename Op::In in[U];
-      const int gl = min(A.ncg, G);
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int i = min(i0 + u * kSellTpb, nr - 1);   // (clamped: a load past the end repeats the last row)
-          w[g][u] = g < gl ? p0[static_cast<size_t>(g) * A.nrows + i] : static_cast<T>(0);
-        }
-#pragma unroll
-      for (int u = 0; u < U; ++u) in[u] = op.load(row0 + min(i0 + u * kSellTpb, nr - 1));
-      T v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = w[0][u];
-#pragma unroll
-      for (int g = 1; g < G; ++g)
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (g < gl) v[u] += w[g][u];
-      for (int g = G; g < A.ncg; ++g)   // more than G groups: the rest one group at a time
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] += p0[static_cast<size_t>(g) * A.nrows + min(i0 + u * kSellTpb, nr - 1)];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = i0 + u * kSellTpb;
-        if (i < nr) op.apply(row0 + i, v[u], in[u], sacc);
-      }
-    }
-  } else {
-    // one column group: the sums are final in LDS; the functor's operands U rows at a time
-    constexpr int U = 8;
-    for (int i0 = t; i0 < nr; i0 += kSellTpb * U) {
-      typename Op::In in[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) in[u] = op.load(row0 + min(i0 + u * kSellTpb, nr - 1));
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = i0 + u * kSellTpb;
-        if (i < nr) op.apply(row0 + i, s_y[i], in[u], sacc);
-      }
-    }
-  }
-  dev::block_sum<NS, kSellTpb>(sacc, s_red);
-  if (t == 0) {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) rec[static_cast<size_t>(rr) * NS + k] = sacc[k];
-    if (!(dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the record before the count
-    s_last = (dbg & 8) ? rr == A.nrr - 1
-                       : __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(A.nrr - 1);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  if (!(dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (t == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  fin.run(rec, A.nrr, s_red);
 }
 
 // ---------------------------------------------------------------------------------------------

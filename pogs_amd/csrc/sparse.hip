@@ -545,35 +545,6 @@ class SparseSolver final : public SolverBase {
     norm_est();
     ctx_.sync();
     ctx_.stats.t_init_s = wall_s() - t0;
-    if (std::getenv("POGS_AMD_SPMV_PROBE")) probe_spmv();
-  }
-
-  // POGS_AMD_SPMV_PROBE=1 (development aid): times the SpMV launch forms on this matrix and prints
-  // microseconds per product -- plain kernel (+ group reduction), the fin kernel, and the fin kernel
-  // with parts of its epilogue switched off (sell.h: probe bits; results are not used).
-  void probe_spmv() {
-    if (!fused_cg_) return;
-    hipStream_t s = ctx_.stream;
-    auto time_us = [&](auto &&launch) {
-      for (int i = 0; i < 5; ++i) launch();
-      PhaseTimer pt(s);
-      for (int i = 0; i < 50; ++i) launch();
-      return pt.stop_ms() * 1e3 / 50;
-    };
-    launch_fill<T>(cg_p_.p, static_cast<T>(1), n_, s);
-    launch_fill<T>(cg_r_.p, static_cast<T>(1), m_, s);
-    std::fprintf(stderr, "[pogs_amd spmv probe] A %d x %d: nrr %d ncg %d | At: nrr %d ncg %d\n", m_, n_, A_.nrr, A_.ncg,
-                 At_.nrr, At_.ncg);
-    const double a0 = time_us([&] { spmv<false>(A_, cg_p_.p, nullptr, SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p}, nullptr, 0); });
-    const double t0 = time_us([&] { spmv_t<false>(cg_r_.p, SpAxpbyNormOp<T>{1, 0, nullptr, cg_s_.p}, nullptr); });
-    std::fprintf(stderr, "[pogs_amd spmv probe] plain kernel + group reduction: A %.1f us, At %.1f us\n", a0, t0);
-    for (int flags : {0, 1, 2, 3, 4, 7, 15}) {
-      const double a = time_us([&] { spmv_fin(A_, cg_p_.p, SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p}, FinProbe{ctx_.S.p + kCgQ2, flags}); });
-      const double t = time_us([&] { spmv_fin(At_, cg_r_.p, SpAxpbyNormOp<T>{1, 0, nullptr, cg_s_.p}, FinProbe{ctx_.S.p + kCgS2, flags}); });
-      std::fprintf(stderr, "[pogs_amd spmv probe] fin kernel, probe bits %2d: A %.1f us, At %.1f us\n", flags, a, t);
-    }
-    fin_ctr_.zero(s);
-    ctx_.sync();
   }
 
   int dtype() const override { return sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64; }
@@ -908,17 +879,19 @@ class SparseSolver final : public SolverBase {
     // [SpMV / vector-kernel partials | |x|^2 partials of a CG step | |p|^2 partials]: the last two
     // are summed by the launch that publishes the scalars, so they keep regions of their own
     sp_cgx_off_ = std::max<size_t>(sg * 4 + 64, vb * 3 + 64);
-    sp_cgp_off_ = sp_cgx_off_ + static_cast<size_t>(vec_blocks(n_)) + 8;
-    sp_pre_off_ = sp_cgp_off_ + static_cast<size_t>(vec_blocks(n_)) + 8;   // prox-step sums (deferred on one GPU)
+    const size_t cgreg = static_cast<size_t>(std::max(vec_blocks(n_), kCgfBlocks)) + 8;   // (cg_fused.h: up to kCgfBlocks records)
+    sp_cgp_off_ = sp_cgx_off_ + cgreg;
+    sp_pre_off_ = sp_cgp_off_ + cgreg;   // prox-step sums (deferred on one GPU)
     ctx_.ensure_spart(sp_pre_off_ + vb * 3 + 8);
     // device-resident CGLS loop (cg_fused.h): one GPU, both copies in the tiled layout
     const char *cg_env = std::getenv("POGS_AMD_CG");
     fused_cg_ = !multi_ && A_.sell_ready && At_.sell_ready && !(cg_env && cg_env[0] == 'h') && ctx_.poll_fetch;
     if (fused_cg_) {
-      const size_t nrr = static_cast<size_t>(std::max(A_.nrr, At_.nrr));
-      fin_rec_.alloc(nrr * 4);
-      fin_ctr_.alloc(nrr + 1);
-      fin_ctr_.zero(s);
+      // scalar records of the loop's products: one region for A^T products, one for A products
+      cg_rec_cap_ = static_cast<size_t>(std::max({A_.nrr * A_.ncg, At_.nrr * At_.ncg, kCgfBlocks})) * 2;
+      cg_rec_.alloc(cg_rec_cap_ * 2);
+      const char *ys = std::getenv("POGS_AMD_YSYNC");
+      if (ys) ysync_ = std::max(0, std::atoi(ys));
     }
   }
 
@@ -937,13 +910,13 @@ class SparseSolver final : public SolverBase {
         static SmemGrants grants;
         ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, SQ, true, Op>), smem, grants);
         hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, true, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
-                           x_nrm2, op, static_cast<T *>(nullptr), ctx_.spart.p);
+                           x_nrm2, op, static_cast<T *>(nullptr), ctx_.spart.p, static_cast<const double *>(nullptr));
         grid = g1;
       } else {
         static SmemGrants grants;
         ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, SQ, false, Op>), smem, grants);
         hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, false, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
-                           x_nrm2, op, M.part.p, ctx_.spart.p);
+                           x_nrm2, op, M.part.p, ctx_.spart.p, static_cast<const double *>(nullptr));
         grid = std::max(1, std::min((M.nrows + 255) / 256, spmv_grid_));
         hipLaunchKernelGGL((reduce_parts_kernel<T, Op>), dim3(grid), dim3(256), 0, s, M.part.p, M.nrows, M.ncg, op,
                            ctx_.spart.p);
@@ -980,19 +953,36 @@ class SparseSolver final : public SolverBase {
       launch_sum_jobs(&j, 1, s);
     }
   }
-  // SpMV + group reduction + row functor + `fin` in ONE launch (sell.h: spmv_sell_fin_kernel);
-  // returns the index of its stream-timer pair
-  template <typename Op, typename Fin>
-  size_t spmv_fin(const DevCsr<T> &M, const T *x, const Op &op, const Fin &fin) {
+  // A product of the device-resident CG loop (cg_fused.h): the SpMV and, with more than one column
+  // group, the group reduction that runs the row functor; both return at once unless the loop's
+  // done flag says `run_if_done` (-1: always run).  The functor's scalar records (one per block)
+  // go to `rec`; returns how many there are.  *ev: index of the stream-timer pair.
+  template <typename Op>
+  int spmv_cg(const DevCsr<T> &M, const T *x, const Op &op, double *rec, int run_if_done, size_t *ev) {
     hipStream_t s = ctx_.stream;
     constexpr size_t smem = (static_cast<size_t>(SellCfg<T>::BW) + SellCfg<T>::RR) * sizeof(T);
-    static SmemGrants grants;
-    ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_fin_kernel<T, false, Op, Fin>), smem, grants);
-    const size_t idx = ctx_.stream_timer.begin(s);
-    hipLaunchKernelGGL((spmv_sell_fin_kernel<T, false, Op, Fin>), dim3(M.nrr * M.ncg), dim3(kSellTpb), smem, s,
-                       M.sview(), x, op, M.part.p, fin_rec_.p, fin_ctr_.p, fin);
+    const double *S = ctx_.S.p;
+    const double *guard = run_if_done == 0 ? S + kFcDone : nullptr;
+    const int g1 = M.nrr * M.ncg;
+    int nrec;
+    *ev = ctx_.stream_timer.begin(s);
+    if (M.ncg == 1) {
+      static SmemGrants grants;
+      ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, false, true, Op>), smem, grants);
+      hipLaunchKernelGGL((spmv_sell_kernel<T, false, true, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
+                         static_cast<const double *>(nullptr), op, static_cast<T *>(nullptr), rec, guard);
+      nrec = g1;
+    } else {
+      static SmemGrants grants;
+      ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, false, false, Op>), smem, grants);
+      hipLaunchKernelGGL((spmv_sell_kernel<T, false, false, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
+                         static_cast<const double *>(nullptr), op, M.part.p, rec, guard);
+      nrec = cgf_blocks(M.nrows);
+      hipLaunchKernelGGL((cgf_reduce_kernel<T, Op>), dim3(nrec), dim3(kCgfTpb), 0, s, M.part.p, M.nrows, M.ncg, op, rec, S,
+                         run_if_done);
+    }
     ctx_.stream_timer.end(s);
-    return idx;
+    return nrec;
   }
   // sums of a y-sized quantity: add the other ranks' rows
   void reduce_y_scalars(double *slot, int count) {
@@ -1136,6 +1126,8 @@ class SparseSolver final : public SolverBase {
     cur_ = 0;
     zt_scale_ = 1;
     ctl_.reset();
+    proj_count_ = 0;
+    cg_pred_ = 1;
   }
 
   void sum_vec_partials(int blocks, double *out) {
@@ -1247,52 +1239,78 @@ class SparseSolver final : public SolverBase {
   }
 
   // The prox step and the projection of one iteration with the device-resident CGLS loop
-  // (cg_fused.h): 4 + 4 k launches for k CG steps, one host poll.  Returns the published block.
+  // (cg_fused.h): 6 launches per CG step, one host poll.  Returns the published block.
   const double *prox_and_project_fused(const AdmmPreArgs<T> &pa0, int nw) {
     hipStream_t s = ctx_.stream;
     const int bx = vec_blocks(n_), bm = vec_blocks(m_);
     double *S = ctx_.S.p;
-    double *px = ctx_.spart.p + sp_cgx_off_, *pp = ctx_.spart.p + sp_cgp_off_;
-    double *xpart = ctx_.spart.p;   // the fin launches keep their records elsewhere: the base region is free
+    double *rec_t = cg_rec_.p, *rec_a = cg_rec_.p + cg_rec_cap_;          // A^T products, A products
+    double *rec_x = ctx_.spart.p + sp_cgx_off_, *rec_p = ctx_.spart.p + sp_cgp_off_;
+    double *cpart = ctx_.spart.p;   // closing launch: [bx + bm][2]
     const double shift = 1.0, kEps = std::numeric_limits<T>::epsilon();
     const double tol = static_cast<double>(ctl_.proj_tol());
     T *x = x_[nw].p;
+    // y = A x by the recurrence, except every ysync_-th projection (and the first), which takes the
+    // product itself
+    const bool ysync = ysync_ <= 0 || (proj_count_ % static_cast<unsigned long long>(ysync_)) == 0;
+    ++proj_count_;
     // prox, sums, over-relaxation; r = y0 - A x_warm (A x_warm is the previous y, see cgls_project),
     // x <- x_warm - x0                                                        (projector_cgls.cpp:62)
     AdmmPreArgs<T> pa = pa0;
     pa.x_aux = x;
     pa.y_aux = cg_r_.p;
+    pa.cg_reset = S + kFcDone;
     launch_admm_pre<T>(pa, s);
-    // s = A^T r - shift x ; p = s ; gamma = |s|^2                             (cgls.h:236-245)
     std::vector<size_t> &ev = fused_events_;
     ev.clear();
-    ev.push_back(spmv_fin(At_, cg_r_.p, SpCgInitOp<T>{static_cast<T>(shift), x, cg_s_.p, cg_p_.p},
-                          FinCgInit{S, pa.partials, bx, bm, kEps}));
+    size_t e;
+    // s = A^T r - shift x ; p = s ; |s_0|^2 records                           (cgls.h:236-245)
+    const int nrec_s0 = spmv_cg(At_, cg_r_.p, SpCgInitOp<T>{static_cast<T>(shift), x, cg_s_.p, cg_p_.p}, rec_t, -1, &e);
+    const int gv = cgf_blocks(std::max(n_, m_)), gp = cgf_blocks(n_);
     int enq = 0;
     auto step = [&]() {
-      // q = A p, |q|^2 ; alpha                                               (cgls.h:257-271)
-      ev.push_back(spmv_fin(A_, cg_p_.p, SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p},
-                            FinCgAlpha{S, enq > 0 ? pp : nullptr, bx, shift, kEps}));
-      // x += alpha p ; r -= alpha q ; |x|^2                                  (:274-277)
-      hipLaunchKernelGGL(cgf_update_xr_kernel<T>, dim3(bx + bm), dim3(kVecTpb), 0, s, n_, m_, S, cg_p_.p, x, cg_q_.p,
-                         cg_r_.p, px, bx);
-      // s = A^T r - shift x ; |s|^2 ; beta ; the stopping test               (:281-292, 301-305)
-      ev.push_back(spmv_fin(At_, cg_r_.p, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p},
-                            FinCgBeta{S, px, bx, tol, 500}));
-      // p = s + beta p ; |p|^2                                               (:295-296)
-      hipLaunchKernelGGL(cgf_update_p_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, S, cg_s_.p, cg_p_.p, pp);
+      // q = A p, |q|^2 records                                               (cgls.h:257-260)
+      const int nrec_q = spmv_cg(A_, cg_p_.p, SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p}, rec_a, 0, &e);
+      ev.push_back(e);
+      // alpha ; x += alpha p ; r -= alpha q ; y_new += alpha q ; |x|^2        (:262-277, 298)
+      CgfStepA<T> a;
+      a.n = n_; a.m = m_; a.S = S;
+      a.first = enq == 0; a.gslot = enq & 1;
+      a.rec_s0 = rec_t; a.nrec_s0 = nrec_s0;
+      a.rec_p = rec_p; a.nrec_p = gp;
+      a.rec_q = rec_a; a.nrec_q = nrec_q;
+      a.shift = shift; a.eps = kEps;
+      a.p = cg_p_.p; a.x = x; a.q = cg_q_.p; a.r = cg_r_.p;
+      a.ycur = y_[cur_].p; a.ynew = ysync ? nullptr : y_[nw].p;
+      a.rec_x = rec_x;
+      hipLaunchKernelGGL(cgf_step_a_kernel<T>, dim3(gv), dim3(kCgfTpb), 0, s, a);
+      // s = A^T r - shift x ; |s|^2 records                                  (:281-286)
+      const int nrec_s = spmv_cg(At_, cg_r_.p, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, rec_t, 0, &e);
+      ev.push_back(e);
+      // beta, gamma, the stopping test ; p = s + beta p ; |p|^2              (:288-305)
+      CgfStepB<T> b;
+      b.n = n_; b.S = S; b.k = enq;
+      b.rec_s = rec_t; b.nrec_s = nrec_s;
+      b.rec_x = rec_x; b.nrec_x = gv;
+      b.tol = tol; b.maxit = 500;                                             // projector_cgls.cpp:17
+      b.s = cg_s_.p; b.p = cg_p_.p; b.rec_p = rec_p;
+      hipLaunchKernelGGL(cgf_step_b_kernel<T>, dim3(gp), dim3(kCgfTpb), 0, s, b);
       ++enq;
     };
-    std::vector<size_t> tails;
     auto close = [&]() {
-      // x <- x + x0 (projector_cgls.cpp:75) with the x-half bookkeeping; y = A x (:78) with the
-      // y-half bookkeeping, the iteration's sums and the publish
-      hipLaunchKernelGGL(cgf_close_x_kernel<T>, dim3(bx), dim3(kVecTpb), 0, s, n_, S, x, x_[cur_].p, x12_.p, xtemp_.p,
-                         xpart);
-      const unsigned long long want = ctx_.begin_publish();
-      tails.push_back(spmv_fin(A_, x, SpTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p},
-                               FinCgTail{S, xpart, bx, ctx_.S_host_dev, ctx_.host_seq_dev(), want}));
-      return ctx_.wait_publish(want);
+      // x <- x + x0 (projector_cgls.cpp:75), the bookkeeping of both halves (y_new from the
+      // recurrence), the iteration's sums and the publish
+      CgfClose<T> c;
+      c.n = n_; c.m = m_; c.S = S;
+      c.x = x; c.xprev = x_[cur_].p; c.x12 = x12_.p; c.xtemp = xtemp_.p;
+      c.ynew = ysync ? nullptr : y_[nw].p; c.yprev = y_[cur_].p; c.y12 = y12_.p; c.ytemp = ytemp_.p;
+      c.part = cpart; c.blocks_x = bx;
+      hipLaunchKernelGGL(cgf_close_kernel<T>, dim3(ysync ? bx : bx + bm), dim3(kVecTpb), 0, s, c);
+      ctx_.queue_sum(SumJob{pa.partials, bx, 3, S + kGapX});
+      ctx_.queue_sum(SumJob{pa.partials + static_cast<size_t>(bx) * 3, bm, 3, S + kGapY});
+      ctx_.queue_sum(SumJob{cpart, bx, 2, S + kDXprev2});
+      if (!ysync) ctx_.queue_sum(SumJob{cpart + static_cast<size_t>(bx) * 2, bm, 2, S + kDYprev2});
+      return ctx_.fetch_scalars();
     };
     const int ahead = std::max(1, std::min(cg_pred_, 500));
     for (int k = 0; k < ahead; ++k) step();
@@ -1304,13 +1322,14 @@ class SparseSolver final : public SolverBase {
     const int steps = static_cast<int>(Sh[kFcSteps]);
     cg_pred_ = std::max(1, steps);
     ctx_.stats.cg_iters += static_cast<unsigned long long>(steps);
-    // launches that found the loop ended (or, for the closing ones, not ended) were no-ops
-    for (int k = steps; k < enq; ++k) {
-      ctx_.stream_timer.drop(ev[1 + 2 * static_cast<size_t>(k)]);
-      ctx_.stream_timer.drop(ev[2 + 2 * static_cast<size_t>(k)]);
+    // launches that found the loop ended were no-ops
+    for (size_t k = 2 * static_cast<size_t>(steps); k < ev.size(); ++k) ctx_.stream_timer.drop(ev[k]);
+    timed_spmvs_ += 1 + 2 * static_cast<unsigned long long>(steps);
+    if (ysync) {
+      // y = A x fused with the y-half bookkeeping                             (projector_cgls.cpp:78)
+      spmv<false>(A_, x, nullptr, SpTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p}, S + kDYprev2, 0, true);
+      Sh = ctx_.fetch_scalars();
     }
-    for (size_t i = 0; i + 1 < tails.size(); ++i) ctx_.stream_timer.drop(tails[i]);
-    timed_spmvs_ += 2 + 2 * static_cast<unsigned long long>(steps);
     return Sh;
   }
 
@@ -1458,8 +1477,10 @@ class SparseSolver final : public SolverBase {
   // device-resident CGLS loop (cg_fused.h)
   bool fused_cg_ = false;
   int cg_pred_ = 1;              // CG steps enqueued ahead: what the previous projection took
-  DevBuf<double> fin_rec_;       // per-row-range scalar records of a fin launch
-  DevBuf<unsigned> fin_ctr_;     // its counters (zero between launches)
+  DevBuf<double> cg_rec_;        // scalar records of its products: [A^T products | A products]
+  size_t cg_rec_cap_ = 0;
+  int ysync_ = 16;               // y = A x explicitly every ysync_-th iteration (0: always), else by recurrence
+  unsigned long long proj_count_ = 0;
   FnBuf<T> f_, g_, fs_, gs_;
   AdmmControl<T> ctl_;
   bool loaded_ = false;   // load_problem has run: f, g and the control block are valid

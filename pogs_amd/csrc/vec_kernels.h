@@ -23,10 +23,11 @@ enum Slot : int {
   kSkRatio = 32,   // sum over the entries of (new / old) of a Sinkhorn-Knopp pass
   // device-resident CGLS loop (cg_fused.h): the scalars of cgls.h:236-306 and its loop control
   kFcDone = 40,    // != 0: the projection's CG loop has ended (converged, or maxit steps)
-  kFcSteps,        // CG steps taken by the current projection
+  kFcSteps,        // CG steps taken by the current projection (adjacent to kFcDone: reset together)
   kFcNorms0,       // |s_0|^2
-  kFcGamma, kFcAlpha, kFcBeta, kFcDelta, kFcIndef,
-  kNumSlots = 48
+  kFcGamma0, kFcGamma1,   // gamma, ping-pong by step parity (read and written by different launches only)
+  kFcAlpha, kFcBeta, kFcDelta, kFcIndef,
+  kNumSlots = 52
 };
 
 template <typename T>
@@ -49,8 +50,10 @@ struct AdmmPreArgs {
   T rho, alpha;
   double *partials;  // [blocks_x + blocks_y][3]
   int blocks_x;
-  // optional (CGLS warm start, cg_fused.h): x_aux = x_cur - xtemp_new, y_aux = ytemp_new - y_cur
+  // optional (CGLS warm start, cg_fused.h): x_aux = x_cur - xtemp_new, y_aux = ytemp_new - y_cur;
+  // cg_reset[0..1] = 0 (the CG loop's done flag and step count)
   T *x_aux = nullptr, *y_aux = nullptr;
+  double *cg_reset = nullptr;
 };
 
 // clamp c,e >= 0 (FunctionObj::CheckConsts, prox_lib.h:62-69) and scale by the

@@ -38,6 +38,10 @@ __global__ void __launch_bounds__(kVecTpb) admm_pre_kernel(AdmmPreArgs<T> a) {
   T *z12 = is_x ? a.x12 : a.y12;
   T *ztemp = is_x ? a.xtemp : a.ytemp;
   const int i = blk * kVecTpb + threadIdx.x;
+  if (a.cg_reset && blockIdx.x == 0 && threadIdx.x == 0) {
+    a.cg_reset[0] = 0.0;
+    a.cg_reset[1] = 0.0;
+  }
   double acc[3] = {0.0, 0.0, 0.0};
   if (i < n) {
     const T prev = cur[i];
