@@ -360,7 +360,7 @@ def run_config(env, name, with_cpu):
         times.append(elapsed)
     elapsed = statistics.median(times)
     st = solver.stats()
-    nranks_comm = solver.comm_nranks() if hasattr(solver, "comm_nranks") else (world if dist_arg is not None else 0)
+    nranks_comm = st.get("comm_nranks", 0)   # as ncclCommCount reports it (0: no communicator)
 
     line = None
     if rank == 0:

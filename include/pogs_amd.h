@@ -144,7 +144,9 @@ typedef struct PogsAmdStats {
   double equil_ms, normest_ms, gram_ms, chol_ms, trtri_ms;
   double gram_flops;
   double reserved[8];             /* [0] / [1]: one-pass iteration, rho predictions hit / missed;
-                                     [2]: all-reduce calls issued by the handle so far      */
+                                     [2]: all-reduce calls issued by the handle so far;
+                                     [3]: ranks of the handle's communicator as RCCL reports
+                                          them (ncclCommCount; 0 without row shards)             */
 } PogsAmdStats;
 
 /* Fill `out` (POGS_AMD_UNIQUE_ID_BYTES) with a fresh RCCL unique id (rank 0

@@ -11,14 +11,28 @@ import sys
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpogs_amd.so")
 
-# PyTorch ships its own libamdhip64/librccl.  If torch is (going to be) used in
-# this process it must be the first to load the HIP runtime, otherwise two
-# runtimes end up in one address space and device pointers cannot be shared.
-if "torch" not in sys.modules and os.environ.get("POGS_AMD_NO_TORCH_PRELOAD", "0") != "1":
-    try:  # pragma: no cover - depends on the environment
-        import torch  # noqa: F401
-    except Exception:
-        pass
+# PyTorch ships its own libamdhip64 / librccl.  A process that hands torch DEVICE pointers to this
+# library (Solver(device_ptr=True): bench.py, the full-size tests) must have torch load its HIP
+# runtime first, otherwise two runtimes end up in one address space and the pointers mean nothing
+# to the other one.  The package itself never imports torch: a pure ctypes / C caller and this
+# package behave alike.  Either import torch before pogs_amd, or set POGS_AMD_TORCH_PRELOAD=1 to
+# have it done here; Solver(device_ptr=True) refuses to run if torch appeared in the process only
+# after this library was loaded (torch_loaded_first below).
+TORCH_LOADED_FIRST = "torch" in sys.modules
+if not TORCH_LOADED_FIRST and os.environ.get("POGS_AMD_TORCH_PRELOAD", "0") == "1":
+    import torch  # noqa: F401
+
+    TORCH_LOADED_FIRST = True
+
+
+def check_device_pointer_interop():
+    """Called before a caller-supplied device pointer is used: raises if torch was imported AFTER
+    this library (its HIP runtime is then a second one)."""
+    if "torch" in sys.modules and not TORCH_LOADED_FIRST:
+        raise RuntimeError(
+            "pogs_amd was imported before torch: the two then run on separate HIP runtimes and a torch device "
+            "pointer is not valid here.  Import torch first, or set POGS_AMD_TORCH_PRELOAD=1.")
+
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -61,6 +75,7 @@ class PogsAmdStats(ctypes.Structure):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
         d["spec_hits"], d["spec_misses"] = self.reserved[0], self.reserved[1]
         d["collectives"] = int(self.reserved[2])   # all-reduce calls issued by the handle so far
+        d["comm_nranks"] = int(self.reserved[3])   # ranks of the communicator as RCCL reports them (0: no row shards)
         return d
 
 

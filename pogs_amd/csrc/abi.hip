@@ -93,19 +93,26 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// `h` (may be null): the handle the entry point works on.  An error inside a row-sharded solve
+// aborts the handle's communicator (SolverBase::on_error), so that the peers' next collective
+// fails or times out instead of waiting for this rank for ever.
 template <typename F>
-int guarded(F &&fn) {
+int guarded(F &&fn, PogsAmdSolver *h = nullptr) {
+  auto failed = [&](const char *what) {
+    g_last_error = what;
+    std::fprintf(stderr, "pogs_amd: %s\n", what);
+    try {
+      if (h && h->impl) h->impl->on_error();
+    } catch (...) {}
+    return POGS_ERROR;
+  };
   try {
     g_last_error.clear();
     return fn();
   } catch (const std::exception &e) {
-    g_last_error = e.what();
-    std::fprintf(stderr, "pogs_amd: %s\n", e.what());
-    return POGS_ERROR;
+    return failed(e.what());
   } catch (...) {
-    g_last_error = "unknown error";
-    std::fprintf(stderr, "pogs_amd: unknown error\n");
-    return POGS_ERROR;
+    return failed("unknown error");
   }
 }
 
@@ -298,7 +305,7 @@ int PogsAmdSolve(PogsAmdSolver *s, const void *f_a, const void *f_b, const void 
     FnHost g{g_a, g_b, g_c, g_d, g_e, g_h};
     return s->impl->solve(f, g, make_params(rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop), x,
                           y, l, mu, optval, final_iter);
-  });
+  }, s);
 }
 
 int PogsAmdBeginRun(PogsAmdSolver *s, const void *f_a, const void *f_b, const void *f_c, const void *f_d,
@@ -312,7 +319,7 @@ int PogsAmdBeginRun(PogsAmdSolver *s, const void *f_a, const void *f_b, const vo
     FnHost g{g_a, g_b, g_c, g_d, g_e, g_h};
     s->impl->begin_run(f, g, make_params(rho, abs_tol, rel_tol, max_iter, 0, adaptive_rho, gap_stop));
     return 0;
-  });
+  }, s);
 }
 
 int PogsAmdIterate(PogsAmdSolver *s, unsigned int iters, double *seconds, unsigned int *solves_completed) {
@@ -321,7 +328,7 @@ int PogsAmdIterate(PogsAmdSolver *s, unsigned int iters, double *seconds, unsign
     DeviceGuard guard(s->impl->device());
     s->impl->iterate(iters, seconds, solves_completed);
     return 0;
-  });
+  }, s);
 }
 
 int PogsAmdSetWarmStart(PogsAmdSolver *s, const void *x0, const void *l0) {

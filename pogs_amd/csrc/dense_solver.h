@@ -173,6 +173,7 @@ class DenseSolver final : public SolverBase {
 
   int dtype() const override { return sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64; }
   int device() const override { return ctx_.device; }
+  void on_error() override { ctx_.on_error(); }
   PogsAmdStats &stats() override { return ctx_.stats; }
 
   int solve(const FnHost &f, const FnHost &g, const SolveParams &p, void *x, void *y, void *l, void *mu,
@@ -1617,6 +1618,7 @@ class DenseSolver final : public SolverBase {
 
   void collect_stream_timer() {
     ctx_.stats.reserved[2] = static_cast<double>(ctx_.dist.collectives());   // all-reduce calls since creation
+    ctx_.stats.reserved[3] = static_cast<double>(ctx_.dist.comm_nranks());   // ranks as the communicator reports them
     if (!ctx_.stream_timer.enabled()) return;
     unsigned long long cnt = 0;
     ctx_.stats.stream_ms += ctx_.stream_timer.collect_ms(&cnt);

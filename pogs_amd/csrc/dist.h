@@ -51,6 +51,17 @@ class DistComm {
   template <typename T>
   void allreduce3(T *buf, size_t count, double *s1, size_t n1, double *s2, size_t n2, hipStream_t stream);
   unsigned long long collectives() const { return ncoll_; }   // all-reduce calls issued so far
+  // Ranks of the communicator as RCCL itself reports them (ncclCommCount); world() for the test
+  // transport, 0 when there is no communicator.
+  int comm_nranks() const;
+  // A collective that a peer never joined leaves this rank's stream inside the all-reduce kernel for
+  // ever.  abort() tears the communicator down (ncclCommAbort: the kernel returns, later calls on
+  // this handle fail); Ctx::wait_publish calls it when a publish does not arrive within
+  // POGS_AMD_COLL_TIMEOUT_S seconds (default 300), and the entry point returns POGS_ERROR.
+  void abort();
+  bool aborted() const { return aborted_; }
+  // "" or RCCL's description of an asynchronous error on the communicator (ncclCommGetAsyncError)
+  const char *async_error() const;
 
   static void unique_id(char *out);  // fresh id (rank 0)
 
@@ -62,6 +73,7 @@ class DistComm {
   double *pack_ = nullptr;  // fp64 staging of allreduce2 / allreduce3 (device)
   size_t pack_cap_ = 0;
   mutable unsigned long long ncoll_ = 0;
+  bool aborted_ = false;
 };
 
 }  // namespace pogs_amd

@@ -29,6 +29,9 @@ struct RcclApi {
   int (*GetUniqueId)(UniqueId *) = nullptr;
   int (*CommInitRank)(ncclComm_t *, int, UniqueId, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommAbort)(ncclComm_t) = nullptr;
+  int (*CommCount)(const ncclComm_t, int *) = nullptr;
+  int (*CommGetAsyncError)(ncclComm_t, int *) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
 };
@@ -51,6 +54,9 @@ RcclApi &api() {
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(sym("ncclCommAbort"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(sym("ncclCommCount"));
+    a.CommGetAsyncError = reinterpret_cast<decltype(a.CommGetAsyncError)>(sym("ncclCommGetAsyncError"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
   });
@@ -151,7 +157,9 @@ __global__ void __launch_bounds__(256) unpack_kernel(const double *in, size_t nv
 
 DistComm::~DistComm() {
   if (comm_) {
-    try { api().CommDestroy(comm_); } catch (...) {}
+    // (an aborted communicator is already gone; one whose collective may still be stuck is aborted,
+    // not destroyed: ncclCommDestroy would wait for the stuck kernel)
+    try { if (!aborted_) api().CommDestroy(comm_); } catch (...) {}
   }
   delete static_cast<std::shared_ptr<LocalGroup> *>(local_);
   if (pack_) (void)hipFree(pack_);
@@ -179,8 +187,31 @@ void DistComm::init(int rank, int world, const char *unique_id) {
   check(api().CommInitRank(&comm_, world, id, rank), "ncclCommInitRank");
 }
 
+int DistComm::comm_nranks() const {
+  if (local_) return world_;
+  if (!comm_ || aborted_) return 0;
+  int n = 0;
+  check(api().CommCount(comm_, &n), "ncclCommCount");
+  return n;
+}
+
+void DistComm::abort() {
+  if (comm_ && !aborted_) {
+    aborted_ = true;
+    try { (void)api().CommAbort(comm_); } catch (...) {}
+  }
+}
+
+const char *DistComm::async_error() const {
+  if (!comm_ || aborted_) return "";
+  int e = 0;
+  if (api().CommGetAsyncError(comm_, &e) != 0 || e == 0) return "";
+  return api().GetErrorString ? api().GetErrorString(e) : "asynchronous RCCL error";
+}
+
 void DistComm::reduce_raw(void *buf, size_t count, int dtype, hipStream_t stream) const {
   if (count == 0 || !active()) return;
+  if (aborted_) throw Error("the RCCL communicator of this handle was aborted (a collective timed out or failed)");
   ++ncoll_;
   if (local_) {
     LocalGroup &g = **static_cast<std::shared_ptr<LocalGroup> *>(local_);

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/pogs_amd.h"
@@ -222,10 +223,28 @@ struct Ctx {
   unsigned long long *host_seq_dev() const { return reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots); }
   const double *wait_publish(unsigned long long want) {
     unsigned long long *seqp = reinterpret_cast<unsigned long long *>(S_host.p + kNumSlots);
-    unsigned spins = 0, idle_seen = 0;
+    unsigned spins = 0, idle_seen = 0, checks = 0;
+    double t_wait0 = 0;
     while (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != want) {
       if (++spins == (1u << 14)) {   // ~ every few hundred microseconds: surface a failed stream
         spins = 0;
+        // Row shards: a peer that never joins a collective (it failed, or was killed) leaves this
+        // rank's stream inside the all-reduce for ever.  After coll_timeout_s without the publish
+        // (or as soon as RCCL reports an asynchronous error) the communicator is aborted and the
+        // call fails with POGS_ERROR instead of hanging.
+        if (dist.active() && (++checks & 255u) == 0) {
+          const double now = wall_s();
+          if (t_wait0 == 0) t_wait0 = now;
+          const char *ae = dist.async_error();
+          if (ae[0] || now - t_wait0 > coll_timeout_s()) {
+            const std::string why = ae[0] ? std::string("RCCL reported: ") + ae
+                                          : "no progress for " + std::to_string(static_cast<int>(coll_timeout_s())) +
+                                                " s inside a collective (a peer rank did not join it)";
+            dist.abort();
+            poisoned = true;
+            throw Error("row-sharded solve aborted: " + why);
+          }
+        }
         const hipError_t q = hipStreamQuery(stream);
         if (q == hipSuccess) {
           if (__atomic_load_n(seqp, __ATOMIC_ACQUIRE) == want) break;
@@ -267,6 +286,14 @@ struct Ctx {
     }
     return wait_publish(want);
   }
+  static double coll_timeout_s() {
+    static const double v = [] {
+      const char *e = std::getenv("POGS_AMD_COLL_TIMEOUT_S");
+      const double t = e ? std::atof(e) : 300.0;
+      return t > 0 ? t : 300.0;
+    }();
+    return v;
+  }
   bool poll_fetch = true;
   ScalarOverlay overlay;
   SumJob pending[kMaxSumJobs];
@@ -292,12 +319,21 @@ struct Ctx {
   }
   double tmark_last = 0;
   bool poisoned = false;   // set when an error left the stream / communicator in an unknown state
+  // an exception escaped a solve on this context: with row shards the peers are (or will be) inside
+  // a collective this rank no longer takes part in -- abort the communicator so that they fail too,
+  // and never hand this stream to another solver
+  void on_error() {
+    if (dist.active()) {
+      dist.abort();
+      poisoned = true;
+    }
+  }
   ~Ctx() {
     if (!stream) return;
     DeviceGuard guard(device);
     // a stream that faulted (or was left inside a failed collective) must not be handed to the
     // next solver: recycle it only if it drains cleanly
-    const bool healthy = hipStreamSynchronize(stream) == hipSuccess && !poisoned;
+    const bool healthy = !poisoned && hipStreamSynchronize(stream) == hipSuccess;
     if (ctx_recycle() && healthy) {
       std::lock_guard<std::mutex> lock(ctx_pool_mutex());
       CtxResources r;
@@ -551,6 +587,8 @@ struct SolverBase {
   virtual void project(const void *x0, const void *y0, double tol, void *x, void *y) = 0;
   virtual void mul(char trans, double alpha, const void *x, double beta, void *y) = 0;
   virtual PogsAmdStats &stats() = 0;
+  // an exception left one of the entry points: see guarded() in abi.hip
+  virtual void on_error() {}
 };
 
 }  // namespace pogs_amd

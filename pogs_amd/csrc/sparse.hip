@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 #include "cg_fused.h"
@@ -403,10 +404,14 @@ __global__ void fill_transpose_kernel(const T *val, const int *ind, const int *p
   }
 }
 
-// Sorts each segment by (index, value position is irrelevant: indices are unique
-// unless the input repeats an entry) with an all-ascending bitonic network, so the
-// transposed matrix is exactly what the reference's stable csr2csc builds
-// (gsl_spmat.h:32-55).  One workgroup per segment; LDS when it fits.
+// Sorts each segment by index with an all-ascending bitonic network, so the transposed matrix is
+// exactly what the reference's stable csr2csc builds (gsl_spmat.h:32-55).  An input that repeats
+// an entry (the same column twice in a row: the reference's gather product simply adds both,
+// gsl_spblas.h:16-40) leaves ties, which the scatter above delivers in no particular order: they
+// are broken by the value's bit pattern, so the stored order -- and with it every sum -- is the
+// same from run to run (the reference's order among such ties is their CSR order; the two differ
+// only in the association of three or more equal-index terms).  One workgroup per segment; LDS
+// when it fits.
 template <typename T>
 __global__ void __launch_bounds__(256) sort_segments_kernel(const int *ptr, int nseg, int *ind, T *val) {
   constexpr int CAP = 2048;
@@ -430,9 +435,17 @@ __global__ void __launch_bounds__(256) sort_segments_kernel(const int *ptr, int 
           const int l = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);
           if (l > i && l < len) {  // elements >= len act as +inf and never move
             const int a = ki[i], b = ki[l];
-            if (a > b) {
+            const T va = kv[i], vb = kv[l];
+            bool swap = a > b;
+            if (a == b) {
+              typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type ba, bb;
+              __builtin_memcpy(&ba, &va, sizeof(T));
+              __builtin_memcpy(&bb, &vb, sizeof(T));
+              swap = ba > bb;
+            }
+            if (swap) {
               ki[i] = b; ki[l] = a;
-              const T tv = kv[i]; kv[i] = kv[l]; kv[l] = tv;
+              kv[i] = vb; kv[l] = va;
             }
           }
         }
@@ -549,6 +562,7 @@ class SparseSolver final : public SolverBase {
 
   int dtype() const override { return sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64; }
   int device() const override { return ctx_.device; }
+  void on_error() override { ctx_.on_error(); }
   PogsAmdStats &stats() override { return ctx_.stats; }
 
   int solve(const FnHost &f, const FnHost &g, const SolveParams &p, void *x, void *y, void *l, void *mu,
@@ -1443,6 +1457,7 @@ class SparseSolver final : public SolverBase {
 
   void collect_timer() {
     ctx_.stats.reserved[2] = static_cast<double>(ctx_.dist.collectives());   // all-reduce calls since creation
+    ctx_.stats.reserved[3] = static_cast<double>(ctx_.dist.comm_nranks());   // ranks as the communicator reports them
     ctx_.stats.matvecs += timed_spmvs_;
     if (ctx_.stream_timer.enabled()) {
       unsigned long long cnt = 0;

@@ -313,6 +313,8 @@ class Solver:
             assert len(uid) == _lib.UNIQUE_ID_BYTES
             # (a c_char array field reads back as an immutable bytes copy: write through the address)
             ctypes.memmove(ctypes.addressof(dist_s) + _lib.PogsAmdDist.unique_id.offset, uid, _lib.UNIQUE_ID_BYTES)
+        if device_ptr:
+            _lib.check_device_pointer_interop()
         self.sparse = (not device_ptr) and HAS_SCIPY and sp.issparse(A)
         if self.sparse:
             A_csr = sp.csr_matrix(A, dtype=self.dtype)

@@ -72,3 +72,25 @@ def dense_lasso_rows(m, n, seed=0, density=0.1, noise=0.1, chunk=4000):
         # (element-wise product + numpy's own pairwise sum: no BLAS, so no dependence on its threads)
         b[r0:r1] = (blk[:, nz].astype(np.float64) * x_true[nz]).sum(axis=1) + noise * rng.standard_normal(r1 - r0)
     return A, b, x_true
+
+
+def dense_logistic_rows(m, n, seed=0, density=0.3, logit_std=None, chunk=4000):
+    """The logistic recipe (python/benchmarks/problems/logistic.py:27-37 without its bias term:
+    w_true ~ N(0,1) on 30 % of the entries, labels 2 (U < sigma(A w)) - 1) generated in row chunks
+    with no BLAS in the generator: the same bits on every machine for a given (m, n, seed, chunk).
+    logit_std=None is the recipe as SURVEY.md section 8(d) states it (nearly separable at large n);
+    a value rescales w_true so that std(A w) = logit_std."""
+    rng = np.random.default_rng(seed)
+    w = rng.standard_normal(n) * (rng.random(n) < density)
+    if logit_std is not None:
+        w *= logit_std / np.sqrt(max(np.sum(w * w), 1e-300))
+    A = np.empty((m, n), np.float32)
+    lab = np.empty(m, np.float64)
+    nz = np.flatnonzero(w)
+    for r0 in range(0, m, chunk):
+        r1 = min(m, r0 + chunk)
+        blk = rng.standard_normal((r1 - r0, n), dtype=np.float32)
+        A[r0:r1] = blk
+        z = (blk[:, nz].astype(np.float64) * w[nz]).sum(axis=1)
+        lab[r0:r1] = 2.0 * (rng.random(r1 - r0) < 1.0 / (1.0 + np.exp(-z))) - 1.0
+    return A, lab, w

@@ -1,6 +1,5 @@
 import os, sys, subprocess, tempfile, time, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
-os.environ["POGS_AMD_NO_TORCH_PRELOAD"] = "1"
 from pogs_amd import graph as G, synth
 m, n, maxit = int(sys.argv[1]), 10000, int(sys.argv[2])
 A, b, _ = synth.dense_lasso_rows(m, n, seed=2024)

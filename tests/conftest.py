@@ -18,6 +18,9 @@ for p in (ROOT, os.path.dirname(__file__)):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # the GPU tests hand torch device pointers to the library: torch has to bring its HIP runtime
+    # first (pogs_amd/_lib.py: the package does not import torch on its own)
+    os.environ.setdefault("POGS_AMD_TORCH_PRELOAD", "1")
     import oracle_binding
 
     oracle_binding.build_oracle()

@@ -52,7 +52,7 @@ def _one_pass_forced_off():
     return os.environ.get("POGS_AMD_FUSED") == "0" or bool(os.environ.get("POGS_AMD_XL_LIMIT"))
 
 
-def _xtol32(got_iters, want_iters, loose=3e-4):
+def _xtol32(got_iters, want_iters, loose=2e-4):
     """fp32 bound on ||dx|| / ||x|| against the oracle.  When both stop at the same iteration they
     walked the same trajectory and differ by rounding only -- measured 2e-7 .. 1.2e-6 on every
     problem family (scripts/parity_report.py; the compiled reference differs from ITSELF by the
@@ -60,7 +60,8 @@ def _xtol32(got_iters, want_iters, loose=3e-4):
     so the bound is 2e-5.  When they stop a few iterations apart (a rounding-sized difference in a
     residual next to its threshold) the iterates differ by what ADMM still moves per iteration at
     that point, which the stopping rule itself puts at ~1e-4: the north-star tolerance, with the
-    number of iterations apart as the factor, capped at `loose`."""
+    number of iterations apart as the factor, capped at `loose` = 2e-4 (twice the north-star
+    tolerance; profiles/r03_fp32_spread.txt has the reference-vs-reference distances behind it)."""
     d = abs(int(got_iters) - int(want_iters))
     return 2e-5 if d == 0 else min(loose, 1e-4 * (1 + d))
 
@@ -609,7 +610,7 @@ def test_512_thread_plan_one_pass_iteration(dtype, shape, monkeypatch):
     assert st["spec_hits"] > 0.8 * got["iterations"] and st_ref["spec_hits"] == 0   # one-pass vs two-pass
     assert st["matvecs"] < 0.7 * st_ref["matvecs"]
     assert abs(int(got["iterations"]) - int(ref["iterations"])) <= (1 if dtype == np.float64 else max(3, ref["iterations"] // 10))
-    assert relerr(got["x"], ref["x"]) < _tol(dtype, 1e-7, _xtol32(got["iterations"], ref["iterations"], loose=5e-4))
+    assert relerr(got["x"], ref["x"]) < _tol(dtype, 1e-7, _xtol32(got["iterations"], ref["iterations"]))
     assert got["optval"] == pytest.approx(ref["optval"], rel=_tol(dtype, 1e-8, 2e-4))
 
 
@@ -948,7 +949,7 @@ def test_windowed_passes_on_small_matrices(dtype, shape, cgls, monkeypatch):
     # (fp32: the window partial sums round differently, the solve may stop an iteration apart;
     # measured with equal counts: 1.2e-6, scripts/parity_report.py)
     # the dense CGLS option is inexact by construction (projection tolerance 1e-2 sqrt(r)): 1e-3
-    xt = 1e-3 if cgls else _xtol32(got["iterations"], want["iterations"], loose=1e-3)
+    xt = 1e-3 if cgls else _xtol32(got["iterations"], want["iterations"])
     assert relerr(got["x"], want["x"]) < _tol(dtype, 1e-6, xt)
     assert got["optval"] == pytest.approx(want["optval"], rel=_tol(dtype, 1e-7, 5e-3))
 
@@ -983,7 +984,7 @@ def test_fp16_split_gram_is_as_exact_as_the_fp32_product(shape, monkeypatch):
     rb, rf = out["f16"][1], out["fp32"][1]
     assert rb["status"] == rf["status"] == 0
     assert abs(int(rb["iterations"]) - int(rf["iterations"])) <= max(3, rf["iterations"] // 10)
-    assert relerr(rb["x"], rf["x"]) < _xtol32(rb["iterations"], rf["iterations"], loose=5e-4)
+    assert relerr(rb["x"], rf["x"]) < _xtol32(rb["iterations"], rf["iterations"])
 
 
 @pytest.mark.gpu

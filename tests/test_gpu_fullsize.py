@@ -26,10 +26,12 @@ def _torch():
     return torch
 
 
-def test_c2_dense_lasso_100000x10000_kkt_and_operator_properties():
-    """configs[1]: dense fp32 lasso 100000 x 10000, A resident in HBM (device pointer)."""
+def test_c2_dense_lasso_100000x10000_kkt_and_operator_properties(ref_farm):
+    """configs[1]: dense fp32 lasso 100000 x 10000, A resident in HBM (device pointer).
+    (First test of the module: it also starts the module's live reference runs in the background.)"""
     torch = _torch()
     pogs = _pogs()
+    ref_farm.start()
     m, n = 100000, 10000
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev)
@@ -133,6 +135,47 @@ def test_c4_sparse_lasso_2e6x5e5_kkt():
     obj = 0.5 * np.sum((y - b) ** 2) + LAM * np.abs(x).sum()
     assert r["optval"] == pytest.approx(obj, rel=5e-3)
     assert 0.5 * np.sum((Ax - b) ** 2) + LAM * np.abs(x).sum() < 0.5 * np.sum((A @ xt - b) ** 2) + LAM * np.abs(xt).sum()
+
+
+def test_c2_and_c4_solves_are_bitwise_reproducible():
+    """Every reduction of the engine has a fixed order (column partials by workgroup, scalar records
+    by block, CSR / column-block order inside a row), so a solve is a pure function of its inputs:
+    fresh handles on the same matrix give identical bits in x, y, l and the same iteration count --
+    at configs[1] (one-pass iteration with rho speculation, fp16-split Gram) and at configs[3]
+    (device-resident CGLS loop, tiled SpMV)."""
+    torch = _torch()
+    pogs = _pogs()
+    A, f, gg = _c2_problem(torch, pogs)
+    runs = [_engine_solve(pogs, A, f, gg, {}) for _ in range(3)]
+    del A
+    for r in runs[1:]:
+        assert r["iterations"] == runs[0]["iterations"] and r["status"] == 0
+        for k in "xyl":
+            assert np.array_equal(r[k], runs[0][k]), ("c2", k)
+    import scipy.sparse as sp
+
+    m, n, k = 2000000, 500000, 50
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    cols, _ = torch.sort(torch.randint(0, n, (m, k), generator=g, device=dev, dtype=torch.int32), dim=1)
+    vals = torch.randn((m, k), generator=g, device=dev, dtype=torch.float32)
+    A = sp.csr_matrix((vals.cpu().numpy().ravel(), cols.cpu().numpy().ravel(), np.arange(0, m * k + 1, k, dtype=np.int32)),
+                      shape=(m, n))
+    del cols, vals
+    A.sum_duplicates()
+    rng = np.random.default_rng(0)
+    b = A @ (rng.standard_normal(n) * (rng.random(n) < 0.05)) + 0.1 * rng.standard_normal(m)
+    f, gg = pogs.graph.lasso_functions(b, LAM, n)
+    runs = []
+    for _ in range(2):
+        with pogs.Solver(A, dtype=np.float32) as s:
+            runs.append(s.solve(f, gg))
+            runs.append(s.solve(f, gg))       # and a second solve on the same handle
+    for r in runs[1:]:
+        assert r["iterations"] == runs[0]["iterations"] and r["status"] == 0
+        for kk in "xyl":
+            assert np.array_equal(r[kk], runs[0][kk]), ("c4", kk)
 
 
 def test_c4_solution_matches_openmp_oracle_at_full_size():
@@ -555,26 +598,11 @@ def test_c2_solution_matches_compiled_reference():
         assert np.linalg.norm(live["x"].astype(np.float64) - x32) <= 2e-5 * np.linalg.norm(x32)
 
 
-@pytest.mark.parametrize("family", ["lasso", "ridge", "elastic_net", "logistic", "huber", "svm", "nonneg_ls"])
-def test_every_solve_family_against_the_live_reference_at_60000x2000(family):
-    """Each of the seven solve_* families (python/pogs/graph.py:393-743) at 60000 x 2000 fp32 against
-    the compiled reference run live on this box, as PogsS (fp32) AND as PogsD on the widened matrix
-    (fp64) -- the small-size family tests go through the oracle; this closes the chain engine ->
-    reference at a size where the one-pass kernels, the fp16-split Gram product and the
-    Sinkhorn-Knopp shortcut are all active.  Bars (north star): x within 1e-4 of both reference
-    solutions; iterations within 10 % of the fp64 reference's and not above the fp32 reference's by
-    more than that (on ridge / elastic net / huber the fp32 build needs 30-70 % more iterations than
-    its fp64 build -- its sequential fp32 sums over 60000 rows, see the C2 test -- and the engine
-    follows the fp64 count); optval within 1e-4 of the fp64 reference's on equal counts (the fp32
-    build adds its 60000 function values in fp32: its own optval is 1e-4 off on logistic).
-    svm: the reference does not converge on a hinge loss of this size within max_iter (status 3 for
-    any lambda tried), so both sides run 300 iterations and the iterates are compared."""
-    import oracle_binding as ob
+_DENSE_FAMILIES = ["lasso", "ridge", "elastic_net", "logistic", "huber", "svm", "nonneg_ls"]
+_SPARSE_FAMILIES = ["lasso", "ridge", "elastic_net", "logistic", "huber", "nonneg_ls"]
 
-    if not ob.ref_available():
-        pytest.skip("compiled reference not present (oracle/_ref is built in the build container)")
-    pogs = _pogs()
-    G = pogs.graph
+
+def _dense_family_problem(G, family):
     m, n = 60000, 2000
     rng = np.random.default_rng(101)
     A = rng.standard_normal((m, n), dtype=np.float32)
@@ -596,15 +624,133 @@ def test_every_solve_family_against_the_live_reference_at_60000x2000(family):
             "huber": lambda: G.huber_functions(b, 1.0, 0.5, n),
             "svm": lambda: G.svm_functions(b, 1.0, n),
             "nonneg_ls": lambda: G.nonneg_ls_functions(b, n)}[family]()
-    soa = lambda fv: {k: getattr(fv, k) for k in "habcde"}  # noqa: E731
-    max_iter = 300 if family == "svm" else 2500
-    want_status = 3 if family == "svm" else 0
-    half = max(1, ob.ref_threads() // 2)          # the two reference builds run side by side
-    run32 = ob.ref_start(A, soa(f), soa(g), dtype=np.float32, threads=half, max_iter=max_iter)
-    run64 = ob.ref_start(A.astype(np.float64), soa(f), soa(g), dtype=np.float64, threads=half, max_iter=max_iter)
+    return A, f, g, (300 if family == "svm" else 2500), (3 if family == "svm" else 0)
+
+
+def _sparse_family_problem(G, family):
+    from pogs_amd import synth
+
+    m, n = 100000, 20000
+    A, b, xt = synth.csr_lasso(m, n, 20, seed=7, dtype=np.float32)
+    rng = np.random.default_rng(8)
+    if family == "logistic":
+        z = A.astype(np.float64) @ xt
+        b = 2.0 * (rng.random(m) < 1.0 / (1.0 + np.exp(-2.0 * z / z.std()))) - 1.0
+    elif family == "nonneg_ls":
+        b = A.astype(np.float64) @ np.abs(xt) + 0.1 * rng.standard_normal(m)
+    elif family == "huber":
+        b = b.copy()
+        b[rng.random(m) < 0.02] += 20.0
+    f, g = {"lasso": lambda: G.lasso_functions(b, 0.1 * float(np.max(np.abs(A.T @ b))), n),
+            "ridge": lambda: G.ridge_functions(b, 5.0, n),
+            "elastic_net": lambda: G.elastic_net_functions(b, 5.0, 2.0, n),
+            "logistic": lambda: G.logistic_functions(b, 0.01, n),
+            "huber": lambda: G.huber_functions(b, 1.0, 0.5, n),
+            "nonneg_ls": lambda: G.nonneg_ls_functions(b, n)}[family]()
+    return A, f, g
+
+
+def _c3_problem(torch, pogs):
+    m, n = 200000, 5000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float32)
+    w = torch.randn(n, generator=g, device=dev) * (torch.rand(n, generator=g, device=dev) < 0.3)
+    w = w * (2.0 / torch.sqrt((w * w).sum()))
+    lab = (2.0 * (torch.rand(m, generator=g, device=dev) < torch.sigmoid(A @ w)) - 1.0).double().cpu().numpy()
+    f, gg = pogs.graph.logistic_functions(lab, 0.01, n)
+    return A, f, gg
+
+
+_soa = lambda fv: {k: getattr(fv, k) for k in "habcde"}  # noqa: E731
+
+
+class _RefFarm:
+    """The live reference runs of this module, ALL started together in the background the first time
+    one of them is asked for (27 subprocesses of the compiled reference, two BLAS threads each; the
+    reference is all but single-threaded on the GPU box's host anyway,
+    profiles/r03_ref_cpu_diagnosis.md): the module's GPU tests run while they work, and a test that
+    needs a reference solution collects it.  One after the other they cost the suite five minutes."""
+
+    def __init__(self):
+        self.runs, self.problems, self.started = {}, {}, False
+
+    def start(self):
+        import oracle_binding as ob
+
+        if self.started:
+            return
+        self.started = True
+        pogs, torch = _pogs(), _torch()
+        G = pogs.graph
+        A, f, gg = _c3_problem(torch, pogs)
+        self.runs["c3"] = (ob.ref_start(A.cpu().numpy(), _soa(f), _soa(gg), dtype=np.float32, verbose=1, threads=2),)
+        del A
+        for fam in _DENSE_FAMILIES:
+            A, f, g, max_iter, _ = _dense_family_problem(G, fam)
+            self.runs["dense:" + fam] = (
+                ob.ref_start(A, _soa(f), _soa(g), dtype=np.float32, threads=2, max_iter=max_iter),
+                ob.ref_start(A.astype(np.float64), _soa(f), _soa(g), dtype=np.float64, threads=2, max_iter=max_iter))
+        for fam in _SPARSE_FAMILIES:
+            A, f, g = _sparse_family_problem(G, fam)
+            self.runs["sparse:" + fam] = (ob.ref_start(A, _soa(f), _soa(g), dtype=np.float32, threads=1),
+                                          ob.ref_start(A.astype(np.float64), _soa(f), _soa(g), dtype=np.float64, threads=1))
+
+    def collect(self, key, timeout=1200):
+        self.start()
+        return tuple(r.finish(timeout=timeout) for r in self.runs.pop(key))
+
+    def close(self):
+        for runs in self.runs.values():
+            for r in runs:
+                try:
+                    r.proc.kill()
+                    r.proc.communicate()
+                except Exception:
+                    pass
+                try:
+                    r.td.cleanup()
+                except Exception:
+                    pass
+        self.runs = {}
+
+
+@pytest.fixture(scope="module")
+def ref_farm():
+    import oracle_binding as ob
+
+    farm = _RefFarm()
+    if not ob.ref_available():
+        farm.started = True      # nothing to start: the tests that need a reference skip
+    yield farm
+    farm.close()
+
+
+@pytest.mark.parametrize("family", _DENSE_FAMILIES)
+def test_every_solve_family_against_the_live_reference_at_60000x2000(family, ref_farm):
+    """Each of the seven solve_* families (python/pogs/graph.py:393-743) at 60000 x 2000 fp32 against
+    the compiled reference run live on this box, as PogsS (fp32) AND as PogsD on the widened matrix
+    (fp64) -- the small-size family tests go through the oracle; this closes the chain engine ->
+    reference at a size where the one-pass kernels, the fp16-split Gram product and the
+    Sinkhorn-Knopp shortcut are all active.  Bars (north star): x within 1e-4 of both reference
+    solutions; iterations within 10 % of the fp64 reference's and not above the fp32 reference's by
+    more than that (on ridge / elastic net / huber the fp32 build needs 30-70 % more iterations than
+    its fp64 build -- its sequential fp32 sums over 60000 rows, see the C2 test -- and the engine
+    follows the fp64 count); optval within 1e-4 of the fp64 reference's on equal counts (the fp32
+    build adds its 60000 function values in fp32: its own optval is 1e-4 off on logistic).
+    svm: the reference does not converge on a hinge loss of this size within max_iter (status 3 for
+    any lambda tried), so both sides run 300 iterations and the iterates are compared.
+    (The reference runs come from the module's background farm, see _RefFarm.)"""
+    import oracle_binding as ob
+
+    if not ob.ref_available():
+        pytest.skip("compiled reference not present (oracle/_ref is built in the build container)")
+    pogs = _pogs()
+    G = pogs.graph
+    A, f, g, max_iter, want_status = _dense_family_problem(G, family)
     got = G._solve_graph_form(A, f, g, 1e-4, 1e-4, max_iter, 0, 1.0, dtype=np.float32)
-    ref32 = run32.finish(timeout=900)
-    ref64 = run64.finish(timeout=900)
+    ref32, ref64 = ref_farm.collect("dense:" + family)
     it, it32, it64 = got["iterations"] + 1, ref32["iterations"] + 1, ref64["iterations"] + 1
     x = got["x"].astype(np.float64)
     rel = lambda r: np.linalg.norm(x - r["x"].astype(np.float64)) / max(np.linalg.norm(r["x"].astype(np.float64)), 1e-300)  # noqa: E731
@@ -624,42 +770,22 @@ def test_every_solve_family_against_the_live_reference_at_60000x2000(family):
         assert rel_o <= (1e-4 if it == it64 else 1e-2)
 
 
-@pytest.mark.parametrize("family", ["lasso", "ridge", "elastic_net", "logistic", "huber", "nonneg_ls"])
-def test_sparse_solve_families_against_the_live_reference_at_100000x20000(family):
+@pytest.mark.parametrize("family", _SPARSE_FAMILIES)
+def test_sparse_solve_families_against_the_live_reference_at_100000x20000(family, ref_farm):
     """The sparse path (PogsSparseS: CSR + transposed copy, CGLS projector; matrix_sparse.cpp,
     projector_cgls.cpp, cgls.h) for six solve_* families at 100000 x 20000, 2e6 non-zeros, fp32,
     against the compiled reference's fp32 and fp64 builds run live (3-10 s each).  Same bars as the
     dense family test; C4 itself is pinned to the OpenMP oracle above (the reference is
     single-threaded on this path and needs tens of minutes at 1e8 non-zeros)."""
     import oracle_binding as ob
-    from pogs_amd import synth
 
     if not ob.ref_available():
         pytest.skip("compiled reference not present (oracle/_ref is built in the build container)")
     pogs = _pogs()
     G = pogs.graph
-    m, n = 100000, 20000
-    A, b, xt = synth.csr_lasso(m, n, 20, seed=7, dtype=np.float32)
-    rng = np.random.default_rng(8)
-    if family == "logistic":
-        z = A.astype(np.float64) @ xt
-        b = 2.0 * (rng.random(m) < 1.0 / (1.0 + np.exp(-2.0 * z / z.std()))) - 1.0
-    elif family == "nonneg_ls":
-        b = A.astype(np.float64) @ np.abs(xt) + 0.1 * rng.standard_normal(m)
-    elif family == "huber":
-        b = b.copy()
-        b[rng.random(m) < 0.02] += 20.0
-    f, g = {"lasso": lambda: G.lasso_functions(b, 0.1 * float(np.max(np.abs(A.T @ b))), n),
-            "ridge": lambda: G.ridge_functions(b, 5.0, n),
-            "elastic_net": lambda: G.elastic_net_functions(b, 5.0, 2.0, n),
-            "logistic": lambda: G.logistic_functions(b, 0.01, n),
-            "huber": lambda: G.huber_functions(b, 1.0, 0.5, n),
-            "nonneg_ls": lambda: G.nonneg_ls_functions(b, n)}[family]()
-    soa = lambda fv: {k: getattr(fv, k) for k in "habcde"}  # noqa: E731
-    run32 = ob.ref_start(A, soa(f), soa(g), dtype=np.float32, threads=2)
-    run64 = ob.ref_start(A.astype(np.float64), soa(f), soa(g), dtype=np.float64, threads=2)
+    A, f, g = _sparse_family_problem(G, family)
     got = G._solve_graph_form(A, f, g, 1e-4, 1e-4, 2500, 0, 1.0, dtype=np.float32)
-    ref32, ref64 = run32.finish(timeout=900), run64.finish(timeout=900)
+    ref32, ref64 = ref_farm.collect("sparse:" + family)
     it, it32, it64 = got["iterations"] + 1, ref32["iterations"] + 1, ref64["iterations"] + 1
     x = got["x"].astype(np.float64)
     rel = lambda r: np.linalg.norm(x - r["x"].astype(np.float64)) / max(np.linalg.norm(r["x"].astype(np.float64)), 1e-300)  # noqa: E731
@@ -725,9 +851,10 @@ def test_wide_10000x100000_solution_matches_compiled_reference():
         assert abs(r["optval"] - float(fx["optval_fp64"])) <= 1e-4 * float(fx["optval_fp64"])
 
 
-def test_c3_solution_matches_compiled_reference():
+def test_c3_solution_matches_compiled_reference(ref_farm):
     """configs[2] at full size (200000 x 5000 logistic, logits with std 2) against the compiled
-    reference on the same inputs (measured: ||dx|| / ||x|| = 2.3e-5, optval 7e-5, 188 vs 184 iterations)."""
+    reference on the same inputs (measured: ||dx|| / ||x|| = 2.3e-5, optval 7e-5, 188 vs 184 iterations).
+    (The reference run comes from the module's background farm, see _RefFarm.)"""
     import oracle_binding as ob
 
     if not ob.ref_available():
@@ -735,16 +862,8 @@ def test_c3_solution_matches_compiled_reference():
     torch = _torch()
     pogs = _pogs()
     m, n = 200000, 5000
-    dev = torch.device("cuda:0")
-    g = torch.Generator(device=dev)
-    g.manual_seed(0)
-    A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float32)
-    w = torch.randn(n, generator=g, device=dev) * (torch.rand(n, generator=g, device=dev) < 0.3)
-    w = w * (2.0 / torch.sqrt((w * w).sum()))
-    lab = (2.0 * (torch.rand(m, generator=g, device=dev) < torch.sigmoid(A @ w)) - 1.0).double().cpu().numpy()
-    f, gg = pogs.graph.logistic_functions(lab, 0.01, n)
-    soa = lambda fv: {k: getattr(fv, k) for k in "habcde"}  # noqa: E731
-    run = ob.ref_start(A.cpu().numpy(), soa(f), soa(gg), dtype=np.float32, verbose=1)
+    ref_farm.start()
+    A, f, gg = _c3_problem(torch, pogs)
     r = _engine_solve(pogs, A, f, gg, {})
     # BASELINE.json words configs[2] "(... CGLS projector)": the reference's dense entry point only
     # has the direct projector (src/interface_c/pogs_c.cpp:19-20), the engine offers both -- the
@@ -754,7 +873,7 @@ def test_c3_solution_matches_compiled_reference():
     with pogs.Solver(A.data_ptr(), dtype=np.float32, shape=(m, n), device_ptr=True, projector=L.PROJ_CGLS) as s:
         rc = s.solve(f, gg)
     del A
-    ref = run.finish(timeout=900)
+    (ref,) = ref_farm.collect("c3")
     _assert_matches_reference(r, ref, "c3 defaults")
     xr = ref["x"].astype(np.float64)
     rel_c = np.linalg.norm(rc["x"].astype(np.float64) - xr) / np.linalg.norm(xr)

@@ -174,6 +174,95 @@ def test_csc_input_through_raw_abi():
     assert relerr(x, want["x"]) < 1e-6
 
 
+def _messy_csr(m, n, per_row, seed):
+    """CSR arrays the reference accepts and scipy would canonicalise away: column indices in random
+    order inside each row, and repeated (row, column) entries left un-summed (the reference's product
+    is a plain gather over ptr / ind, src/cpu/include/gsl/gsl_spblas.h:16-40: indifferent to both)."""
+    rng = np.random.default_rng(seed)
+    ptr, ind, val = [0], [], []
+    for i in range(m):
+        k = int(rng.integers(0, 2 * per_row))
+        c = rng.integers(0, n, size=k)
+        if k >= 3:
+            c[1] = c[0]                      # a duplicate
+            if i % 5 == 0:
+                c[2] = c[0]                  # ... sometimes a triple
+        rng.shuffle(c)
+        ind += list(c)
+        val += list(rng.standard_normal(k))
+        ptr.append(len(ind))
+    return np.array(val), np.array(ptr, np.int32), np.array(ind, np.int32)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("order", ["csr", "csc"])
+def test_unsorted_indices_and_unsummed_duplicates_through_raw_abi(dtype, order):
+    """"int32 indices (unsorted allowed)".  PogsSparseD/S fed a matrix with
+    shuffled column indices and repeated entries, as CSR and as CSC, against the oracle run on the
+    very same arrays (and the compiled reference where it is available)."""
+    pogs = _pogs()
+    from pogs_amd import _lib
+
+    m, n = 2500, 700
+    if order == "csr":
+        val, ptr, ind = _messy_csr(m, n, 9, seed=21)
+        A_raw = sp.csr_matrix((val.astype(dtype), ind, ptr), shape=(m, n))       # kept as given: no sum, no sort
+        assert not A_raw.has_canonical_format
+    else:
+        val, ptr, ind = _messy_csr(n, m, 30, seed=22)                             # the rows of A^T
+        A_raw = sp.csc_matrix((val.astype(dtype), ind, ptr), shape=(m, n))
+    A_canon = sp.csr_matrix(A_raw.astype(np.float64)).copy()
+    A_canon.sum_duplicates()
+    rng = np.random.default_rng(23)
+    b = A_canon @ (rng.standard_normal(n) * (rng.random(n) < 0.2)) + 0.1 * rng.standard_normal(m)
+    f, g = pogs.graph.lasso_functions(b, 0.1, n)
+    fa, ga = f.arrays(dtype), g.arrays(dtype)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    x, y, l = np.zeros(n, dtype), np.zeros(m, dtype), np.zeros(m, dtype)
+    real = ctypes.c_double if dtype == np.float64 else ctypes.c_float
+    optval, fi = real(), ctypes.c_uint()
+    data = np.ascontiguousarray(val.astype(dtype))
+    fn = _lib.lib.PogsSparseD if dtype == np.float64 else _lib.lib.PogsSparseS
+    st = fn(1 if order == "csr" else 0, m, n, len(data), p(data), p(ptr), p(ind), *[p(fa[k]) for k in "abcdeh"],
+            *[p(ga[k]) for k in "abcdeh"], 1.0, 1e-4, 1e-4, 2500, 0, 1, 1, p(x), p(y), p(l),
+            ctypes.cast(ctypes.byref(optval), ctypes.c_void_p), ctypes.cast(ctypes.byref(fi), ctypes.c_void_p))
+    assert st == 0, _lib.last_error()
+    # the oracle on the same arrays (CSR as given; for CSC the oracle takes the equivalent raw CSR of A)
+    A_or = A_raw if order == "csr" else sp.csr_matrix((val.astype(dtype), ind, ptr), shape=(n, m)).T.tocsr()
+    want = ob.oracle_solve(A_or, soa(f), soa(g), dtype=dtype)
+    assert want["status"] == 0
+    d_it = abs(int(fi.value) - int(want["iterations"]))
+    assert d_it <= (1 if dtype == np.float64 else 3)
+    tol = 1e-6 if dtype == np.float64 else (2e-5 if d_it == 0 else 1e-4 * (1 + d_it))
+    assert relerr(x, want["x"]) < tol
+    assert float(optval.value) == pytest.approx(want["optval"], rel=1e-6 if dtype == np.float64 else 2e-4)
+    # and the canonical form of the same matrix gives the same answer: duplicates ARE summed by the product
+    canon = pogs._solve_graph_form(A_canon.astype(dtype), f, g, dtype=dtype)
+    assert relerr(x, canon["x"]) < (1e-6 if dtype == np.float64 else 2e-4)
+    if ob.ref_available() and order == "csr":
+        ref = ob.ref_solve(A_raw, soa(f), soa(g), dtype=dtype)
+        assert ref["status"] == 0 and abs(int(ref["iterations"]) - int(fi.value)) <= (1 if dtype == np.float64 else 3)
+        assert relerr(x, ref["x"]) < (1e-6 if dtype == np.float64 else 1e-4)
+
+
+def test_duplicate_entries_give_the_same_bits_run_to_run():
+    """The device transpose delivers repeated entries of a column in no particular order; the sort
+    breaks those ties by value, so two handles on the same input hold the same bits."""
+    pogs = _pogs()
+    from pogs_amd import _lib
+
+    m, n = 3000, 500
+    val, ptr, ind = _messy_csr(m, n, 12, seed=31)
+    A = sp.csr_matrix((val.astype(np.float32), ind, ptr), shape=(m, n))
+    rng = np.random.default_rng(32)
+    v = rng.standard_normal(m).astype(np.float32)
+    outs = []
+    for _ in range(3):
+        with pogs.Solver(A, dtype=np.float32) as s:   # (scipy keeps the arrays as given: no sum, no sort)
+            outs.append(s.mul("t", 1.0, v, 0.0, np.zeros(n, np.float32)))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 def test_sparse_warm_start_matches_oracle():
     """Warm start (pogs.cpp:144-156) on the CSR + CGLS path."""
     pogs = _pogs()
