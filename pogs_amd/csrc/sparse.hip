@@ -818,6 +818,17 @@ class SparseSolver final : public SolverBase {
     const long long ntiles = static_cast<long long>(nrr) * ncb;
     const long long nq = ntiles * rr_rows;
     if (ntiles >= (1LL << 30) || nq >= (1LL << 31)) return;
+    {
+      // The plan keeps 8 bytes per (row, column block) pair (count, stream offset, fill cursor) --
+      // on a matrix with many column blocks and few non-zeros per row that outweighs the matrix
+      // itself (5e6 x 5e6: 272 blocks x 5e6 rows x 8 B = 10 GB).  Beyond 4x the CSR bytes, or half of
+      // what the device has free, the plain CSR kernel stays (the same exit as a padding blow-up).
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+      const double tmp_bytes = 8.0 * static_cast<double>(nq);
+      const double csr_bytes = static_cast<double>(M.nnz) * (sizeof(T) + 4.0);
+      if (tmp_bytes > 4.0 * csr_bytes + 64e6 || (free_b && tmp_bytes > 0.5 * static_cast<double>(free_b))) return;
+    }
     M.rr_rows = rr_rows; M.nrr = nrr; M.ncb = ncb; M.ncg = ncg;
     const SellDims D = M.sdims();
     M.scnt.alloc(nq); M.ssoff.alloc(nq);

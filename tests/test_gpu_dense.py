@@ -988,6 +988,48 @@ def test_fp16_split_gram_is_as_exact_as_the_fp32_product(shape, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_gram_256_tile_on_an_ill_conditioned_matrix(monkeypatch):
+    """For n >= 8192 the fp16-split Gram product runs on the 256 x 256 tile, whose units are ONE
+    truncating MFMA chain of up to ~12800 rows (the 128 tile flushes 1024-row chains with IEEE
+    adds).  The evidence for that default was the well-conditioned C2 family; this is the opposite
+    case: strongly correlated columns (every column = 0.05 own noise + a shared direction) over six
+    decades of column scale, so G = A^T A has a condition number ~1e5 even after equilibration.
+    The projection built on the 256 tile has to satisfy its KKT system as well as the 128 tile's and
+    the native fp32 product's, and the three solves have to agree.  POGS_AMD_GRAM_TILE=128 stays
+    the documented escape hatch."""
+    pogs = _pogs()
+    m, n = 9216, 8192
+    rng = np.random.default_rng(77)
+    A = (0.05 * rng.standard_normal((m, n), dtype=np.float32) + rng.standard_normal((m, 1), dtype=np.float32))
+    A *= np.exp(rng.uniform(-7, 7, (1, n))).astype(np.float32)
+    xt = rng.standard_normal(n) * (rng.random(n) < 0.05)
+    b = A.astype(np.float64) @ xt + 0.1 * rng.standard_normal(m)
+    f, g = pogs.graph.ridge_functions(b, 1.0, n)
+    x0, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    out = {}
+    for mode, env in (("t256", {}), ("t128", {"POGS_AMD_GRAM_TILE": "128"}), ("fp32", {"POGS_AMD_GRAM": "fp32"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pogs.Solver(A, dtype=np.float32) as s:
+            A_eq, _, _, _ = s.equilibrated()
+            px, py = s.project(x0, y0)
+            A64 = A_eq.astype(np.float64)
+            kkt = np.linalg.norm(A64.T @ (py - y0) + (px - x0)) / np.sqrt(n)
+            out[mode] = (kkt, s.solve(f, g, max_iter=400))
+        for k in env:
+            monkeypatch.delenv(k)
+    print("ill-conditioned Gram: KKT residual of the projection 256 tile %.2e, 128 tile %.2e, fp32 MFMA %.2e; iterations %s"
+          % (out["t256"][0], out["t128"][0], out["fp32"][0], [out[k][1]["iterations"] + 1 for k in ("t256", "t128", "fp32")]))
+    assert out["t256"][0] < 3.0 * max(out["t128"][0], out["fp32"][0]) + 1e-6
+    ref = out["fp32"][1]
+    for k in ("t256", "t128"):
+        r = out[k][1]
+        assert r["status"] == ref["status"]
+        assert abs(int(r["iterations"]) - int(ref["iterations"])) <= max(3, ref["iterations"] // 10)
+        assert relerr(r["x"], ref["x"]) < 2e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(9))
 def test_random_mixed_function_problems_follow_the_oracle(seed):
     """Randomised problems with a DIFFERENT function type per element of f and g (all 16 `h`, random

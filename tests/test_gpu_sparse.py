@@ -236,9 +236,15 @@ def test_unsorted_indices_and_unsummed_duplicates_through_raw_abi(dtype, order):
     tol = 1e-6 if dtype == np.float64 else (2e-5 if d_it == 0 else 1e-4 * (1 + d_it))
     assert relerr(x, want["x"]) < tol
     assert float(optval.value) == pytest.approx(want["optval"], rel=1e-6 if dtype == np.float64 else 2e-4)
-    # and the canonical form of the same matrix gives the same answer: duplicates ARE summed by the product
+    # The canonical form of the same matrix is the same PROBLEM (the product adds repeated entries), but
+    # not the same run: equilibration and the Frobenius norm work on the stored entries (a^2 + b^2 for a
+    # repeated pair where the summed matrix has (a + b)^2; matrix_sparse.cpp:158-242), so the scaled
+    # problem and the stopping point differ -- measured 1.2e-3 in x at the default tolerances.  Both are
+    # solutions of the same lasso to the stopping rule's accuracy:
     canon = pogs._solve_graph_form(A_canon.astype(dtype), f, g, dtype=dtype)
-    assert relerr(x, canon["x"]) < (1e-6 if dtype == np.float64 else 2e-4)
+    assert canon["status"] == 0 and relerr(x, canon["x"]) < 1e-2
+    obj = lambda v: 0.5 * np.sum((A_canon @ v.astype(np.float64) - b) ** 2) + 0.1 * np.abs(v).sum()  # noqa: E731
+    assert obj(x) == pytest.approx(obj(canon["x"]), rel=1e-3)
     if ob.ref_available() and order == "csr":
         ref = ob.ref_solve(A_raw, soa(f), soa(g), dtype=dtype)
         assert ref["status"] == 0 and abs(int(ref["iterations"]) - int(fi.value)) <= (1 if dtype == np.float64 else 3)
