@@ -10,7 +10,9 @@ that rank.
 Workloads (BASELINE.json `configs`); rows are PER GPU ("weak" scaling):
   c2 (default, the metric's configuration): solve_lasso, dense fp32, A = 100000 x 10000 per
       GPU, synthetic N(0,1), x_true 10% dense, b = A x_true + 0.1 N(0,1), lambda = 0.1,
-      default tolerances, direct projector.  N = 8 is config C5 (800000 x 10000).
+      default tolerances, direct projector.  N = 8 is config C5 (800000 x 10000).  At N = 1 the
+      matrix is numpy's (pogs_amd.synth.dense_lasso_rows(seed=2024), the committed fixture's
+      problem), at N > 1 every rank draws its rows on its device (torch, seed 1000 + rank).
   c3: solve_logistic, dense fp32, A = 200000 x 5000, labels from logits with std 2
       (pogs_amd/synth.py: the reference recipe is nearly separable at this size), lambda = 0.01.
   c4: solve_lasso, CSR fp32, A = 2000000 x 500000 with 50 non-zeros per row, CGLS projector.
@@ -30,10 +32,13 @@ windows are timed back to back and the median is reported (`windows`).
 Inputs are resident in HBM when the timed region starts.  The JSON line carries `roofline`
 (the dominant kernel, timed with HIP events on the solver's stream over the timed region)
 and, at N = 1, `cpu_baseline`: the compiled reference (oracle/_ref, clean subprocess) on the
-same (A, b, lambda) on this box's host cores, the WHOLE workload (no sample, no scaling; about
-two minutes at c2), with `parity_vs_reference` comparing the two solutions; if the reference
-does not finish inside --cpu-budget-s the line carries two unscaled numbers instead (the
-reference on the leading 30 % of the rows, the OpenMP oracle port on the whole workload).
+same (A, b, lambda) on this box's host cores, on the WHOLE matrix (no row sample, nothing
+scaled), capped at --cpu-iters ADMM iterations -- on the GPU box's host its fp32 build does not
+reach the default tolerances at c2 and would run twenty minutes into max_iter
+(profiles/r03_ref_cpu_diagnosis.md); --cpu-full runs it to its end.  `parity_vs_reference`
+for c2 is taken against the committed reference solutions of exactly the benchmarked problem
+(tests/golden/c2_reference.npz: at one GPU c2's matrix is that fixture's, regenerated from its
+seed).  c4: the OpenMP oracle port on the whole workload to convergence.
 Without --config (the driver's invocation) and at N = 1 the c3 and c4 workloads are run after c2
 (GPU legs only) and attached as `secondary`: {c3: {...}, c4: {...}} with their own value /
 ms_per_step / roofline.

@@ -200,6 +200,7 @@ class DenseSolver final : public SolverBase {
     collect_stream_timer();
     if (p.verbose > 0 && ctx_.dist.rank() == 0) {
       print_summary(status, st.t_total_s, st.t_init_s, ctl_);
+      if (p.verbose > 3) print_timing_breakdown(st.t_loop_s, st.iterations);
       std::printf("POGS-AMD dense/%s: status %d, iter %u, init %.3e s, loop %.3e s\n", use_cgls_ ? "cgls" : "direct",
                   status, ctl_.k, st.t_init_s, st.t_loop_s);
     }
@@ -983,7 +984,11 @@ class DenseSolver final : public SolverBase {
     launch_add_diag<T>(G, ld, k_, static_cast<T>(1), s);                 // projector_direct_dense.cpp:118-119
     {
       PhaseTimer pt(s);
-      cholesky_lower<T>(G, ld, k_, Wp_, ld, s);
+      {
+        const char *la = std::getenv("POGS_AMD_CHOL_LOOKAHEAD");
+        const bool lookahead = !(la && la[0] == '0') && k_ >= 2048;
+        cholesky_lower<T>(G, ld, k_, Wp_, ld, s, lookahead ? ctx_.aux_stream() : nullptr);
+      }
       ctx_.stats.chol_ms = pt.stop_ms();
     }
     ctx_.tmark("cholesky");
@@ -1143,6 +1148,7 @@ class DenseSolver final : public SolverBase {
     ctl_.max_iter = p.max_iter;
     ctl_.adaptive_rho = p.adaptive_rho;
     ctl_.gap_stop = p.gap_stop;
+    ctl_.say_rho = p.verbose > 3 && ctx_.dist.rank() == 0;
     ctl_.rho0 = static_cast<T>(p.rho);
     ctl_.m_glob = ctx_.m_global;
     ctl_.n = n_;

@@ -589,6 +589,7 @@ class SparseSolver final : public SolverBase {
     collect_timer();
     if (p.verbose > 0 && ctx_.dist.rank() == 0) {
       print_summary(status, st.t_total_s, st.t_init_s, ctl_);
+      if (p.verbose > 3) print_timing_breakdown(st.t_loop_s, st.iterations);
       std::printf("POGS-AMD sparse/cgls: status %d, iter %u, init %.3e s, loop %.3e s, cg %llu, spmv %llu\n", status,
                   ctl_.k, st.t_init_s, st.t_loop_s, st.cg_iters, st.matvecs);
     }
@@ -1135,6 +1136,7 @@ class SparseSolver final : public SolverBase {
     ctl_.max_iter = p.max_iter;
     ctl_.adaptive_rho = p.adaptive_rho;
     ctl_.gap_stop = p.gap_stop;
+    ctl_.say_rho = p.verbose > 3 && ctx_.dist.rank() == 0;
     ctl_.rho0 = static_cast<T>(p.rho);
     ctl_.m_glob = ctx_.m_global;
     ctl_.n = n_;

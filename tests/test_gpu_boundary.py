@@ -97,6 +97,16 @@ def test_verbose_summary_in_the_reference_format(capfd, sparse):
         assert 0 <= val < 1e-4
     pogs.solve_lasso(A, b, 0.1, verbose=0)
     assert capfd.readouterr().out == ""
+    # verbose > 3 (pogs.cpp:206, 432-459, 501-506): the adaptive-rho messages, a line every 10 iterations,
+    # the per-iteration timing breakdown; the oracle prints the same rho messages for the same run
+    r4 = pogs.solve_lasso(A, b, 0.1, verbose=4)
+    out4 = capfd.readouterr().out
+    rho_lines = [ln for ln in out4.splitlines() if ln.startswith(("+ rho ", "- rho ", "spectral rho update: "))]
+    assert rho_lines, "no adaptive-rho message at verbose = 4"
+    assert all(float(ln.split()[2 if ln[0] in "+-" else 3]) > 0 for ln in rho_lines)
+    tb = [ln for ln in out4.splitlines() if ln.startswith("Timing breakdown (per-iter avg): prox = ")]
+    assert len(tb) == 1 and ", proj = " in tb[0] and ", residual = " in tb[0]
+    assert r4["iterations"] == r["iterations"]
 
 
 def test_iterate_before_begin_run_is_an_error_not_a_garbage_run():
