@@ -984,11 +984,7 @@ class DenseSolver final : public SolverBase {
     launch_add_diag<T>(G, ld, k_, static_cast<T>(1), s);                 // projector_direct_dense.cpp:118-119
     {
       PhaseTimer pt(s);
-      {
-        const char *la = std::getenv("POGS_AMD_CHOL_LOOKAHEAD");
-        const bool lookahead = !(la && la[0] == '0') && k_ >= 2048;
-        cholesky_lower<T>(G, ld, k_, Wp_, ld, s, lookahead ? ctx_.aux_stream() : nullptr);
-      }
+      cholesky_lower<T>(G, ld, k_, Wp_, ld, s);
       ctx_.stats.chol_ms = pt.stop_ms();
     }
     ctx_.tmark("cholesky");

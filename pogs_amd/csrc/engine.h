@@ -131,7 +131,6 @@ struct PhaseTimer {
 // of streams and 4 KB blocks per device for the life of the process).
 struct CtxResources {
   hipStream_t stream = nullptr;
-  hipStream_t aux = nullptr;    // second stream (Cholesky look-ahead), created on first use
   double *host = nullptr;       // kNumSlots + 1 doubles, hipHostMallocMapped | Coherent
   int device = -1;
 };
@@ -167,7 +166,6 @@ struct Ctx {
       for (size_t i = 0; i < pool.size(); ++i)
         if (pool[i].device == device) {
           stream = pool[i].stream;
-          aux = pool[i].aux;
           S_host.p = pool[i].host;
           pool.erase(pool.begin() + static_cast<long>(i));
           break;
@@ -193,13 +191,6 @@ struct Ctx {
     }
     std::memset(&stats, 0, sizeof(stats));
     stream_timer.enable(profile);
-  }
-  // a second stream for work that may overlap the main one (the Cholesky's look-ahead); created on
-  // first use, recycled with the main stream
-  hipStream_t aux = nullptr;
-  hipStream_t aux_stream() {
-    if (!aux) POGS_HIP_CHECK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-    return aux;
   }
   void ensure_spart(size_t count) {
     if (count > spart_cap) {
@@ -342,14 +333,11 @@ struct Ctx {
     DeviceGuard guard(device);
     // a stream that faulted (or was left inside a failed collective) must not be handed to the
     // next solver: recycle it only if it drains cleanly
-    const bool healthy = !poisoned && hipStreamSynchronize(stream) == hipSuccess &&
-                         (!aux || hipStreamSynchronize(aux) == hipSuccess);
-    if (!(ctx_recycle() && healthy) && aux) (void)hipStreamDestroy(aux);
+    const bool healthy = !poisoned && hipStreamSynchronize(stream) == hipSuccess;
     if (ctx_recycle() && healthy) {
       std::lock_guard<std::mutex> lock(ctx_pool_mutex());
       CtxResources r;
       r.stream = stream;
-      r.aux = aux;
       r.host = S_host.p;
       r.device = device;
       ctx_pool().push_back(r);

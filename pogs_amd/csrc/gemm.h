@@ -112,7 +112,7 @@ template <> struct CholBlock<double> { static constexpr int NB = 64; };
 // factor L; W (n x n, leading dim ldw, zero-initialised by the caller) receives
 // the inverses of L's diagonal blocks.
 template <typename T>
-void cholesky_lower(T *G, size_t ldg, int n, T *W, size_t ldw, hipStream_t s, hipStream_t aux = nullptr);
+void cholesky_lower(T *G, size_t ldg, int n, T *W, size_t ldw, hipStream_t s);
 
 // Completes W = L^{-1} (lower triangular) from the diagonal-block inverses.
 // tmp must hold n * ldw elements.

@@ -821,87 +821,26 @@ void launch_gemm(bool a_kmaj, bool b_kmaj, bool lower_only, const GemmArgs<T> &g
 }
 
 template <typename T>
-void cholesky_lower(T *G, size_t ldg, int n, T *W, size_t ldw, hipStream_t s, hipStream_t aux) {
+void cholesky_lower(T *G, size_t ldg, int n, T *W, size_t ldw, hipStream_t s) {
   constexpr int NB = CholBlock<T>::NB;
-  if (!aux || n < 8 * NB) {
-    for (int o = 0; o < n; o += NB) {
-      const int nb = (n - o < NB) ? n - o : NB;
-      T *Gd = G + static_cast<size_t>(o) * ldg + o;
-      T *Wd = W + static_cast<size_t>(o) * ldw + o;
-      hipLaunchKernelGGL((potrf_inv_kernel<T, NB>), dim3(1), dim3(256), 0, s, Gd, ldg, nb, Wd, ldw);
-      const int rem = n - o - nb;
-      if (rem > 0) {
-        T *L21 = G + static_cast<size_t>(o + nb) * ldg + o;
-        // L21 <- A21 * inv(L11)^T, in place: one tile column, each workgroup reads
-        // its own row block completely before it writes it.
-        GemmArgs<T> g1{rem, nb, nb, L21, ldg, Wd, ldw, L21, ldg, static_cast<T>(1), static_cast<T>(0)};
-        launch_gemm<T>(false, false, false, g1, s);
-        // A22 <- A22 - L21 L21^T (lower tiles)
-        T *A22 = G + static_cast<size_t>(o + nb) * ldg + (o + nb);
-        GemmArgs<T> g2{rem, rem, nb, L21, ldg, L21, ldg, A22, ldg, static_cast<T>(-1), static_cast<T>(1)};
-        launch_gemm<T>(false, false, true, g2, s);
-      }
-    }
-    return;
-  }
-  // Look-ahead.  The loop above is a chain of three dependent launches per panel -- the one-workgroup
-  // diagonal factorisation (54 us), the panel product (19 us), the trailing update (90 us on average
-  // at n = 10000) -- although only the NEXT panel's columns of the trailing update stand between one
-  // panel and the next.  Here the diagonal block, the panel and the update of the next panel's columns
-  // run on `aux`, the update of the remaining columns on `s`, so that the bulk of one step's update
-  // overlaps the next step's latency-bound head.  The same kernels produce every tile with the same
-  // operands in the same order: the factor is bit for bit the one of the loop above.
-  //   aux:  [wait bulk(i-2)] potrf(i), panel(i), record P(i); [wait bulk(i-1)] lookahead(i)
-  //   s:    [wait P(i)] bulk(i), record B(i)
-  hipEvent_t P[3], B[3], e0, e1;
-  for (int q = 0; q < 3; ++q) {
-    POGS_HIP_CHECK(hipEventCreateWithFlags(&P[q], hipEventDisableTiming));
-    POGS_HIP_CHECK(hipEventCreateWithFlags(&B[q], hipEventDisableTiming));
-  }
-  POGS_HIP_CHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-  POGS_HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-  POGS_HIP_CHECK(hipEventRecord(e0, s));
-  POGS_HIP_CHECK(hipStreamWaitEvent(aux, e0, 0));   // everything queued on s so far (the Gram matrix)
-  int i = 0;
-  for (int o = 0; o < n; o += NB, ++i) {
+  for (int o = 0; o < n; o += NB) {
     const int nb = (n - o < NB) ? n - o : NB;
     T *Gd = G + static_cast<size_t>(o) * ldg + o;
     T *Wd = W + static_cast<size_t>(o) * ldw + o;
-    if (i >= 2) POGS_HIP_CHECK(hipStreamWaitEvent(aux, B[(i - 2) % 3], 0));
-    hipLaunchKernelGGL((potrf_inv_kernel<T, NB>), dim3(1), dim3(256), 0, aux, Gd, ldg, nb, Wd, ldw);
+    hipLaunchKernelGGL((potrf_inv_kernel<T, NB>), dim3(1), dim3(256), 0, s, Gd, ldg, nb, Wd, ldw);
     const int rem = n - o - nb;
-    if (rem <= 0) break;
-    T *L21 = G + static_cast<size_t>(o + nb) * ldg + o;
-    GemmArgs<T> g1{rem, nb, nb, L21, ldg, Wd, ldw, L21, ldg, static_cast<T>(1), static_cast<T>(0)};
-    launch_gemm<T>(false, false, false, g1, aux);
-    POGS_HIP_CHECK(hipEventRecord(P[i % 3], aux));
-    // the next panel's columns of A22 <- A22 - L21 L21^T (lower tiles), on aux
-    const int nb2 = rem < NB ? rem : NB;
-    T *A22 = G + static_cast<size_t>(o + nb) * ldg + (o + nb);
-    if (i >= 1) POGS_HIP_CHECK(hipStreamWaitEvent(aux, B[(i - 1) % 3], 0));
-    GemmArgs<T> g2{rem, nb2, nb, L21, ldg, L21, ldg, A22, ldg, static_cast<T>(-1), static_cast<T>(1)};
-    launch_gemm<T>(false, false, true, g2, aux);
-    // the remaining columns, on s
-    POGS_HIP_CHECK(hipStreamWaitEvent(s, P[i % 3], 0));
-    const int rem2 = rem - nb2;
-    if (rem2 > 0) {
-      T *L21b = L21 + static_cast<size_t>(nb2) * ldg;
-      T *A22b = A22 + static_cast<size_t>(nb2) * ldg + nb2;
-      GemmArgs<T> g3{rem2, rem2, nb, L21b, ldg, L21b, ldg, A22b, ldg, static_cast<T>(-1), static_cast<T>(1)};
-      launch_gemm<T>(false, false, true, g3, s);
+    if (rem > 0) {
+      T *L21 = G + static_cast<size_t>(o + nb) * ldg + o;
+      // L21 <- A21 * inv(L11)^T, in place: one tile column, each workgroup reads
+      // its own row block completely before it writes it.
+      GemmArgs<T> g1{rem, nb, nb, L21, ldg, Wd, ldw, L21, ldg, static_cast<T>(1), static_cast<T>(0)};
+      launch_gemm<T>(false, false, false, g1, s);
+      // A22 <- A22 - L21 L21^T (lower tiles)
+      T *A22 = G + static_cast<size_t>(o + nb) * ldg + (o + nb);
+      GemmArgs<T> g2{rem, rem, nb, L21, ldg, L21, ldg, A22, ldg, static_cast<T>(-1), static_cast<T>(1)};
+      launch_gemm<T>(false, false, true, g2, s);
     }
-    POGS_HIP_CHECK(hipEventRecord(B[i % 3], s));
   }
-  POGS_HIP_CHECK(hipEventRecord(e1, aux));
-  POGS_HIP_CHECK(hipStreamWaitEvent(s, e1, 0));
-  // (the events may be destroyed while work that refers to them is still queued: the runtime keeps
-  // them alive until then)
-  for (int q = 0; q < 3; ++q) {
-    (void)hipEventDestroy(P[q]);
-    (void)hipEventDestroy(B[q]);
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
 }
 
 template <typename T>
@@ -997,7 +936,7 @@ void launch_add_diag(T *G, size_t ldg, int n, T v, hipStream_t s) {
 
 #define POGS_INST(T)                                                                           \
   template void launch_gemm<T>(bool, bool, bool, const GemmArgs<T> &, hipStream_t);            \
-  template void cholesky_lower<T>(T *, size_t, int, T *, size_t, hipStream_t, hipStream_t);                 \
+  template void cholesky_lower<T>(T *, size_t, int, T *, size_t, hipStream_t);                 \
   template void trtri_lower<T>(const T *, size_t, int, T *, size_t, T *, hipStream_t);         \
   template void launch_transpose<T>(const T *, size_t, int, int, T *, size_t, hipStream_t);    \
   template void launch_sum_slabs<T>(const T *, size_t, int, T *, size_t, int, hipStream_t);       \
