@@ -27,7 +27,7 @@ timed region (init_s); a complete cold solve is reported as time_to_converge_s.
 value = N * K / T: iterations of one per-GPU shard per second, summed over ranks (at N = 1 the
 ADMM it/s of the configuration).  T is the max over ranks of the time of exactly K steps
 between barrier + synchronize on both sides; when K steps take less than 0.1 s several such
-windows are timed back to back and the median is reported (`windows`).
+windows are timed back to back and their mean is reported (`windows`, `window_s`).
 
 Inputs are resident in HBM when the timed region starts.  The JSON line carries `roofline`
 (the dominant kernel, timed with HIP events on the solver's stream over the timed region)
@@ -47,7 +47,6 @@ import argparse
 import json
 import os
 import socket
-import statistics
 import sys
 import time
 
@@ -363,7 +362,10 @@ def run_config(env, name, with_cpu):
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         times.append(elapsed)
-    elapsed = statistics.median(times)
+    # the windows are consecutive stretches of the same real solves: their MEAN is the iteration rate
+    # (the median would drop the windows that hold a solve's dearer iterations -- a missed rho
+    # prediction's extra pass, the two-step CG projections late in a sparse solve)
+    elapsed = sum(times) / len(times)
     st = solver.stats()
     nranks_comm = st.get("comm_nranks", 0)   # as ncclCommCount reports it (0: no communicator)
 
@@ -470,7 +472,7 @@ def main():
     # the driver's invocation (no --config, one GPU): c3 and c4 under the same clock, GPU legs only
     if args.config is None and env.world == 1 and not args.no_secondary and not (args.m or args.n) \
             and args.projector == "default":
-        keep = ("value", "unit", "ms_per_step", "steps", "windows", "config", "roofline", "time_to_converge_s", "init_s",
+        keep = ("value", "unit", "ms_per_step", "steps", "windows", "window_s", "config", "roofline", "time_to_converge_s", "init_s",
                 "solve_iterations", "solve_status", "setup_ms")
         sec = {}
         for name in ("c3", "c4"):

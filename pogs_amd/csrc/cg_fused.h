@@ -43,7 +43,8 @@
 namespace pogs_amd {
 namespace {
 
-constexpr int kCgfTpb = 256;
+constexpr int kCgfTpb = 1024;     // few, fat blocks: every block of a consumer re-adds the producer's records
+constexpr int kCgfWaves = kCgfTpb / 64;
 constexpr int kCgfBlocks = 512;   // upper bound on the blocks (= scalar records) of the loop's vector launches
 
 inline int cgf_blocks(int n) { return std::max(1, std::min(kCgfBlocks, (n + kCgfTpb - 1) / kCgfTpb)); }
@@ -52,7 +53,7 @@ inline int cgf_blocks(int n) { return std::max(1, std::min(kCgfBlocks, (n + kCgf
 // the totals, and every block that runs this on the same records gets the same bits (per-thread
 // strided partial sums, wavefront butterfly, the four wavefront totals in order).
 template <int NS>
-__device__ __forceinline__ void cgf_sum(const double *p, int count, double (&out)[NS], double *smem /* [NS * 4] */) {
+__device__ __forceinline__ void cgf_sum(const double *p, int count, double (&out)[NS], double *smem /* [NS * kCgfWaves] */) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #pragma unroll
   for (int k = 0; k < NS; ++k) out[k] = 0.0;
@@ -64,11 +65,16 @@ __device__ __forceinline__ void cgf_sum(const double *p, int count, double (&out
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     const double w = dev::wave_sum(out[k]);
-    if (lane == 0) smem[k * 4 + wave] = w;
+    if (lane == 0) smem[k * kCgfWaves + wave] = w;
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < NS; ++k) out[k] = (smem[k * 4 + 0] + smem[k * 4 + 1]) + (smem[k * 4 + 2] + smem[k * 4 + 3]);
+  for (int k = 0; k < NS; ++k) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < kCgfWaves; ++w) tot += smem[k * kCgfWaves + w];
+    out[k] = tot;
+  }
 }
 
 // s_j = (A^T r)_j - shift xcg_j ; p_j = s_j ; |s|^2                        (cgls.h:236-245)
@@ -159,7 +165,7 @@ struct CgfStepA {
 // y_new = (first ? y_warm : y_new) + alpha q; partial |x|^2 (:298)
 template <typename T>
 __global__ void __launch_bounds__(kCgfTpb) cgf_step_a_kernel(CgfStepA<T> a) {
-  __shared__ double s_sum[8];
+  __shared__ double s_sum[kCgfWaves];
   __shared__ double s_red[kCgfTpb / 64];
   if (cgf_skip(a.S, 0)) return;
   double gamma, p2;
@@ -238,7 +244,7 @@ struct CgfStepB {
 // p = s + beta p, partial |p|^2 (:295-296)
 template <typename T>
 __global__ void __launch_bounds__(kCgfTpb) cgf_step_b_kernel(CgfStepB<T> a) {
-  __shared__ double s_sum[8];
+  __shared__ double s_sum[kCgfWaves];
   __shared__ double s_red[kCgfTpb / 64];
   if (cgf_skip(a.S, 0)) return;
   double g[1], x2[1];
