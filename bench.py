@@ -55,6 +55,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+PROFILE_EVERY = 4   # HIP-event brackets on every 4th launch of the dominant kernel (a bracket costs the stream ~6 us)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable by a float4 copy
 
 CONFIGS = {
@@ -328,12 +329,12 @@ def run_config(env, name, with_cpu):
     torch.cuda.synchronize()
     t0 = time.time()
     if sparse:
-        solver = pogs_amd.Solver(A, dtype=np.float32, device=local, profile=True, dist=dist_arg)
+        solver = pogs_amd.Solver(A, dtype=np.float32, device=local, profile=PROFILE_EVERY, dist=dist_arg)
     else:
         from pogs_amd import _lib as L
 
         solver = pogs_amd.Solver(A.data_ptr(), dtype=np.float32, shape=(m, n), device_ptr=True, device=local,
-                                 profile=True, dist=dist_arg,
+                                 profile=PROFILE_EVERY, dist=dist_arg,
                                  projector=L.PROJ_CGLS if args.projector == "cgls" else L.PROJ_DEFAULT)
     init_s = time.time() - t0
     f, g = functions(cfg, G, b, n)
@@ -432,7 +433,9 @@ def run_config(env, name, with_cpu):
                          "traffic_source": ("static: %s (rocprofv3 --pmc passes of this command, committed; not "
                                             "measured in this run)" % traffic_src) if traffic_src else None,
                          "kernel": kernel, "bytes_per_launch": bytes_per_launch,
-                         "avg_launch_ms": avg_ms, "launches": st["stream_launches"], "iteration": iteration},
+                         "avg_launch_ms": avg_ms, "launches": st["stream_launches"],
+                         "launch_sampling": "HIP events around every %d-th launch of the kernel in the timed region" % PROFILE_EVERY,
+                         "iteration": iteration},
             "time_to_converge_s": init_s + solve_s, "init_s": init_s, "loop_s": st_solve["t_loop_s"],
             "solve_iterations": res["iterations"] + 1, "solve_status": res["status"],
             "exact_residual_iters": st_solve["exact_iters"],

@@ -121,7 +121,9 @@ typedef struct PogsAmdDist {
 typedef struct PogsAmdOptions {
   int device;          /* HIP device ordinal; -1 = current device                   */
   int projector;       /* enum POGS_AMD_PROJECTOR                                   */
-  int profile;         /* 1: bracket the dominant kernels with HIP events           */
+  int profile;         /* 1: bracket the dominant kernels with HIP events; k > 1:
+                          every k-th such launch only (an event record costs the
+                          stream a few microseconds of idle time)                   */
   int reserved[5];
 } PogsAmdOptions;
 

@@ -122,7 +122,7 @@ class DenseSolver final : public SolverBase {
           preload_gemm_code();
         });
     }
-    ctx_.init(opt ? opt->device : -1, opt ? opt->profile != 0 : false);
+    ctx_.init(opt ? opt->device : -1, opt ? opt->profile : 0);
     m_ = static_cast<int>(m);
     n_ = static_cast<int>(n);
     POGS_CHECK(m > 0 && n > 0 && m < (1u << 31) && n < (1u << 31), "bad dimensions");

@@ -536,7 +536,7 @@ class SparseSolver final : public SolverBase {
   SparseSolver(int ord, size_t m, size_t n, size_t nnz, const void *data, const int *ptr, const int *ind, int mem,
                const PogsAmdOptions *opt, const PogsAmdDist *dist) {
     const double t0 = wall_s();
-    ctx_.init(opt ? opt->device : -1, opt ? opt->profile != 0 : false);
+    ctx_.init(opt ? opt->device : -1, opt ? opt->profile : 0);
     POGS_CHECK(m > 0 && n > 0 && m < (1u << 31) && n < (1u << 31) && nnz < (1ull << 31), "bad dimensions");
     m_ = static_cast<int>(m);
     n_ = static_cast<int>(n);
