@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cn
 template <typename T>
 __global__ void sell_fill_kernel(const T *val, const int *ind, const int *ptr, SellDims D, const unsigned short *cnt,
                                  const unsigned *soff, unsigned short *cursor, const int *tile_unit, T *sval,
-                                 unsigned short *sloc, unsigned short *srid) {
+                                 unsigned short *sloc, unsigned short *srid, unsigned *dst_out) {
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < D.nrows; r += gridDim.x * blockDim.x) {
     const int rr = r / D.rr_rows, lr = r - rr * D.rr_rows;
     for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
@@ -477,12 +477,22 @@ __global__ void sell_fill_kernel(const T *val, const int *ind, const int *ptr, S
       const size_t dst = (static_cast<size_t>(u0) + static_cast<size_t>(sidx >> 6) * K) * 64 +
                          static_cast<size_t>(k_el / kSellUB) * (64 * kSellUB) + (sidx & 63) * kSellUB + (k_el % kSellUB);
       sval[dst] = val[k];
+      if (dst_out) dst_out[k] = static_cast<unsigned>(dst);
       if (sloc) {
         sloc[dst] = static_cast<unsigned short>(c - cb * D.bw);
         if (j + 1 == cnt[idx]) srid[dst] = static_cast<unsigned short>(lr);
       }
     }
   }
+}
+
+// sval[dst[k]] = val[k]: the values again (after a rescaling of the CSR copy), through the positions
+// sell_fill_kernel recorded -- coalesced reads, no per-(row, tile) bookkeeping
+template <typename T>
+__global__ void __launch_bounds__(256) sell_refill_kernel(const T *__restrict__ val, const unsigned *__restrict__ dst,
+                                                          size_t nnz, T *sval) {
+  for (size_t k = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; k < nnz; k += static_cast<size_t>(gridDim.x) * 256)
+    sval[dst[k]] = val[k];
 }
 
 }  // namespace pogs_amd
