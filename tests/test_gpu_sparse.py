@@ -132,6 +132,43 @@ def test_sparse_lasso_fp32_scaled_c4():
     assert relerr(got["x"], GOLD["csr20000_f32_x"]) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_cg_loop_variants_walk_the_same_trajectory(dtype, monkeypatch):
+    """The device-resident CGLS loop (cg_fused.h) with y = A x from the CG recurrence every iteration
+    (POGS_AMD_YSYNC=1000000), with the explicit product every 16th (default) and every iteration
+    (POGS_AMD_YSYNC=0, the reference's projector_cgls.cpp:78), and round 2's host-polled loop
+    (POGS_AMD_CG=host): the same iteration counts, the same CG step total, x within rounding -- and all
+    of them on the oracle's trajectory."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.csr_lasso(20000, 5000, 50, seed=3, dtype=dtype)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 5000)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype)
+    res = {}
+    for name, env in (("ysync16", {}), ("never", {"POGS_AMD_YSYNC": "1000000"}), ("always", {"POGS_AMD_YSYNC": "0"}),
+                      ("host", {"POGS_AMD_CG": "host"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pogs.Solver(A, dtype=dtype) as s:
+            r = s.solve(f, g)
+            st = s.stats()
+        for k in env:
+            monkeypatch.delenv(k)
+        res[name] = (r, st)
+    ref = res["always"][0]
+    tol = 1e-9 if dtype == np.float64 else 2e-6
+    for name, (r, st) in res.items():
+        assert r["status"] == 0 and r["iterations"] == ref["iterations"], name
+        assert st["cg_iters"] == res["always"][1]["cg_iters"], (name, st["cg_iters"])
+        assert relerr(r["x"], ref["x"]) < tol, (name, relerr(r["x"], ref["x"]))
+        assert relerr(r["y"], ref["y"]) < 10 * tol, name
+    assert abs(int(ref["iterations"]) - int(want["iterations"])) <= (1 if dtype == np.float64 else 3)
+    assert relerr(ref["x"], want["x"]) < (1e-6 if dtype == np.float64 else 2e-5)
+    # fewer products with the recurrence: one per iteration less, except the synchronising ones
+    assert res["never"][1]["matvecs"] < res["always"][1]["matvecs"] - 0.9 * (ref["iterations"] - 1)
+
+
 @pytest.mark.parametrize("problem", ["ridge", "logistic", "svm", "nonneg_ls"])
 def test_sparse_other_families(problem):
     pogs = _pogs()
