@@ -6,6 +6,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -90,8 +91,14 @@ struct LocalGroup {
       cv.notify_all();
       return;
     }
-    if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g; }))
-      throw Error("local communicator: a rank did not reach the collective within 120 s");
+    // (the same limit as the RCCL path's, Ctx::wait_publish: POGS_AMD_COLL_TIMEOUT_S, at most 120 s here)
+    const char *te = std::getenv("POGS_AMD_COLL_TIMEOUT_S");
+    const double lim = std::min(120.0, te && std::atof(te) > 0 ? std::atof(te) : 120.0);
+    if (!cv.wait_for(lk, std::chrono::duration<double>(lim), [&] { return gen != g; })) {
+      // leave the group consistent for the ranks that did arrive: this collective is void
+      --arrived;
+      throw Error("local communicator: a rank did not reach the collective within " + std::to_string(static_cast<int>(lim)) + " s");
+    }
   }
 };
 

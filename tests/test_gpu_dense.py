@@ -988,6 +988,58 @@ def test_fp16_split_gram_is_as_exact_as_the_fp32_product(shape, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_a_peer_that_never_joins_a_collective_is_an_error_not_a_hang(monkeypatch):
+    """Row shards: rank 1 creates its handle (the setup's collectives need both ranks) and then never
+    solves.  Rank 0's first all-reduce of the loop must come back as POGS_ERROR after
+    POGS_AMD_COLL_TIMEOUT_S seconds -- with the reason in PogsAmdLastError -- instead of waiting for
+    ever, and the handle must still destroy cleanly.  (In-process test communicator; the RCCL path has
+    the same limit in Ctx::wait_publish plus ncclCommAbort, which one GPU cannot exercise.)"""
+    import threading
+    import time
+
+    pogs = _pogs()
+    from pogs_amd import _lib, synth
+
+    monkeypatch.setenv("POGS_AMD_TEST_TRANSPORT", "1")
+    monkeypatch.setenv("POGS_AMD_COLL_TIMEOUT_S", "3")
+    m, n = 3000, 200
+    A, b, _ = synth.dense_lasso(m, n, seed=61, dtype=np.float64)
+    f, g = pogs.graph.lasso_functions(b, 0.1, n)
+    uid = (b"POGSLOCAL:" + os.urandom(8).hex().encode()).ljust(128, b"\0")
+    created = threading.Barrier(2)
+    out = {}
+
+    def rank(r):
+        lo, hi = (0, 1500) if r == 0 else (1500, m)
+        s = pogs.Solver(A[lo:hi], dtype=np.float64, dist=(r, 2, m, uid))
+        try:
+            created.wait(60)
+            if r == 0:
+                t0 = time.time()
+                try:
+                    s.solve(f.slice(lo, hi), g)
+                    out["result"] = "solved"
+                except Exception as e:       # the Python layer raises on POGS_ERROR
+                    out["result"] = repr(e)
+                out["seconds"] = time.time() - t0
+                out["last_error"] = _lib.last_error()
+            else:
+                time.sleep(8)                # never joins the loop's collectives
+        finally:
+            s.close()
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not any(t.is_alive() for t in ts), "a rank is still waiting"
+    assert out.get("result") != "solved", out
+    assert "did not reach the collective" in (out.get("last_error", "") + out.get("result", "")), out
+    assert 2.0 < out["seconds"] < 30.0, out
+
+
+@pytest.mark.gpu
 def test_gram_256_tile_on_an_ill_conditioned_matrix(monkeypatch):
     """For n >= 8192 the fp16-split Gram product runs on the 256 x 256 tile, whose units are ONE
     truncating MFMA chain of up to ~12800 rows (the 128 tile flushes 1024-row chains with IEEE
