@@ -249,23 +249,40 @@ def cpu_baseline(cfg, A_host, f, g, args, engine, fixture=None):
     return out, parity
 
 
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources, as scripts/pmc_summary.py records it."""
+    import hashlib
+
+    d = os.path.join(ROOT, "pogs_amd", "csrc")
+    hh = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".h", ".hip")):
+            hh.update(fn.encode())
+            hh.update(open(os.path.join(d, fn), "rb").read())
+    return hh.hexdigest()[:16]
+
+
 def pmc_traffic(name, kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of
     this command (profiles/pmc_traffic_<config>.json: separate FETCH_SIZE / WRITE_SIZE passes,
-    gfx950 half-count correction applied; scripts/pmc_summary.py).  (None, None) if absent."""
+    gfx950 half-count correction applied; scripts/pmc_summary.py).  Returns (bytes, file, fresh):
+    `fresh` says whether the counters were collected on the kernel sources this run uses (the file
+    records their hash).  (None, None, None) if absent."""
     rel = os.path.join("profiles", "pmc_traffic_%s.json" % name)
     path = os.path.join(ROOT, rel)
     if not os.path.exists(path):
-        return None, None
+        return None, None, None
     try:
         d = json.load(open(path))
+        meta = d.pop("_meta", {})
         sel = [e for k, e in d.items() if kernel_substr in k]
         cnt = sum(e["launches"] for e in sel)
         if not cnt:
-            return None, None
-        return sum(e["hbm_bytes_per_launch_corrected"] * e["launches"] for e in sel) / cnt, rel
+            return None, None, None
+        fresh = meta.get("csrc_sha16") == csrc_sha16() if meta.get("csrc_sha16") else None
+        return sum(e["hbm_bytes_per_launch_corrected"] * e["launches"] for e in sel) / cnt, rel, fresh
     except Exception:
-        return None, None
+        return None, None, None
 
 
 class Env:
@@ -432,8 +449,9 @@ def run_config(env, name, with_cpu):
                              "bytes": passes * 4.0 * m * n, "frac": passes * 4.0 * m * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}
                 projector = "CGLS on the dense matrix (matrix-free)"
                 workload += " [--projector cgls]"
-        traffic, traffic_src = (pmc_traffic(name, kernel_key) if (m, n) == (cfg["m"], cfg["n"]) and args.projector == "default"
-                                else (None, None))
+        traffic, traffic_src, traffic_fresh = (pmc_traffic(name, kernel_key)
+                                               if (m, n) == (cfg["m"], cfg["n"]) and args.projector == "default"
+                                               else (None, None, None))
         line = {
             "metric": "admm_iterations_per_sec_%s_fp32 (per-GPU shard, summed over GPUs)" % cfg["kind"],
             "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -445,7 +463,10 @@ def run_config(env, name, with_cpu):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": ("static: %s (rocprofv3 --pmc passes of this command, committed; not "
-                                            "measured in this run)" % traffic_src) if traffic_src else None,
+                                            "measured in this run; %s)"
+                                            % (traffic_src, "collected on the kernel sources of this build" if traffic_fresh
+                                               else "STALE: the kernel sources have changed since the counters were collected"
+                                               if traffic_fresh is False else "no source hash in the file")) if traffic_src else None,
                          "kernel": kernel, "bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": avg_ms, "launches": st["stream_launches"],
                          "launch_sampling": "HIP events around every %d-th launch of the kernel in the timed region" % PROFILE_EVERY,

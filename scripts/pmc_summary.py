@@ -41,5 +41,16 @@ for name in sorted(set(fetch) | set(write)):
     fe, wr = sum(f) / len(f) * 1024.0, sum(w) / len(w) * 1024.0
     out[name] = {"launches": len(f), "noop_launches_excluded": noop, "fetch_size_bytes_raw": fe, "write_size_bytes": wr,
                  "hbm_bytes_per_launch_corrected": 2.0 * fe + wr}
+# which kernel sources the counters belong to: bench.py compares this with the sources it runs on
+import hashlib
+import os
+
+csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pogs_amd", "csrc")
+hh = hashlib.sha256()
+for fn in sorted(os.listdir(csrc)):
+    if fn.endswith((".h", ".hip")):
+        hh.update(fn.encode())
+        hh.update(open(os.path.join(csrc, fn), "rb").read())
+out["_meta"] = {"csrc_sha16": hh.hexdigest()[:16]}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print("wrote", sys.argv[3], len(out), "kernels")
