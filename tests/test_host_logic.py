@@ -181,3 +181,44 @@ def test_pogs_solve_fills_in_the_problem_or_falls_through(monkeypatch):
     import pogs_amd
 
     assert pogs_amd.pogs_solve is front.pogs_solve               # exported like the reference's (__init__.py:29)
+
+
+def test_bench_bookkeeping_without_a_gpu(tmp_path, monkeypatch):
+    """bench.py's host-side pieces that need no GPU: the kernel-source hash that dates the committed
+    PMC traffic figures (fresh / stale / unknown), the fixture the c2 workload is generated from, and
+    the synthetic generators' reproducibility (the fixtures depend on it bit for bit)."""
+    import importlib.util
+    import json
+
+    from pogs_amd import synth
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sha = bench.csrc_sha16()
+    assert len(sha) == 16 and sha == bench.csrc_sha16()
+    # a traffic file collected on these sources, on other sources, and one without a hash
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    entry = {"kern<float, 1>": {"launches": 4, "hbm_bytes_per_launch_corrected": 10.0},
+             "kern<float, 2>": {"launches": 1, "hbm_bytes_per_launch_corrected": 20.0},
+             "other": {"launches": 9, "hbm_bytes_per_launch_corrected": 99.0}}
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_sha16", lambda: sha)
+    for meta, want in (({"csrc_sha16": sha}, True), ({"csrc_sha16": "0" * 16}, False), (None, None)):
+        d = dict(entry)
+        if meta is not None:
+            d["_meta"] = meta
+        (prof / "pmc_traffic_c9.json").write_text(json.dumps(d))
+        val, rel, fresh = bench.pmc_traffic("c9", "kern<float")
+        assert val == pytest.approx((4 * 10.0 + 20.0) / 5) and rel.endswith("pmc_traffic_c9.json") and fresh is want
+    assert bench.pmc_traffic("nope", "kern") == (None, None, None)
+    # the c2 fixture names the generator's arguments; a small instance of that generator is reproducible
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "c2_reference.npz"))
+    assert tuple(int(v) for v in fx["shape"]) == (bench.CONFIGS["c2"]["m"], bench.CONFIGS["c2"]["n"]) and int(fx["seed"]) == 2024
+    A1, b1, _ = synth.dense_lasso_rows(900, 70, seed=int(fx["seed"]), chunk=400)
+    A2, b2, _ = synth.dense_lasso_rows(900, 70, seed=int(fx["seed"]), chunk=400)
+    assert np.array_equal(A1, A2) and np.array_equal(b1, b2) and A1.dtype == np.float32
+    L1 = synth.dense_logistic_rows(500, 40, seed=33, chunk=200)
+    L2 = synth.dense_logistic_rows(500, 40, seed=33, chunk=200)
+    assert np.array_equal(L1[0], L2[0]) and np.array_equal(L1[1], L2[1]) and set(np.unique(L1[1])) <= {-1.0, 1.0}
