@@ -30,9 +30,13 @@ static __global__ void cg_beta_kernel(double *S, double *cg) {
 }
 
 // x += alpha p (n);  r -= alpha q (m);  partial |x|^2      (cgls.h:274-277, 298)
+// yacc (optional): y_acc = ysrc + alpha q -- the recurrence A x_new = A x_warm + sum alpha_k q_k that
+// replaces the product y = A x at the end of the projection (projector_cgls.cpp:78; cg_fused.h);
+// ysrc is A x_warm on the first step and yacc itself afterwards.
 template <typename T>
 __global__ void __launch_bounds__(kVecTpb) cg_update_xr_kernel(int n, int m, const double *cg, const T *p, T *x,
-                                                               const T *q, T *r, double *partials, int blocks_x) {
+                                                               const T *q, T *r, double *partials, int blocks_x,
+                                                               const T *ysrc, T *yacc) {
   __shared__ double s_red[kVecTpb / 64];
   const T alpha = static_cast<T>(cg[kCgAlpha]);
   const T neg_alpha = static_cast<T>(-cg[kCgAlpha]);
@@ -46,7 +50,11 @@ __global__ void __launch_bounds__(kVecTpb) cg_update_xr_kernel(int n, int m, con
     }
   } else {
     const int i = (blockIdx.x - blocks_x) * kVecTpb + threadIdx.x;
-    if (i < m) r[i] += neg_alpha * q[i];
+    if (i < m) {
+      const T qi = q[i];
+      r[i] += neg_alpha * qi;
+      if (yacc) yacc[i] = ysrc[i] + alpha * qi;
+    }
     return;   // (uniform per workgroup) only the x blocks carry a partial sum: partials has blocks_x entries
   }
   dev::block_sum<1, kVecTpb>(acc, s_red);

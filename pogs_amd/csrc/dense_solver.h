@@ -138,6 +138,7 @@ class DenseSolver final : public SolverBase {
     // dense + CGLS: instantiated by the reference (pogs.cpp:1983-1984) but not reachable from
     // its C ABI; offered here as an option (no Gram / factorisation, any shape)
     use_cgls_ = opt && opt->projector == POGS_AMD_PROJ_CGLS;
+    if (const char *ys = std::getenv("POGS_AMD_YSYNC")) ysync_ = std::max(0, std::atoi(ys));
     POGS_CHECK(!(use_cgls_ && multi_), "the CGLS projector is single-GPU");
     constexpr int VEC = Vec16<T>::N;
     n_pad_ = static_cast<int>(round_up(n, VEC));
@@ -1046,7 +1047,10 @@ class DenseSolver final : public SolverBase {
   // (projector_cgls.cpp:59-75, cgls.h:200-323).  x: warm start in, projected x out.
   // Ax_warm: A times the warm start if the caller has it (inside the ADMM loop it is the
   // previous y), which replaces the two initial matrix passes by vector algebra.
-  void cgls_project(const T *x0, const T *y0, T *x, T tol, const T *Ax_warm) {
+  // yacc (with Ax_warm): receives A x by the recurrence A x_warm + sum alpha_k q_k, so that the caller
+  // needs no product for y = A x (cg_fused.h); untouched when the loop takes no step.  Returns the
+  // number of CG steps taken.
+  int cgls_project(const T *x0, const T *y0, T *x, T tol, const T *Ax_warm, T *yacc = nullptr) {
     hipStream_t s = ctx_.stream;
     const int bx = vec_blocks(n_);
     const double shift = 1.0;
@@ -1088,12 +1092,15 @@ class DenseSolver final : public SolverBase {
     const double *S = ctx_.fetch_scalars();
     const double norms0 = std::sqrt(S[kCgS2]);
     const int maxit = (norms0 < kEps) ? 0 : 500;
+    int steps = 0;
     for (int k = 0; k < maxit; ++k) {
       pass_n(cg_p_.p, CgQRowOp<T>{cg_q_.p}, ctx_.S.p + kCgQ2, 1);     // q = A p
       hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(1), 0, s, ctx_.S.p, cg_.p, shift, kEps);
       const int bm = vec_blocks(m_);
       hipLaunchKernelGGL(cg_update_xr_kernel<T>, dim3(bx + bm), dim3(kVecTpb), 0, s, n_, m_, cg_.p, cg_p_.p, x,
-                         cg_q_.p, cg_r_.p, vp, bx);
+                         cg_q_.p, cg_r_.p, vp, bx,
+                         (yacc && Ax_warm) ? (k == 0 ? Ax_warm : static_cast<const T *>(yacc)) : static_cast<const T *>(nullptr),
+                         (yacc && Ax_warm) ? yacc : static_cast<T *>(nullptr));
       sum_vp(bx, ctx_.S.p + kCgX2);
       pass_t(cg_r_.p);
       hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(1), 0, s, ctx_.S.p, cg_.p);
@@ -1102,9 +1109,11 @@ class DenseSolver final : public SolverBase {
       S = ctx_.fetch_scalars();
       const double norms = std::sqrt(S[kCgS2]), normx = std::sqrt(S[kCgX2]);
       ++ctx_.stats.cg_iters;
+      ++steps;
       if ((norms <= norms0 * static_cast<double>(tol)) || (normx * static_cast<double>(tol) >= 1.0)) break;
     }
     launch_axpby<T>(n_, static_cast<T>(1), x0, static_cast<T>(1), x, s);   // x += x0
+    return steps;
   }
 
   // ---- per-solve -----------------------------------------------------------
@@ -1161,6 +1170,7 @@ class DenseSolver final : public SolverBase {
     cur_ = 0;
     zt_scale_ = 1;
     spec_valid_ = false;
+    proj_count_ = 0;
     ctl_.reset();
   }
 
@@ -1218,19 +1228,31 @@ class DenseSolver final : public SolverBase {
     if (use_cgls_) {
       // (2c) CGLS projector (projector_cgls.cpp:52-88), warm-started with the previous x (pogs.cpp:281)
       POGS_HIP_CHECK(hipMemcpyAsync(x_[nw].p, x_[cur_].p, n_ * sizeof(T), hipMemcpyDeviceToDevice, s));
-      cgls_project(xtemp_.p, ytemp_.p, x_[nw].p, ctl_.proj_tol(), y_[cur_].p);
-      StreamArgs<T> a = argsA();
-      a.xin = x_[nw].p;
-      ctx_.stream_timer.begin(s);
-      launch_stream<T, true, false, false, kFull, Tag>(planA_, a,
-                                                  ProjTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p}, s);
-      ctx_.stream_timer.end(s);
-      sum_row_scalars(stream_grid<true, false>(planA_, m_), 2, ctx_.S.p + kDYprev2);
+      // y = A x (projector_cgls.cpp:78): from the CG recurrence y_warm + sum alpha_k q_k, except every
+      // ysync_-th projection, which takes the product itself (cg_fused.h; POGS_AMD_YSYNC)
+      const bool ysync = ysync_ <= 0 || (proj_count_ % static_cast<unsigned long long>(ysync_)) == 0;
+      ++proj_count_;
+      const int steps = cgls_project(xtemp_.p, ytemp_.p, x_[nw].p, ctl_.proj_tol(), y_[cur_].p, ysync ? nullptr : y_[nw].p);
+      if (ysync) {
+        StreamArgs<T> a = argsA();
+        a.xin = x_[nw].p;
+        ctx_.stream_timer.begin(s);
+        launch_stream<T, true, false, false, kFull, Tag>(planA_, a,
+                                                    ProjTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p}, s);
+        ctx_.stream_timer.end(s);
+        sum_row_scalars(stream_grid<true, false>(planA_, m_), 2, ctx_.S.p + kDYprev2);
+        ctx_.stats.matvecs += 1;
+      } else {
+        if (steps == 0) POGS_HIP_CHECK(hipMemcpyAsync(y_[nw].p, y_[cur_].p, m_ * sizeof(T), hipMemcpyDeviceToDevice, s));
+        double *spy = ctx_.spart.p;   // (the prox step's partials there have been summed above)
+        launch_admm_tail<T>(m_, y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, spy, s);
+        SumJob jy{spy, vec_blocks(m_), 2, ctx_.S.p + kDYprev2};
+        launch_sum_jobs(&jy, 1, s);
+      }
       double *sp2 = ctx_.spart.p + static_cast<size_t>(planA_.grid_max) * 6;
       launch_admm_tail<T>(n_, x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, sp2, s);
       SumJob jt{sp2, vec_blocks(n_), 2, ctx_.S.p + kDXprev2};
       launch_sum_jobs(&jt, 1, s);
-      ctx_.stats.matvecs += 1;
     } else if (tall_) {
       // (2) projection: x = (G + I)^{-1} (xtemp + A^T ytemp), y = A x   (projector_direct_dense.cpp:122-127)
       gemv_t_partials(ytemp_.p);
@@ -1651,6 +1673,8 @@ class DenseSolver final : public SolverBase {
   bool warm_pending_ = false;
   std::vector<T> warm_x_, warm_l_;
   T rho_pred_ = 1, zs_pred_ = 1;
+  int ysync_ = 16;                       // dense CGLS option: y = A x explicitly every ysync_-th projection (0: always)
+  unsigned long long proj_count_ = 0;
   DevBuf<T> x_[2], y_[2], xt_, yt_, xtemp_, ytemp_, x12_, y12_, rhs_, tvec_, tmpn_;
   DevBuf<T> xout_, yout_, lout_, muout_;
   FnBuf<T> f_, g_, fs_, gs_;

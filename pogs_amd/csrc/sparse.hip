@@ -1240,7 +1240,8 @@ class SparseSolver final : public SolverBase {
       // x += alpha p ; r -= alpha q ; |x|^2                                  (:274-277)
       const int bm = vec_blocks(m_);
       hipLaunchKernelGGL(cg_update_xr_kernel<T>, dim3(bx + bm), dim3(kVecTpb), 0, s, n_, m_, cg_.p, cg_p_.p, x,
-                         cg_q_.p, cg_r_.p, fuse ? px : ctx_.spart.p, bx);
+                         cg_q_.p, cg_r_.p, fuse ? px : ctx_.spart.p, bx, static_cast<const T *>(nullptr),
+                         static_cast<T *>(nullptr));
       if (fuse) ctx_.queue_sum(SumJob{px, bx, 1, ctx_.S.p + kCgX2});
       else sum_vec_partials(bx, ctx_.S.p + kCgX2);
       // s = A^T r - shift x ; |s|^2 ; beta ; p = s + beta p ; |p|^2          (:281-296)
