@@ -293,7 +293,8 @@ def solve_nonneg_ls(A, b, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0, 
 class Solver:
     """Keeps the equilibrated matrix and its factorisation on the GPU across solves.
 
-    ``A``: numpy array / scipy sparse matrix (host), or an integer device pointer
+    ``A``: numpy array / scipy sparse matrix (host), an integer device pointer (dense), or a tuple
+    (data_ptr, indptr_ptr, indices_ptr, nnz) of device addresses of a CSR matrix (sparse)
     with ``shape=(m, n)`` and ``device_ptr=True`` (e.g. ``tensor.data_ptr()``).
     ``dist``: None, or ``(rank, world, m_global, unique_id_bytes)`` for a
     row-sharded solve where this process holds ``m`` consecutive rows.
@@ -316,7 +317,16 @@ class Solver:
         if device_ptr:
             _lib.check_device_pointer_interop()
         self.sparse = (not device_ptr) and HAS_SCIPY and sp.issparse(A)
-        if self.sparse:
+        if device_ptr and isinstance(A, (tuple, list)):
+            # CSR already resident in HBM: (data_ptr, indptr_ptr, indices_ptr, nnz) device addresses
+            # (data of the solver's dtype, int32 indices), with shape=(m, n)
+            self.sparse = True
+            self.m, self.n = shape
+            dptr, pptr, iptr, nnz = (int(v) for v in A)
+            st = lib.PogsAmdCreateSparse(ctypes.byref(self._h), code, int(Ordering.ROW_MAJ), self.m, self.n, nnz,
+                                         ctypes.c_void_p(dptr), ctypes.c_void_p(pptr), ctypes.c_void_p(iptr), _lib.DEVICE,
+                                         ctypes.byref(opt), ctypes.byref(dist_s) if dist_s is not None else None)
+        elif self.sparse:
             A_csr = sp.csr_matrix(A, dtype=self.dtype)
             self.m, self.n = A_csr.shape
             data = np.ascontiguousarray(A_csr.data, dtype=self.dtype)

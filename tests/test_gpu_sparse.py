@@ -306,6 +306,33 @@ def test_duplicate_entries_give_the_same_bits_run_to_run():
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
+def test_device_resident_csr_gives_the_host_paths_bits():
+    """PogsAmdCreateSparse with mem = POGS_AMD_DEVICE (bench.py hands the CSR arrays over in HBM, as it does
+    the dense matrices): same handle contents, same solve, bit for bit."""
+    import torch
+
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.csr_lasso(6000, 1500, 25, seed=14, dtype=np.float32)
+    f, g = pogs.graph.lasso_functions(b, 0.1, 1500)
+    with pogs.Solver(A, dtype=np.float32) as s:
+        host = s.solve(f, g)
+    dev = torch.device("cuda:0")
+    data = torch.from_numpy(np.ascontiguousarray(A.data, np.float32)).to(dev)
+    ptr = torch.from_numpy(np.ascontiguousarray(A.indptr, np.int32)).to(dev)
+    ind = torch.from_numpy(np.ascontiguousarray(A.indices, np.int32)).to(dev)
+    keep = (data.clone(), ptr.clone(), ind.clone())
+    with pogs.Solver((data.data_ptr(), ptr.data_ptr(), ind.data_ptr(), A.nnz), dtype=np.float32, shape=A.shape,
+                     device_ptr=True) as s:
+        got = s.solve(f, g)
+    assert got["status"] == host["status"] == 0 and got["iterations"] == host["iterations"]
+    for k in "xyl":
+        assert np.array_equal(got[k], host[k]), k
+    # the caller's arrays are never written (SURVEY.md section 8(b): inputs are copied)
+    assert torch.equal(data, keep[0]) and torch.equal(ptr, keep[1]) and torch.equal(ind, keep[2])
+
+
 def test_sparse_warm_start_matches_oracle():
     """Warm start (pogs.cpp:144-156) on the CSR + CGLS path."""
     pogs = _pogs()
