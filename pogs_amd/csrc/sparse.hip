@@ -710,23 +710,27 @@ class SparseSolver final : public SolverBase {
                        r1, cursor.p, second.val.p, second.ind.p);
     hipLaunchKernelGGL(sort_segments_kernel<T>, dim3(std::min(c1, 65536)), dim3(256), 0, s, second.ptr.p, c1,
                        second.ind.p, second.val.p);
-    std::vector<int> hptr2(c1 + 1);
-    POGS_HIP_CHECK(hipMemcpyAsync(hptr2.data(), second.ptr.p, (c1 + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
-    ctx_.sync();
-    auto set_blocks = [&](DevCsr<T> &M, const std::vector<int> &hp) {
-      std::vector<int> b = make_row_blocks(hp, M.nrows);
-      M.nblocks = static_cast<int>(b.size()) - 1;
-      M.blocks.alloc(b.size());
-      POGS_HIP_CHECK(hipMemcpy(M.blocks.p, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
-    };
-    set_blocks(first, hptr);
-    set_blocks(second, hptr2);
     first.ncols = c1;
     second.ncols = r1;
     const char *ev = std::getenv("POGS_AMD_SPMV");
     if (!(ev && ev[0] == 'p')) {   // POGS_AMD_SPMV=plain keeps the plain CSR kernel (testing aid)
       build_sell(first);
       build_sell(second);
+    }
+    // row blocks of the plain CSR kernel: only for a copy that did not get its tiled form (the host
+    // walk over every row and the copy of the transposed ptr array cost ~5 ms at C4)
+    auto set_blocks = [&](DevCsr<T> &M, const std::vector<int> &hp) {
+      std::vector<int> b = make_row_blocks(hp, M.nrows);
+      M.nblocks = static_cast<int>(b.size()) - 1;
+      M.blocks.alloc(b.size());
+      POGS_HIP_CHECK(hipMemcpy(M.blocks.p, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
+    };
+    if (!first.sell_ready) set_blocks(first, hptr);
+    if (!second.sell_ready) {
+      std::vector<int> hptr2(c1 + 1);
+      POGS_HIP_CHECK(hipMemcpyAsync(hptr2.data(), second.ptr.p, (c1 + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+      ctx_.sync();
+      set_blocks(second, hptr2);
     }
     if (ord == ROW_MAJ) { A_ = std::move(first); At_ = std::move(second); }
     else { At_ = std::move(first); A_ = std::move(second); }
