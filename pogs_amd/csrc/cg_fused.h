@@ -282,7 +282,7 @@ struct CgfClose {
   const double *S;
   T *x; const T *xprev, *x12; T *xtemp;           // x <- x + x0 (x0 = xtemp), the x-half bookkeeping
   T *ynew; const T *yprev, *y12; T *ytemp;        // y half (the recurrence's y_new); ynew == nullptr: skip
-  double *part;                                    // [blocks_x + blocks_y][2]
+  double *part;                                    // [blocks_x + blocks_y][2], blocks = pre_blocks()
   int blocks_x;
 };
 // closing launch: x <- x + x0 (projector_cgls.cpp:75) and the element-wise projection tail of both
@@ -294,26 +294,43 @@ __global__ void __launch_bounds__(kVecTpb) cgf_close_kernel(CgfClose<T> a) {
   if (a.S[kFcDone] == 0.0) return;
   double acc[2] = {0.0, 0.0};
   if (static_cast<int>(blockIdx.x) < a.blocks_x) {
-    const int i = blockIdx.x * kVecTpb + threadIdx.x;
-    if (i < a.n) {
-      const T x0 = a.xtemp[i];
-      const T zn = a.x[i] + x0;   // the reference: x <- 1 * x0 + x (blas_axpy)
-      a.x[i] = zn;
-      const T d1 = a.xprev[i] - zn, d2 = a.x12[i] - zn;
-      acc[0] = static_cast<double>(d1) * d1;
-      acc[1] = static_cast<double>(d2) * d2;
-      a.xtemp[i] = x0 - zn;
+    T x0[kPreU], xc[kPreU], xp[kPreU], xh[kPreU];
+#pragma unroll
+    for (int u = 0; u < kPreU; ++u) {
+      const int i = (blockIdx.x * kPreU + u) * kVecTpb + threadIdx.x;
+      if (i < a.n) { x0[u] = a.xtemp[i]; xc[u] = a.x[i]; xp[u] = a.xprev[i]; xh[u] = a.x12[i]; }
+    }
+#pragma unroll
+    for (int u = 0; u < kPreU; ++u) {
+      const int i = (blockIdx.x * kPreU + u) * kVecTpb + threadIdx.x;
+      if (i < a.n) {
+        const T zn = xc[u] + x0[u];   // the reference: x <- 1 * x0 + x (blas_axpy)
+        a.x[i] = zn;
+        const T d1 = xp[u] - zn, d2 = xh[u] - zn;
+        acc[0] += static_cast<double>(d1) * d1;
+        acc[1] += static_cast<double>(d2) * d2;
+        a.xtemp[i] = x0[u] - zn;
+      }
     }
   } else {
-    const int i = (blockIdx.x - a.blocks_x) * kVecTpb + threadIdx.x;
-    if (i < a.m) {
-      const T yp = a.yprev[i];
-      const T zn = (a.S[kFcSteps] == 0.0) ? yp : a.ynew[i];
-      a.ynew[i] = zn;
-      const T d1 = yp - zn, d2 = a.y12[i] - zn;
-      acc[0] = static_cast<double>(d1) * d1;
-      acc[1] = static_cast<double>(d2) * d2;
-      a.ytemp[i] -= zn;
+    const bool no_step = a.S[kFcSteps] == 0.0;
+    T yp[kPreU], yn[kPreU], yh[kPreU], yt[kPreU];
+#pragma unroll
+    for (int u = 0; u < kPreU; ++u) {
+      const int i = ((blockIdx.x - a.blocks_x) * kPreU + u) * kVecTpb + threadIdx.x;
+      if (i < a.m) { yp[u] = a.yprev[i]; yn[u] = no_step ? yp[u] : a.ynew[i]; yh[u] = a.y12[i]; yt[u] = a.ytemp[i]; }
+    }
+#pragma unroll
+    for (int u = 0; u < kPreU; ++u) {
+      const int i = ((blockIdx.x - a.blocks_x) * kPreU + u) * kVecTpb + threadIdx.x;
+      if (i < a.m) {
+        const T zn = yn[u];
+        a.ynew[i] = zn;
+        const T d1 = yp[u] - zn, d2 = yh[u] - zn;
+        acc[0] += static_cast<double>(d1) * d1;
+        acc[1] += static_cast<double>(d2) * d2;
+        a.ytemp[i] = yt[u] - zn;
+      }
     }
   }
   dev::block_sum<2, kVecTpb>(acc, s_red);

@@ -1218,11 +1218,11 @@ class DenseSolver final : public SolverBase {
     pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
     pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
     pa.partials = ctx_.spart.p;
-    pa.blocks_x = vec_blocks(n_);
+    pa.blocks_x = pre_blocks(n_);
     launch_admm_pre<T>(pa, s);
     {
       SumJob j[2] = {{ctx_.spart.p, pa.blocks_x, 3, ctx_.S.p + kGapX},
-                     {ctx_.spart.p + static_cast<size_t>(pa.blocks_x) * 3, vec_blocks(m_), 3, ctx_.S.p + kGapY}};
+                     {ctx_.spart.p + static_cast<size_t>(pa.blocks_x) * 3, pre_blocks(m_), 3, ctx_.S.p + kGapY}};
       launch_sum_jobs(j, 2, s);
     }
     if (use_cgls_) {
@@ -1338,7 +1338,7 @@ class DenseSolver final : public SolverBase {
   bool iteration_fused(unsigned verbose) {
     hipStream_t s = ctx_.stream;
     const int nw = cur_ ^ 1;
-    const int by = vec_blocks(m_);
+    const int by = pre_blocks(m_);
     const int gridC = pre_cols_grid(n_pad_, Vec16<T>::N);
     // every scalar sum of the iteration that needs no exchange runs in the launch that publishes
     // the scalar block; on row shards the y-side sums travel in the tail of the pack buffer
@@ -1490,7 +1490,7 @@ class DenseSolver final : public SolverBase {
   bool iteration_fused_wide(unsigned verbose) {
     hipStream_t s = ctx_.stream;
     const int nw = cur_ ^ 1;
-    const int bx = vec_blocks(n_), by = vec_blocks(m_);
+    const int bx = pre_blocks(n_), by = pre_blocks(m_);
     // (A) prox / over-relaxation: y half always, x half unless already speculated
     AdmmPreArgs<T> pa;
     pa.n_x = spec_valid_ ? 0 : n_; pa.n_y = m_;

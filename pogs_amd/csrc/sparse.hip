@@ -1288,7 +1288,7 @@ class SparseSolver final : public SolverBase {
   // (cg_fused.h): 6 launches per CG step, one host poll.  Returns the published block.
   const double *prox_and_project_fused(const AdmmPreArgs<T> &pa0, int nw) {
     hipStream_t s = ctx_.stream;
-    const int bx = vec_blocks(n_), bm = vec_blocks(m_);
+    const int bx = pre_blocks(n_), bm = pre_blocks(m_);
     double *S = ctx_.S.p;
     double *rec_t = cg_rec_.p, *rec_a = cg_rec_.p + cg_rec_cap_;          // A^T products, A products
     double *rec_x = ctx_.spart.p + sp_cgx_off_, *rec_p = ctx_.spart.p + sp_cgp_off_;
@@ -1392,7 +1392,7 @@ class SparseSolver final : public SolverBase {
     pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
     pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
     pa.partials = ctx_.spart.p + sp_pre_off_;
-    pa.blocks_x = vec_blocks(n_);
+    pa.blocks_x = pre_blocks(n_);
     const double *S;
     if (fused_cg_) {
       S = prox_and_project_fused(pa, nw);
@@ -1400,7 +1400,7 @@ class SparseSolver final : public SolverBase {
     launch_admm_pre<T>(pa, s);
     {
       SumJob j[2] = {{pa.partials, pa.blocks_x, 3, ctx_.S.p + kGapX},
-                     {pa.partials + static_cast<size_t>(pa.blocks_x) * 3, vec_blocks(m_), 3, ctx_.S.p + kGapY}};
+                     {pa.partials + static_cast<size_t>(pa.blocks_x) * 3, pre_blocks(m_), 3, ctx_.S.p + kGapY}};
       if (!multi_) {
         // one GPU: summed by the launch that publishes the scalar block next (the first fetch of the
         // projection); the partials have a region of their own until then

@@ -48,7 +48,7 @@ struct AdmmPreArgs {
   T *x12, *y12;
   T *xtemp, *ytemp;
   T rho, alpha;
-  double *partials;  // [blocks_x + blocks_y][3]
+  double *partials;  // [blocks_x + blocks_y][3]; blocks = pre_blocks(n)
   int blocks_x;
   // optional (CGLS warm start, cg_fused.h): x_aux = x_cur - xtemp_new, y_aux = ytemp_new - y_cur;
   // cg_reset[0..1] = 0 (the CG loop's done flag and step count)
@@ -65,6 +65,10 @@ void launch_scale_objective(FnView<T> fn, T *a, T *c, T *d, T *e, const T *scale
 
 constexpr int kVecTpb = 256;
 inline int vec_blocks(int n) { return (n + kVecTpb - 1) / kVecTpb; }
+// admm_pre_kernel / cgf_close_kernel: kPreU chunks of kVecTpb elements per workgroup -- a quarter of the
+// workgroup reductions and of the partial sums the closing launch adds up (1.1e6 elements at C4)
+constexpr int kPreU = 4;
+inline int pre_blocks(int n) { return (n + kVecTpb * kPreU - 1) / (kVecTpb * kPreU); }
 
 // pre-projection step: prox, gap / norm partials, over-relaxation.
 // Writes partials [blocks][3] = {sum w*h, sum w^2, sum h^2}; x blocks first.

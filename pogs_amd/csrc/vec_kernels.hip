@@ -37,26 +37,39 @@ __global__ void __launch_bounds__(kVecTpb) admm_pre_kernel(AdmmPreArgs<T> a) {
   const T *zt = is_x ? a.xt : a.yt;
   T *z12 = is_x ? a.x12 : a.y12;
   T *ztemp = is_x ? a.xtemp : a.ytemp;
-  const int i = blk * kVecTpb + threadIdx.x;
   if (a.cg_reset && blockIdx.x == 0 && threadIdx.x == 0) {
     a.cg_reset[0] = 0.0;
     a.cg_reset[1] = 0.0;
   }
+  T *aux = is_x ? a.x_aux : a.y_aux;
   double acc[3] = {0.0, 0.0, 0.0};
-  if (i < n) {
-    const T prev = cur[i];
-    const T ztv = a.zt_scale * zt[i];
-    const T v = prev - ztv;                                       // pogs.cpp:257
-    const T h = dev::ProxEval(fn.h[i], fn.a[i], fn.b[i], fn.c[i], fn.d[i], fn.e[i], v, a.rho);  // :263
-    const T w = v - h;                                            // :267
-    z12[i] = h;
-    const T zt_new = ztv + a.alpha * h + (static_cast<T>(1) - a.alpha) * prev;   // :276-278
-    ztemp[i] = zt_new;
-    T *aux = is_x ? a.x_aux : a.y_aux;
-    if (aux) aux[i] = is_x ? prev - zt_new : zt_new - prev;
-    acc[0] = static_cast<double>(w) * h;                          // :268
-    acc[1] = static_cast<double>(w) * w;
-    acc[2] = static_cast<double>(h) * h;
+  // all loads of the kPreU chunks first: the kernel is a latency chain of eight streams per element
+  T prev[kPreU], ztv[kPreU], fa[kPreU], fb[kPreU], fc[kPreU], fd[kPreU], fe[kPreU];
+  int fh[kPreU];
+#pragma unroll
+  for (int u = 0; u < kPreU; ++u) {
+    const int i = (blk * kPreU + u) * kVecTpb + threadIdx.x;
+    if (i < n) {
+      prev[u] = cur[i]; ztv[u] = zt[i];
+      fh[u] = fn.h[i]; fa[u] = fn.a[i]; fb[u] = fn.b[i]; fc[u] = fn.c[i]; fd[u] = fn.d[i]; fe[u] = fn.e[i];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kPreU; ++u) {
+    const int i = (blk * kPreU + u) * kVecTpb + threadIdx.x;
+    if (i < n) {
+      const T zs = a.zt_scale * ztv[u];
+      const T v = prev[u] - zs;                                     // pogs.cpp:257
+      const T h = dev::ProxEval(fh[u], fa[u], fb[u], fc[u], fd[u], fe[u], v, a.rho);  // :263
+      const T w = v - h;                                            // :267
+      z12[i] = h;
+      const T zt_new = zs + a.alpha * h + (static_cast<T>(1) - a.alpha) * prev[u];   // :276-278
+      ztemp[i] = zt_new;
+      if (aux) aux[i] = is_x ? prev[u] - zt_new : zt_new - prev[u];
+      acc[0] += static_cast<double>(w) * h;                         // :268
+      acc[1] += static_cast<double>(w) * w;
+      acc[2] += static_cast<double>(h) * h;
+    }
   }
   dev::block_sum<3, kVecTpb>(acc, s_red);
   if (threadIdx.x == 0) {
@@ -237,7 +250,7 @@ void launch_scale_objective(FnView<T> fn, T *a, T *c, T *d, T *e, const T *scale
 
 template <typename T>
 void launch_admm_pre(const AdmmPreArgs<T> &a, hipStream_t s) {
-  const int blocks = a.blocks_x + vec_blocks(a.n_y);
+  const int blocks = a.blocks_x + pre_blocks(a.n_y);
   hipLaunchKernelGGL(admm_pre_kernel<T>, dim3(blocks), dim3(kVecTpb), 0, s, a);
 }
 
