@@ -1142,6 +1142,9 @@ class DenseSolver final : public SolverBase {
         all_logistic = all_logistic && f.h[i] == kLogistic;
       }
     }
+    pre_cheap_ = true;
+    for (int i = 0; i < m_ && pre_cheap_; ++i) pre_cheap_ = is_cheap_prox(f.h[i]);
+    for (int j = 0; j < n_ && pre_cheap_; ++j) pre_cheap_ = is_cheap_prox(g.h[j]);
     fused_now_ = fused_ok_ && (all_cheap || all_logistic);
     fused_logistic_ = fused_now_ && all_logistic && !all_cheap;
     // scaled copies: h and b shared with the originals (pogs.cpp:608-617)
@@ -1216,7 +1219,7 @@ class DenseSolver final : public SolverBase {
     pa.zt_scale = zt_scale_;
     pa.x12 = x12_.p; pa.y12 = y12_.p;
     pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
-    pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
+    pa.rho = ctl_.rho; pa.alpha = ctl_.alpha(); pa.cheap = pre_cheap_;
     pa.partials = ctx_.spart.p;
     pa.blocks_x = pre_blocks(n_);
     launch_admm_pre<T>(pa, s);
@@ -1365,7 +1368,7 @@ class DenseSolver final : public SolverBase {
       pa.zt_scale = zt_scale_;
       pa.x12 = x12_.p; pa.y12 = y12_.p;
       pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
-      pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
+      pa.rho = ctl_.rho; pa.alpha = ctl_.alpha(); pa.cheap = pre_cheap_;
       pa.partials = pre_part;
       pa.blocks_x = 0;
       launch_admm_pre<T>(pa, s);
@@ -1500,7 +1503,7 @@ class DenseSolver final : public SolverBase {
     pa.zt_scale = zt_scale_;
     pa.x12 = x12_.p; pa.y12 = y12_.p;
     pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
-    pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
+    pa.rho = ctl_.rho; pa.alpha = ctl_.alpha(); pa.cheap = pre_cheap_;
     pa.partials = ctx_.spart.p;
     pa.blocks_x = spec_valid_ ? 0 : bx;
     launch_admm_pre<T>(pa, s);
@@ -1666,6 +1669,7 @@ class DenseSolver final : public SolverBase {
   DevBuf<double> cg_;
   size_t lda_ = 0;
   StreamPlan planA_, planW_;
+  bool pre_cheap_ = false;      // every f_i, g_j has a few-operation prox (admm_pre_kernel inlines it)
   T *Wp_ = nullptr, *Up_ = nullptr;   // views into fac_
   DevBuf<T> A_, fac_, d_, e_, colpart_, colpart2_, y12s_, ytemps_;
   DevBuf<double> pack_;         // row shards, one-pass iteration: the packed all-reduce buffer

@@ -1146,6 +1146,9 @@ class SparseSolver final : public SolverBase {
     up(g_, g, n_);
     warn_negative_coeffs<T>(f, m_);   // prox_lib.h:62-69 (the clamp is in scale_objective_kernel)
     warn_negative_coeffs<T>(g, n_);
+    pre_cheap_ = true;
+    for (int i = 0; i < m_ && pre_cheap_; ++i) pre_cheap_ = is_cheap_prox(f.h[i]);
+    for (int j = 0; j < n_ && pre_cheap_; ++j) pre_cheap_ = is_cheap_prox(g.h[j]);
     launch_scale_objective<T>(f_.view(), fs_.a.p, fs_.c.p, fs_.d.p, fs_.e.p, d_.p, m_, true, s);
     launch_scale_objective<T>(g_.view(), gs_.a.p, gs_.c.p, gs_.d.p, gs_.e.p, e_.p, n_, false, s);
     ctl_ = AdmmControl<T>();
@@ -1390,7 +1393,7 @@ class SparseSolver final : public SolverBase {
     pa.zt_scale = zt_scale_;
     pa.x12 = x12_.p; pa.y12 = y12_.p;
     pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
-    pa.rho = ctl_.rho; pa.alpha = ctl_.alpha();
+    pa.rho = ctl_.rho; pa.alpha = ctl_.alpha(); pa.cheap = pre_cheap_;
     pa.partials = ctx_.spart.p + sp_pre_off_;
     pa.blocks_x = pre_blocks(n_);
     const double *S;
@@ -1528,6 +1531,7 @@ class SparseSolver final : public SolverBase {
   size_t cg_rec_cap_ = 0;
   int ysync_ = 16;               // y = A x explicitly every ysync_-th iteration (0: always), else by recurrence
   unsigned long long proj_count_ = 0;
+  bool pre_cheap_ = false;       // every f_i, g_j has a few-operation prox (admm_pre_kernel inlines it)
   FnBuf<T> f_, g_, fs_, gs_;
   AdmmControl<T> ctl_;
   bool loaded_ = false;   // load_problem has run: f, g and the control block are valid

@@ -54,6 +54,9 @@ struct AdmmPreArgs {
   // cg_reset[0..1] = 0 (the CG loop's done flag and step count)
   T *x_aux = nullptr, *y_aux = nullptr;
   double *cg_reset = nullptr;
+  // every f_i and g_j is one of the few-operation base functions (is_cheap_prox): the prox is inlined
+  // instead of a call into the full library (Lambert W, cubic roots, Newton steps behind one switch)
+  bool cheap = false;
 };
 
 // clamp c,e >= 0 (FunctionObj::CheckConsts, prox_lib.h:62-69) and scale by the

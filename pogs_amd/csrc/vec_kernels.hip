@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(kVecTpb) scale_objective_kernel(FnView<T> fn, 
   a[i] = ai; c[i] = ci; d[i] = di; e[i] = ei;
 }
 
-template <typename T>
+template <typename T, bool CHEAP>
 __global__ void __launch_bounds__(kVecTpb) admm_pre_kernel(AdmmPreArgs<T> a) {
   __shared__ double s_red[3 * (kVecTpb / 64)];
   const bool is_x = static_cast<int>(blockIdx.x) < a.blocks_x;
@@ -60,7 +60,8 @@ __global__ void __launch_bounds__(kVecTpb) admm_pre_kernel(AdmmPreArgs<T> a) {
     if (i < n) {
       const T zs = a.zt_scale * ztv[u];
       const T v = prev[u] - zs;                                     // pogs.cpp:257
-      const T h = dev::ProxEval(fh[u], fa[u], fb[u], fc[u], fd[u], fe[u], v, a.rho);  // :263
+      const T h = CHEAP ? dev::ProxEvalCheap(fh[u], fa[u], fb[u], fc[u], fd[u], fe[u], v, a.rho)
+                        : dev::ProxEval(fh[u], fa[u], fb[u], fc[u], fd[u], fe[u], v, a.rho);  // :263
       const T w = v - h;                                            // :267
       z12[i] = h;
       const T zt_new = zs + a.alpha * h + (static_cast<T>(1) - a.alpha) * prev[u];   // :276-278
@@ -251,7 +252,8 @@ void launch_scale_objective(FnView<T> fn, T *a, T *c, T *d, T *e, const T *scale
 template <typename T>
 void launch_admm_pre(const AdmmPreArgs<T> &a, hipStream_t s) {
   const int blocks = a.blocks_x + pre_blocks(a.n_y);
-  hipLaunchKernelGGL(admm_pre_kernel<T>, dim3(blocks), dim3(kVecTpb), 0, s, a);
+  if (a.cheap) hipLaunchKernelGGL((admm_pre_kernel<T, true>), dim3(blocks), dim3(kVecTpb), 0, s, a);
+  else hipLaunchKernelGGL((admm_pre_kernel<T, false>), dim3(blocks), dim3(kVecTpb), 0, s, a);
 }
 
 template <typename T>
