@@ -15,6 +15,7 @@
 // W = inv(chol(A^T A + I)) lower-triangular and U = W^T, both n x n_pad.
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
@@ -36,11 +37,14 @@ void rand_uniform_host(double *x, size_t n);
 
 namespace {
 
-// A <- diag(d) A diag(e), accumulating sum of squares of the result
-// (MultDiag + NormEst(kNormFro), matrix_dense.cpp:181,184,215-237).
-template <typename T>
-__global__ void __launch_bounds__(256) scale_de_kernel(T *A, size_t lda, int m, int n_pad, const T *d,
-                                                       const T *e, double *partials, double *max_partials) {
+// diag(d) A diag(e) in two passes (MultDiag + NormEst(kNormFro) + the division by the norm,
+// matrix_dense.cpp:181-186,215-237).  WRITE = false: nothing is stored -- the sum of squares and the largest
+// |entry| of the scaled matrix only.  WRITE = true: dst = (src_ij (d_i e_j)) * post, the same two roundings as
+// storing the scaled matrix and multiplying it by 1 / normA in a pass of its own, which this replaces
+// (read + read/write instead of two read/writes of the matrix; src may be the caller's own buffer).
+template <typename T, bool WRITE>
+__global__ void __launch_bounds__(256) scale_de_kernel(const T *src, T *dst, size_t lda, int m, int n_pad, const T *d,
+                                                       const T *e, T post, double *partials, double *max_partials) {
   using V = typename Vec16<T>::type;
   constexpr int VEC = Vec16<T>::N;
   __shared__ double s_red[4];
@@ -50,22 +54,26 @@ __global__ void __launch_bounds__(256) scale_de_kernel(T *A, size_t lda, int m, 
   T amax = 0;
   for (int row = blockIdx.x; row < m; row += gridDim.x) {
     const T di = d[row];
-    T *rp = A + static_cast<size_t>(row) * lda;
+    const T *rp = src + static_cast<size_t>(row) * lda;
     for (int v = threadIdx.x; v < vpr; v += 256) {
-      V a = *reinterpret_cast<V *>(rp + v * VEC);
+      V a = WRITE ? stream_load<V>(rp + v * VEC) : *reinterpret_cast<const V *>(rp + v * VEC);
       const V ev = *reinterpret_cast<const V *>(e + v * VEC);
       T *ap = reinterpret_cast<T *>(&a);
       const T *ep = reinterpret_cast<const T *>(&ev);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) {
         const T val = ap[c] * (di * ep[c]);
-        ap[c] = val;
-        acc[0] += static_cast<double>(val) * val;
-        amax = fmax(amax, fabs(val));
+        if (WRITE) {
+          ap[c] = val * post;
+        } else {
+          acc[0] += static_cast<double>(val) * val;
+          amax = fmax(amax, fabs(val));
+        }
       }
-      *reinterpret_cast<V *>(rp + v * VEC) = a;
+      if (WRITE) *reinterpret_cast<V *>(dst + static_cast<size_t>(row) * lda + v * VEC) = a;
     }
   }
+  if (WRITE) return;
   dev::block_sum<1, 256>(acc, s_red);
   double mx = static_cast<double>(amax);
   for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
@@ -74,20 +82,6 @@ __global__ void __launch_bounds__(256) scale_de_kernel(T *A, size_t lda, int m, 
   if (threadIdx.x == 0) {
     partials[blockIdx.x] = acc[0];
     max_partials[blockIdx.x] = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
-  }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256) scale_all_kernel(T *A, size_t count_vec, T s) {
-  using V = typename Vec16<T>::type;
-  constexpr int VEC = Vec16<T>::N;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count_vec;
-       i += static_cast<size_t>(gridDim.x) * 256) {
-    V a = reinterpret_cast<V *>(A)[i];
-    T *ap = reinterpret_cast<T *>(&a);
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) ap[c] *= s;
-    reinterpret_cast<V *>(A)[i] = a;
   }
 }
 
@@ -117,7 +111,7 @@ class DenseSolver final : public SolverBase {
         preload.t = std::thread([dev] {
           hipFuncAttributes fa;
           if (hipSetDevice(dev) != hipSuccess) return;
-          (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(scale_all_kernel<T>));
+          (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(scale_de_kernel<T, true>));
           preload_vec_code();
           preload_gemm_code();
         });
@@ -337,10 +331,18 @@ class DenseSolver final : public SolverBase {
     hipStream_t s = ctx_.stream;
     A_.alloc(static_cast<size_t>(srows_) * lda_);
     const hipMemcpyKind kind = (mem == POGS_AMD_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    // A matrix that is already in HBM in the stored layout (same pitch, 16-byte aligned) is not copied: the
+    // equilibration passes read the caller's buffer and its last pass writes the scaled matrix straight into
+    // A_ (equilibrate()); the caller's buffer is never written.  4 GB less to copy at C2 (1.5 ms).
+    const char *ae = std::getenv("POGS_AMD_ALIAS_INPUT");
+    const bool may_alias = mem == POGS_AMD_DEVICE && !(ae && ae[0] == '0') &&
+                           (reinterpret_cast<uintptr_t>(A) % 16) == 0;
     if (tmode_) {
       // stored matrix = A^T, n rows of m: column-major input already is that; row-major is transposed
       if (lda_ != static_cast<size_t>(m_)) A_.zero(s);
-      if (ord != ROW_MAJ) {
+      if (ord != ROW_MAJ && may_alias && lda_ == static_cast<size_t>(m_)) {
+        A_src_ = static_cast<const T *>(A);
+      } else if (ord != ROW_MAJ) {
         POGS_HIP_CHECK(hipMemcpy2DAsync(A_.p, lda_ * sizeof(T), A, m_ * sizeof(T), m_ * sizeof(T), n_, kind, s));
       } else {
         DevBuf<T> stage;
@@ -353,6 +355,8 @@ class DenseSolver final : public SolverBase {
         launch_transpose<T>(src, n_, m_, n_, A_.p, lda_, s);
         ctx_.sync();   // stage is freed at scope exit
       }
+    } else if (ord == ROW_MAJ && may_alias && lda_ == static_cast<size_t>(n_)) {
+      A_src_ = static_cast<const T *>(A);
     } else if (ord == ROW_MAJ) {
       if (lda_ != static_cast<size_t>(n_)) A_.zero(s);
       POGS_HIP_CHECK(hipMemcpy2DAsync(A_.p, lda_ * sizeof(T), A, n_ * sizeof(T), n_ * sizeof(T), m_, kind, s));
@@ -539,6 +543,7 @@ class DenseSolver final : public SolverBase {
     const int gridACC = stream_grid<false, true>(planA_, srows_);
     const int gridBOTH = stream_grid<true, true>(planA_, srows_);
     StreamArgs<T> a = argsA();
+    if (A_src_) a.A = A_src_;   // the caller's buffer (upload()): read-only until the scaled copy is written
     ctx_.tmark("  eq: start");
     // The reference runs a fixed 50 iterations (equil_helper.h:147).  After a few of them the only
     // thing that still moves is the common factor (d * a, e / a) -- the unregularised iteration
@@ -645,8 +650,10 @@ class DenseSolver final : public SolverBase {
     launch_sqrt_inplace<T>(e_.p, n_, s);
     const int sgrid = std::min(srows_, ctx_.num_cu * 8);
     // rows of the stored matrix are scaled by the first vector, its columns by the second
-    hipLaunchKernelGGL(scale_de_kernel<T>, dim3(sgrid), dim3(256), 0, s, A_.p, lda_, srows_, scols_pad_,
-                       tmode_ ? e_.p : d_.p, tmode_ ? d_.p : e_.p, ctx_.spart.p, ctx_.spart.p + sgrid);
+    const T *src = A_src_ ? A_src_ : A_.p;
+    const T *dr = tmode_ ? e_.p : d_.p, *dc = tmode_ ? d_.p : e_.p;
+    hipLaunchKernelGGL((scale_de_kernel<T, false>), dim3(sgrid), dim3(256), 0, s, src, static_cast<T *>(nullptr), lda_,
+                       srows_, scols_pad_, dr, dc, static_cast<T>(1), ctx_.spart.p, ctx_.spart.p + sgrid);
     sum_row_scalars(sgrid, 1, ctx_.S.p + kFro2);
     launch_max_partials(ctx_.spart.p + sgrid, sgrid, ctx_.S.p + kAmax, s);
     if (multi_) ctx_.dist.allreduce(ctx_.S.p + kFro2, 1, s);
@@ -654,9 +661,10 @@ class DenseSolver final : public SolverBase {
     const T normA = static_cast<T>(std::sqrt(S[kFro2])) /
                     std::sqrt(static_cast<T>(std::min<double>(mg, nn)));   // :215-218
     amax_ = S[kAmax] / static_cast<double>(normA);   // largest |entry| of the equilibrated matrix (this shard)
-    const size_t nvec = static_cast<size_t>(srows_) * lda_ / Vec16<T>::N;
-    hipLaunchKernelGGL(scale_all_kernel<T>, dim3(ctx_.num_cu * 8), dim3(256), 0, s, A_.p, nvec,
-                       static_cast<T>(1) / normA);                         // :186
+    hipLaunchKernelGGL((scale_de_kernel<T, true>), dim3(sgrid), dim3(256), 0, s, src, A_.p, lda_, srows_, scols_pad_,
+                       dr, dc, static_cast<T>(1) / normA, static_cast<double *>(nullptr),
+                       static_cast<double *>(nullptr));                    // :181,186
+    A_src_ = nullptr;   // from here on the solver's own (equilibrated) copy
     const T invs = static_cast<T>(1) / std::sqrt(normA);                   // :191-192
     launch_scal<T>(d_.p, invs, m_, s);
     launch_scal<T>(e_.p, invs, n_, s);
@@ -1669,6 +1677,7 @@ class DenseSolver final : public SolverBase {
   DevBuf<double> cg_;
   size_t lda_ = 0;
   StreamPlan planA_, planW_;
+  const T *A_src_ = nullptr;    // upload() .. equilibrate(): the caller's device buffer standing in for A_
   bool pre_cheap_ = false;      // every f_i, g_j has a few-operation prox (admm_pre_kernel inlines it)
   T *Wp_ = nullptr, *Up_ = nullptr;   // views into fac_
   DevBuf<T> A_, fac_, d_, e_, colpart_, colpart2_, y12s_, ytemps_;
