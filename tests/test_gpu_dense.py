@@ -1123,3 +1123,56 @@ def test_random_mixed_function_problems_follow_the_oracle(seed):
         fin = np.isfinite(b)
         if fin.any():
             assert np.linalg.norm(a[fin] - b[fin]) <= 1e-8 * max(np.linalg.norm(b[fin]), 1.0), (key, seed, m, n, sparse)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,col_major", [((3000, 400), False), ((400, 3000), True), ((2999, 402), False)])
+def test_a_device_resident_matrix_is_read_in_place_and_left_untouched(monkeypatch, dtype, shape, col_major):
+    """A matrix that is already in HBM in the stored layout is not copied at setup: the equilibration
+    passes read the caller's buffer and the last one writes the scaled matrix into the solver's own
+    (DenseSolver::upload / equilibrate).  The solve has to come out bit for bit as from host arrays
+    (which are uploaded into the solver's buffer and scaled in place) and as with
+    POGS_AMD_ALIAS_INPUT=0; the caller's buffer must hold the same bytes afterwards; a pointer that
+    is not 16-byte aligned (or a row pitch that is not the padded one: 402 fp64 columns are, 402
+    fp32 columns are not... both are exercised) silently takes the copy."""
+    import torch
+
+    pogs = _pogs()
+    from pogs_amd import synth
+    from pogs_amd.graph import Ordering
+
+    m, n = shape
+    A, b, _ = synth.dense_lasso(m, n, seed=77, dtype=np.float64)
+    A = np.ascontiguousarray(A.astype(dtype))
+    f, g = pogs.graph.lasso_functions(b, 0.2, n)
+    order = Ordering.COL_MAJ if col_major else Ordering.ROW_MAJ
+    stored = np.ascontiguousarray(A.T) if col_major else A     # the bytes as the ABI sees them
+    with pogs.Solver(np.asfortranarray(A) if col_major else A, dtype=dtype, order=order) as s:
+        want = s.solve(f, g)
+    assert want["status"] == 0
+    dev = torch.device("cuda:0")
+
+    def solve_from(ptr_owner, ptr):
+        with pogs.Solver(ptr, dtype=dtype, shape=(m, n), device_ptr=True, order=order) as s:
+            r = s.solve(f, g)
+        torch.cuda.synchronize()
+        return r
+
+    Ad = torch.from_numpy(stored).to(dev)
+    keep = Ad.clone()
+    for alias in ("1", "0"):
+        monkeypatch.setenv("POGS_AMD_ALIAS_INPUT", alias)
+        got = solve_from(Ad, Ad.data_ptr())
+        assert torch.equal(Ad, keep), "the caller's matrix was written (alias=%s)" % alias
+        assert got["iterations"] == want["iterations"], alias
+        assert np.array_equal(got["x"], want["x"]) and np.array_equal(got["y"], want["y"]), alias
+    monkeypatch.setenv("POGS_AMD_ALIAS_INPUT", "1")
+    # the same matrix one element into a larger allocation: fp32 -> 4 bytes off a 16-byte boundary
+    big = torch.empty(stored.size + 8, dtype=Ad.dtype, device=dev)
+    off = big[1:1 + stored.size].view(stored.shape)
+    off.copy_(Ad)
+    got = solve_from(big, off.data_ptr())
+    assert torch.equal(off, keep)
+    assert got["iterations"] == want["iterations"]
+    assert np.array_equal(got["x"], want["x"])
