@@ -524,7 +524,8 @@ void launch_stream_plain(const StreamPlan &p, const StreamArgs<T> &a, const Op &
   if constexpr (Tag::has(TPB_, NV_)) {                                                          \
     if (p.tpb == TPB_ && p.nv == NV_) {                                                         \
       constexpr int R_ = RowsPerStep<DOT, ACC, TPB_>::value;                                    \
-      if constexpr (DOT && ACC && !SQ && TRI == kLower) {                                       \
+      /* (1024, 8): 128 VGPRs per thread -- the phased kernel spills 26-45 of them, the plain one 17-21 */ \
+      if constexpr (DOT && ACC && !SQ && TRI == kLower && !(TPB_ == 1024 && NV_ == 8)) {        \
         if (a.col0 == 0 && tri_phases_enabled()) {                                              \
           hipLaunchKernelGGL((stream_tri_kernel<T, TPB_, NV_, R_, Op>), dim3(grid), dim3(TPB_), 0, s, a, op); \
           return;                                                                               \
