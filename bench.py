@@ -10,19 +10,30 @@ that rank.
 Workloads (BASELINE.json `configs`); rows are PER GPU ("weak" scaling):
   c2 (default, the metric's configuration): solve_lasso, dense fp32, A = 100000 x 10000 per
       GPU, synthetic N(0,1), x_true 10% dense, b = A x_true + 0.1 N(0,1), lambda = 0.1,
-      default tolerances, direct projector.  N = 8 is config C5 (800000 x 10000).  At N = 1 the
-      matrix is numpy's (pogs_amd.synth.dense_lasso_rows(seed=2024), the committed fixture's
-      problem), at N > 1 every rank draws its rows on its device (torch, seed 1000 + rank).
+      default tolerances, direct projector.  N = 8 is config C5 (800000 x 10000).
   c3: solve_logistic, dense fp32, A = 200000 x 5000, labels from logits with std 2
       (pogs_amd/synth.py: the reference recipe is nearly separable at this size), lambda = 0.01.
   c4: solve_lasso, CSR fp32, A = 2000000 x 500000 with 50 non-zeros per row, CGLS projector.
+  c2f64: c2's matrix widened to fp64 -- the arithmetic type of the reference's Python layer
+      (python/pogs/graph.py:281-288), i.e. what a caller who keeps its calling convention runs.
+
+At N = 1 every workload is the problem of a committed fixture of the COMPILED REFERENCE's own
+solution (tests/golden/c2_reference.npz, c3_reference.npz, c4_reference.npz: numpy PCG64
+generators of pogs_amd/synth.py, regenerated here bit for bit and checked against the fixture's
+checksums), so each line carries `parity_vs_reference`.  At N > 1 every rank draws its rows on its
+device (torch, seed 1000 + rank; x_true shared): the shards are row ranges of ONE problem, which
+rank 0 regenerates whole and -- when it fits one GPU -- solves unsharded after the timed region;
+`parity_vs_reference` then holds the sharded solution against that solve (the unsharded engine is
+the one pinned to the reference at N = 1).
 
 A step is ONE ADMM iteration of a real default-tolerance solve (prox, gap and tolerance
 sums, over-relaxation, projection, residual bookkeeping, dual update, adaptive rho, exact
 residuals whenever the reference would evaluate them); when a solve converges the next step
 starts the next solve from the cold start, so K steps are K genuine iterations.  The one-time
 setup (equilibration, norm estimate, Gram + Cholesky / blocked SpMV layout) is outside the
-timed region (init_s); a complete cold solve is reported as time_to_converge_s.
+timed region (init_s); a complete cold solve is reported as time_to_converge_s, and
+`handle_cycles` repeats create / solve / destroy five times (what a caller of the one-shot ABI
+pays per call, src/interface_c/pogs_c.cpp:19-20) and reports every cycle and the slowest.
 
 value = N * K / T: iterations of one per-GPU shard per second, summed over ranks (at N = 1 the
 ADMM it/s of the configuration).  T is the max over ranks of the time of exactly K steps
@@ -31,17 +42,18 @@ windows are timed back to back and their mean is reported (`windows`, `window_s`
 
 Inputs are resident in HBM when the timed region starts.  The JSON line carries `roofline`
 (the dominant kernel, timed with HIP events on the solver's stream over the timed region)
-and, at N = 1, `cpu_baseline`: the compiled reference (oracle/_ref, clean subprocess) on the
-same (A, b, lambda) on this box's host cores, on the WHOLE matrix (no row sample, nothing
-scaled), capped at --cpu-iters ADMM iterations -- on the GPU box's host its fp32 build does not
-reach the default tolerances at c2 and would run twenty minutes into max_iter
-(profiles/r03_ref_cpu_diagnosis.md); --cpu-full runs it to its end.  `parity_vs_reference`
-for c2 is taken against the committed reference solutions of exactly the benchmarked problem
-(tests/golden/c2_reference.npz: at one GPU c2's matrix is that fixture's, regenerated from its
-seed).  c4: the OpenMP oracle port on the whole workload to convergence.
-Without --config (the driver's invocation) and at N = 1 the c3 and c4 workloads are run after c2
-(GPU legs only) and attached as `secondary`: {c3: {...}, c4: {...}} with their own value /
-ms_per_step / roofline.
+and, at N = 1, `cpu_baseline`: the reference CPU path on the same (A, b, lambda) on this box's
+host cores, WHOLE workload (no row sample, nothing scaled).  Dense: the compiled reference in
+both BLAS builds -- oracle/_ref/libpogs_cpu_openblas.so (scipy's OpenBLAS, which threads its
+gemv: the "best configuration") and oracle/_ref/libpogs_cpu.so (MKL, the build the oracle is
+pinned to; on the GPU box's AMD host its sgemv runs on one thread,
+profiles/r03_ref_cpu_diagnosis.md) -- c2 capped at --cpu-iters ADMM iterations (the fp32 build
+does not reach the default tolerances there and would run twenty minutes into max_iter;
+--cpu-full runs it to its end), c3 to convergence.  c4: the OpenMP oracle port to convergence
+(the reference's sparse path is single-threaded: 21 minutes).
+Without --config (the driver's invocation) and at N = 1 the c3, c4 and c2f64 workloads are run
+after c2 and attached as `secondary`, each with its own value / roofline / parity (c3, c4 also
+with their CPU leg).
 """
 import argparse
 import json
@@ -59,10 +71,14 @@ PROFILE_EVERY = 4   # HIP-event brackets on every 4th launch of the dominant ker
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable by a float4 copy
 
 CONFIGS = {
-    "c2": dict(m=100000, n=10000, kind="dense_lasso", lambd=0.1, cfg_index=1),
-    "c3": dict(m=200000, n=5000, kind="dense_logistic", lambd=0.01, cfg_index=2),
-    "c4": dict(m=2000000, n=500000, kind="csr_lasso", lambd=0.1, nnz_per_row=50, cfg_index=3),
+    "c2": dict(m=100000, n=10000, kind="dense_lasso", lambd=0.1, cfg_index=1, dtype="f32", fixture="c2_reference.npz"),
+    "c3": dict(m=200000, n=5000, kind="dense_logistic", lambd=0.01, cfg_index=2, dtype="f32", fixture="c3_reference.npz"),
+    "c4": dict(m=2000000, n=500000, kind="csr_lasso", lambd=0.1, nnz_per_row=50, cfg_index=3, dtype="f32",
+               fixture="c4_reference.npz"),
+    "c2f64": dict(m=100000, n=10000, kind="dense_lasso", lambd=0.1, cfg_index=1, dtype="f64", fixture="c2_reference.npz"),
 }
+HANDLE_CYCLES = 5
+UNSHARDED_CHECK_MAX_BYTES = 96e9   # N > 1: rank 0 solves the whole problem unsharded when the matrix is at most this
 
 
 def parse():
@@ -102,8 +118,8 @@ def maybe_spawn(args):
     os.execve(sys.executable, cmd, env)
 
 
-def fixture_c2():
-    path = os.path.join(ROOT, "tests", "golden", "c2_reference.npz")
+def load_fixture(cfg):
+    path = os.path.join(ROOT, "tests", "golden", cfg["fixture"])
     if not os.path.exists(path):
         return None
     import numpy as np
@@ -111,28 +127,13 @@ def fixture_c2():
     return np.load(path)
 
 
-def make_problem(cfg, m, n, rank, dev, world=1):
-    """Per-rank rows with a shared x_true / w_true (generated on the device).  Returns
-    (matrix: device tensor or scipy CSR, b or labels, host copy of a dense matrix or None).
-
-    c2 on ONE GPU at its own size is the problem of the committed fixture
-    tests/golden/c2_reference.npz (pogs_amd.synth.dense_lasso_rows(seed=2024), regenerated bit for
-    bit on the host and checked against the fixture's checksums): the compiled reference's fp32
-    and fp64 solutions of exactly this (A, b, lambda) are in the fixture, so the line carries
-    `parity_vs_reference` without a 20-minute reference run on this box."""
+def torch_rows(cfg, m, n, rank, dev):
+    """Rank `rank`'s m rows of the N > 1 problem (and of custom sizes): x_true / w_true from seed 1234
+    (shared), rows and noise from seed 1000 + rank, all drawn on the device.  The same call on another
+    device of the same kind gives the same bits, which is how rank 0 regenerates the whole problem."""
     import numpy as np
     import torch
 
-    fx = fixture_c2() if (cfg["kind"] == "dense_lasso" and world == 1) else None
-    if fx is not None and (m, n) == tuple(int(v) for v in fx["shape"]):
-        from pogs_amd import synth
-
-        A_host, b, _ = synth.dense_lasso_rows(m, n, seed=int(fx["seed"]))
-        chk = np.array([float(A_host[::997].astype(np.float64).sum()), float(np.abs(A_host[:, ::113]).astype(np.float64).sum()),
-                        float(np.linalg.norm(b)), float(b[::101].sum())])
-        if not np.allclose(chk, fx["checksums"], rtol=1e-12, atol=0):
-            raise RuntimeError("the generator no longer reproduces the fixture's inputs")
-        return torch.from_numpy(A_host).to(dev), b, A_host
     g = torch.Generator(device=dev)
     g.manual_seed(1234)
     kind = cfg["kind"]
@@ -141,7 +142,7 @@ def make_problem(cfg, m, n, rank, dev, world=1):
         g.manual_seed(1000 + rank)
         A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float32)
         b = A @ x_true + 0.1 * torch.randn(m, generator=g, device=dev)
-        return A, b.double().cpu().numpy(), None
+        return A, b.double().cpu().numpy()
     if kind == "dense_logistic":
         w = torch.randn(n, generator=g, device=dev) * (torch.rand(n, generator=g, device=dev) < 0.3)
         w = w * (2.0 / torch.sqrt((w * w).sum()))
@@ -149,7 +150,7 @@ def make_problem(cfg, m, n, rank, dev, world=1):
         A = torch.randn((m, n), generator=g, device=dev, dtype=torch.float32)
         p = torch.sigmoid(A @ w)
         lab = 2.0 * (torch.rand(m, generator=g, device=dev) < p).double() - 1.0
-        return A, lab.cpu().numpy(), None
+        return A, lab.cpu().numpy()
     # CSR: k uniformly drawn column indices per row, N(0,1) values, duplicates summed
     import scipy.sparse as sp
 
@@ -163,8 +164,49 @@ def make_problem(cfg, m, n, rank, dev, world=1):
     ptr = np.arange(0, m * k + 1, k, dtype=np.int32)
     A = sp.csr_matrix((vals.cpu().numpy().ravel(), cols.cpu().numpy().ravel(), ptr), shape=(m, n))
     A.sum_duplicates()
-    b = A @ x_true + noise
-    return A, b, None
+    return A, A @ x_true + noise
+
+
+def make_problem(cfg, m, n, rank, dev, world=1):
+    """Returns (matrix: device tensor or scipy CSR, b or labels, host copy of a dense matrix or None,
+    fixture or None).
+
+    ONE GPU at the configuration's own size: the problem of the committed fixture of the compiled
+    reference's solution (tests/golden/<cfg["fixture"]>), regenerated bit for bit on the host with
+    the numpy generators of pogs_amd/synth.py and checked against the fixture's checksums -- so the
+    line carries `parity_vs_reference` without a reference run of minutes (c2, c3) to an hour (c4) on
+    this box.  Otherwise: torch_rows."""
+    import numpy as np
+    import torch
+
+    from pogs_amd import synth
+
+    fx = load_fixture(cfg) if world == 1 else None
+    if fx is not None and (m, n) == tuple(int(v) for v in fx["shape"][:2]):
+        kind = cfg["kind"]
+        if kind == "csr_lasso":
+            A, b, _ = synth.csr_lasso(m, n, cfg["nnz_per_row"], seed=int(fx["seed"]), dtype=np.float32)
+            chk = np.array([float(A.nnz), float(A.data[::1009].astype(np.float64).sum()),
+                            float(A.indices[::1013].astype(np.float64).sum()), float(np.linalg.norm(b)), float(b[::101].sum())])
+            A_host = None
+        else:
+            if kind == "dense_lasso":
+                A_host, b, _ = synth.dense_lasso_rows(m, n, seed=int(fx["seed"]))
+            else:
+                A_host, b, _ = synth.dense_logistic_rows(m, n, seed=int(fx["seed"]), logit_std=float(fx["logit_std"]))
+            chk = np.array([float(A_host[::997].astype(np.float64).sum()), float(np.abs(A_host[:, ::113]).astype(np.float64).sum()),
+                            float(np.linalg.norm(b)) if kind == "dense_lasso" else float(b.sum()), float(b[::101].sum())])
+            A = torch.from_numpy(A_host).to(dev)
+            if cfg["dtype"] == "f64":
+                A = A.double()      # widened on the device: the entries are the fp32 matrix's, exactly
+                A_host = None       # (no CPU leg for this workload)
+        if not np.allclose(chk, fx["checksums"], rtol=1e-12, atol=0):
+            raise RuntimeError("the generator no longer reproduces the inputs of %s" % cfg["fixture"])
+        return A, b, A_host, fx
+    A, b = torch_rows(cfg, m, n, rank, dev)
+    if cfg["dtype"] == "f64" and cfg["kind"] != "csr_lasso":
+        A = A.double()
+    return A, b, None, None
 
 
 def functions(cfg, G, b, n):
@@ -173,80 +215,117 @@ def functions(cfg, G, b, n):
     return G.lasso_functions(b, cfg["lambd"], n)
 
 
-def cpu_baseline(cfg, A_host, f, g, args, engine, fixture=None):
-    """Times the reference CPU path on this box's host cores, on the SAME (A, f, g), WHOLE workload:
-    no row sample, nothing scaled.
+def _parity(engine, x_ref, optval_ref, it_ref, against):
+    import numpy as np
 
-    Dense (c2, c3): the compiled reference (oracle/_ref, `kind` "reference"; a clean subprocess, it
-    must not share a process with torch) on all rows; `value` = iterations / (Total - Init) from its
-    own summary line (src/cpu/pogs.cpp:485-490).  The run is capped at --cpu-iters ADMM iterations
-    (default 60): on the GPU box's host the reference's fp32 build does not reach the default
-    tolerances at c2 -- its primal residual stalls 0.2 % above the bound from iteration ~200 on and
-    it runs into max_iter = 2500, twenty minutes (profiles/r03_ref_cpu_diagnosis.md) -- so a run to
-    convergence is only made on request (--cpu-full).  The capped run is the reference's own loop on
-    the whole matrix; its first iterations are its cheapest (no exact-residual passes yet), so the
-    cap flatters the CPU side, not the GPU side.
-    `parity`: against the committed reference solutions of exactly this problem when the workload is
-    the fixture's (c2, one GPU); against the live run when that ran to convergence.
+    xr, xe = np.asarray(x_ref, np.float64), engine["x"].astype(np.float64)
+    return {"against": against, "rel_x": float(np.linalg.norm(xe - xr) / max(np.linalg.norm(xr), 1e-300)),
+            "rel_optval": abs(engine["optval"] - optval_ref) / max(abs(optval_ref), 1e-300),
+            "iterations_reference": int(it_ref), "iterations_engine": engine["iterations"] + 1, "tolerance": 1e-4}
+
+
+def parity_from_fixture(cfg, fx, engine):
+    """`parity_vs_reference` against the committed solutions of the compiled reference on exactly this
+    (A, b, lambda) (tests/golden/make_c2_reference*.py, make_c3_reference.py, make_c4_reference.py)."""
+    what = "tests/golden/%s: the compiled reference" % cfg["fixture"]
+    if "x_fp64" in fx:   # dense fixtures hold both builds; the fp64 one is the algorithm without rounding noise
+        par = _parity(engine, fx["x_fp64"], float(fx["optval_fp64"]), int(fx["iterations_fp64"]) + 1,
+                      what + "'s fp64 build (PogsD) on exactly this (A, b, lambda), run to convergence in the build container")
+        p32 = _parity(engine, fx["x"], float(fx["optval"]), int(fx["iterations"]) + 1, "")
+        par["rel_x_vs_reference_fp32_build"] = p32["rel_x"]
+        par["iterations_reference_fp32_build"] = p32["iterations_reference"]
+        return par
+    par = _parity(engine, fx["x"], float(fx["optval"]), int(fx["iterations"]) + 1,
+                  what + " (PogsSparseS, fp32) on exactly this (A, b, lambda), run to convergence in the build container")
+    # the reference adds the 2.5e6 terms of its optval in fp32 (prox_lib.h:521-529): 1e-3 off its own fp64 value
+    par["note_optval"] = "the reference sums optval in fp32 over m + n terms; objective_at_x in the fixture is the fp64 recomputation"
+    return par
+
+
+# what the CPU leg runs per workload: (BLAS build of the compiled reference, iteration cap or None = to convergence)
+CPU_PLAN = {"c2": [("openblas", "cap"), ("mkl", "cap")], "c3": [("openblas", None)]}
+
+
+def cpu_baseline(name, cfg, A_host, f, g, args, engine):
+    """Times the reference CPU path on this box's host cores, on the SAME (A, f, g), WHOLE workload:
+    no row sample, nothing scaled.  Returns (cpu_baseline dict, live parity dict or None).
+
+    Dense (c2, c3): the compiled reference (`kind` "reference"; a clean subprocess -- it must not share
+    a process with torch), `value` = iterations / (Total - Init) from its own summary line
+    (src/cpu/pogs.cpp:485-490).  Two builds of the same six sources (oracle/Makefile): against
+    scipy's OpenBLAS, which threads its gemv -- SURVEY.md section 8(d)'s "best configuration" for the
+    dense path, BLAS threads = granted cores -- and against MKL, the build the oracle is pinned to,
+    whose sgemv runs on ONE thread on the GPU box's AMD host (profiles/r03_ref_cpu_diagnosis.md).
+    The top-level fields are the best build's; `builds` holds each.  c2 is capped at --cpu-iters ADMM
+    iterations: the reference's fp32 build does not reach the default tolerances there on that host
+    and runs twenty minutes into max_iter (--cpu-full lifts the cap); its first iterations are its
+    cheapest (no exact-residual passes yet), so the cap flatters the CPU side.  c3 runs to
+    convergence.
     Sparse (c4): the OpenMP oracle port on the whole workload to convergence (`kind` "port": the
     reference's sparse path is single-threaded as built and needs 21 minutes,
-    tests/golden/make_c4_reference.py).  Returns (cpu_baseline dict, parity dict or None)."""
+    tests/golden/make_c4_reference.py), OpenMP threads = granted cores."""
     import numpy as np
 
     import oracle_binding as ob
 
-    t_start = time.time()
     sparse = hasattr(A_host, "indptr")
     m, n = A_host.shape
     dt = np.float32
     soa = lambda fv: {k: getattr(fv, k) for k in "habcde"}  # noqa: E731
     fs, gs = soa(f), soa(g)
-
-    def parity_of(x_ref, optval_ref, it_ref, against):
-        xr, xe = np.asarray(x_ref, np.float64), engine["x"].astype(np.float64)
-        return {"against": against, "rel_x": float(np.linalg.norm(xe - xr) / max(np.linalg.norm(xr), 1e-300)),
-                "rel_optval": abs(engine["optval"] - optval_ref) / max(abs(optval_ref), 1e-300),
-                "iterations_reference": int(it_ref), "iterations_engine": engine["iterations"] + 1, "tolerance": 1e-4}
-
     out = {"unit": "it/s", "host_threads_visible": os.cpu_count() or 1, "cpu_quota": ob.cpu_quota()}
-    parity = None
-    if fixture is not None:
-        parity = parity_of(fixture["x_fp64"], float(fixture["optval_fp64"]), int(fixture["iterations_fp64"]) + 1,
-                           "tests/golden/c2_reference.npz: the compiled reference's fp64 build (PogsD) on exactly this (A, b, "
-                           "lambda), run to convergence in the build container")
-        p32 = parity_of(fixture["x"], float(fixture["optval"]), int(fixture["iterations"]) + 1, "")
-        parity["rel_x_vs_reference_fp32_build"] = p32["rel_x"]
-        parity["iterations_reference_fp32_build"] = p32["iterations_reference"]
     if sparse:
         ob.oracle_set_threads()
         r = ob.oracle_solve(A_host, fs, gs, dtype=dt)
         t_init, t_loop = r["info"]["t_init"], r["info"]["t_loop"]
         iters = r["iterations"] + 1
         out.update(kind="port", cores=ob.cpu_quota(), value=iters / max(t_loop, 1e-9), time_to_converge_s=t_init + t_loop,
+                   init_s=t_init, loop_s=t_loop, iterations=iters, converged=r["status"] == 0,
+                   best={"build": "OpenMP oracle port", "threads": ob.cpu_quota(), "value": iters / max(t_loop, 1e-9)},
                    sample="whole workload %dx%d nnz %d fp32 to convergence, OpenMP oracle port (oracle/pogs_oracle.cpp, pinned to "
                           "the reference in tests/), %d threads: %d iterations, total %.1f s, init %.1f s"
                           % (m, n, A_host.nnz, ob.cpu_quota(), iters, t_init + t_loop, t_init))
-        return out, parity_of(r["x"], r["optval"], iters, "oracle port, same A, b, lambda, default tolerances, whole workload")
-    if not ob.ref_available():
-        raise RuntimeError("oracle/_ref/libpogs_cpu.so is missing (built by __graft_entry__.build() where /root/reference exists)")
-    cap = None if args.cpu_full else args.cpu_iters
-    r = ob.ref_solve(A_host, fs, gs, dtype=dt, verbose=1, timeout=args.cpu_budget_s, **({"max_iter": cap} if cap else {}))
-    t_total, t_init = r.get("t_total", r["wall_s"]), r.get("t_init", 0.0)
-    iters = r["iterations"] + 1
-    converged = r["status"] == 0
-    out.update(kind="reference", cores=ob.ref_threads(), value=iters / max(t_total - t_init, 1e-9), init_s=t_init,
-               loop_s=t_total - t_init, iterations=iters, converged=converged, threads_env=ob.ref_env_note(),
-               sample="whole workload %dx%d fp32, compiled reference (oracle/_ref/libpogs_cpu.so), %s: %d iterations%s, "
-                      "Total %.1f s, Init %.1f s (its own summary line); elapsed with process start and input hand-over %.1f s"
-                      % (m, n, "to convergence" if converged else "max_iter = %d" % (cap or 2500), iters,
-                         "" if converged else " (not converged: capped, see cpu_baseline() in bench.py)", t_total, t_init,
-                         time.time() - t_start))
-    if converged:
-        out["time_to_converge_s"] = t_total
-        if parity is None:
-            parity = parity_of(r["x"], r["optval"], iters, "compiled reference (oracle/_ref/libpogs_cpu.so), same A, b, lambda, "
-                                                           "default tolerances, whole workload, this run")
-    return out, parity
+        return out, _parity(engine, r["x"], r["optval"], iters, "oracle port, same A, b, lambda, default tolerances, whole workload, this run")
+    builds, live = {}, None
+    for blas, cap in CPU_PLAN.get(name, [("openblas", "cap")]):
+        if not ob.ref_available(blas):
+            builds[blas] = {"value": None, "sample": "oracle/_ref build for %s missing" % blas}
+            continue
+        cap_it = None if (cap is None or args.cpu_full) else args.cpu_iters
+        t_start = time.time()
+        try:
+            r = ob.ref_solve(A_host, fs, gs, dtype=dt, verbose=1, timeout=args.cpu_budget_s, blas=blas,
+                             **({"max_iter": cap_it} if cap_it else {}))
+        except Exception as e:
+            builds[blas] = {"value": None, "sample": "failed: %r" % (e,)}
+            continue
+        t_total, t_init = r.get("t_total", r["wall_s"]), r.get("t_init", 0.0)
+        iters = r["iterations"] + 1
+        converged = r["status"] == 0
+        lib = "oracle/_ref/libpogs_cpu_openblas.so (scipy OpenBLAS)" if blas == "openblas" else "oracle/_ref/libpogs_cpu.so (MKL)"
+        d = dict(value=iters / max(t_total - t_init, 1e-9), init_s=t_init, loop_s=t_total - t_init, iterations=iters,
+                 converged=converged, threads=ob.ref_threads(),
+                 sample="whole workload %dx%d fp32, compiled reference %s, %s: %d iterations%s, Total %.1f s, Init %.1f s "
+                        "(its own summary line); elapsed with process start and input hand-over %.1f s"
+                        % (m, n, lib, "to convergence" if converged else "max_iter = %d" % (cap_it or 2500), iters,
+                           "" if converged else " (not converged: capped, see cpu_baseline() in bench.py)", t_total, t_init,
+                           time.time() - t_start))
+        if converged:
+            d["time_to_converge_s"] = t_total
+            if live is None:
+                live = _parity(engine, r["x"], r["optval"], iters, "compiled reference (%s), same A, b, lambda, default "
+                                                                   "tolerances, whole workload, this run" % lib)
+        builds[blas] = d
+    ok = {k: v for k, v in builds.items() if v.get("value")}
+    if not ok:
+        raise RuntimeError("no reference build ran: %r" % (builds,))
+    best = max(ok, key=lambda k: ok[k]["value"])
+    out.update(kind="reference", cores=ob.ref_threads(), threads_env=ob.ref_env_note() + " OPENBLAS_NUM_THREADS=%d" % ob.ref_threads(),
+               builds=builds, best={"build": best, "threads": ok[best]["threads"], "value": ok[best]["value"]})
+    out.update({k: ok[best][k] for k in ("value", "init_s", "loop_s", "iterations", "converged", "sample")})
+    if "time_to_converge_s" in ok[best]:
+        out["time_to_converge_s"] = ok[best]["time_to_converge_s"]
+    return out, live
 
 
 def csrc_sha16():
@@ -344,12 +423,14 @@ def run_config(env, name, with_cpu):
         dist.broadcast(uid, 0)
         return (rank, world, m * world, bytes(uid.cpu().tolist()))
 
-    A, b, A_host = make_problem(cfg, m, n, rank, dev, world)
+    np_dtype = np.float64 if cfg["dtype"] == "f64" else np.float32
+    esize = np.dtype(np_dtype).itemsize
+    A, b, A_host, fixture = make_problem(cfg, m, n, rank, dev, world)
     torch.cuda.synchronize()
 
     if sparse:
         # the CSR arrays resident in HBM, like the dense matrices: the timed setup starts from there
-        csr_dev = (torch.from_numpy(np.ascontiguousarray(A.data, np.float32)).to(dev),
+        csr_dev = (torch.from_numpy(np.ascontiguousarray(A.data, np_dtype)).to(dev),
                    torch.from_numpy(np.ascontiguousarray(A.indptr, np.int32)).to(dev),
                    torch.from_numpy(np.ascontiguousarray(A.indices, np.int32)).to(dev))
         torch.cuda.synchronize()
@@ -358,11 +439,11 @@ def run_config(env, name, with_cpu):
         dist_arg = new_dist_arg()
         if sparse:
             return pogs_amd.Solver((csr_dev[0].data_ptr(), csr_dev[1].data_ptr(), csr_dev[2].data_ptr(), A.nnz),
-                                   dtype=np.float32, shape=(m, n), device_ptr=True, device=local, profile=PROFILE_EVERY,
+                                   dtype=np_dtype, shape=(m, n), device_ptr=True, device=local, profile=PROFILE_EVERY,
                                    dist=dist_arg)
         from pogs_amd import _lib as L
 
-        return pogs_amd.Solver(A.data_ptr(), dtype=np.float32, shape=(m, n), device_ptr=True, device=local,
+        return pogs_amd.Solver(A.data_ptr(), dtype=np_dtype, shape=(m, n), device_ptr=True, device=local,
                                profile=PROFILE_EVERY, dist=dist_arg,
                                projector=L.PROJ_CGLS if args.projector == "cgls" else L.PROJ_DEFAULT)
 
@@ -409,6 +490,67 @@ def run_config(env, name, with_cpu):
     elapsed = sum(times) / len(times)
     st = solver.stats()
     nranks_comm = st.get("comm_nranks", 0)   # as ncclCommCount reports it (0: no communicator)
+    solver.close()
+
+    # create / solve / destroy, HANDLE_CYCLES times: what a caller of the one-shot ABI pays per call
+    # (the reference builds and destroys its solver inside PogsD/PogsS, src/interface_c/pogs_c.cpp:19-20);
+    # the library's device pool (pogs_amd/csrc/common.h) is what keeps every cycle at the speed of the fastest
+    cycles = None
+    if world == 1 and dist is None:
+        from pogs_amd import _lib as L
+
+        p0 = L.pool_stats(local)
+        ci, ct, cc = [], [], []
+        for _ in range(HANDLE_CYCLES):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            s_ = create()
+            t1 = time.time()
+            r_ = s_.solve(f, g)
+            t2 = time.time()
+            s_.close()
+            t3 = time.time()
+            assert r_["iterations"] == res["iterations"] and r_["status"] == res["status"]
+            ci.append(t1 - t0)
+            ct.append(t2 - t0)
+            cc.append(t3 - t0)
+        p1 = L.pool_stats(local)
+        cycles = {"n": HANDLE_CYCLES, "init_s": ci, "time_to_converge_s": ct, "create_solve_destroy_s": cc,
+                  "max_init_s": max(ci), "max_time_to_converge_s": max(ct),
+                  "pool": {"hipMalloc_calls": p1["mallocs"] - p0["mallocs"], "hipFree_calls": p1["frees"] - p0["frees"],
+                           "blocks_reused": p1["reuses"] - p0["reuses"], "cached_bytes": p1["cached_bytes"]}}
+
+    # N > 1: the shards are row ranges of ONE problem; rank 0 regenerates it whole and, when it fits,
+    # solves it unsharded -- the sharded solution must land on that solve's
+    unsharded = None
+    if world > 1 and not sparse and args.projector == "default":
+        bsum = torch.tensor([float(np.asarray(b, np.float64).sum())], dtype=torch.float64, device=dev)
+        sums = [torch.zeros_like(bsum) for _ in range(world)]
+        dist.all_gather(sums, bsum)
+        if rank == 0 and float(m) * world * n * esize <= UNSHARDED_CHECK_MAX_BYTES:
+            try:
+                parts = [torch_rows(cfg, m, n, r, dev) for r in range(world)]
+                for r in range(world):   # the regenerated rows are the ranks' own
+                    assert abs(float(parts[r][1].sum()) - float(sums[r].item())) <= 1e-9 * max(1.0, abs(float(sums[r].item()))), r
+                A_all = torch.cat([pp[0] for pp in parts], 0)
+                if cfg["dtype"] == "f64":
+                    A_all = A_all.double()
+                b_all = np.concatenate([pp[1] for pp in parts])
+                del parts
+                f_all, g_all = functions(cfg, G, b_all, n)
+                with pogs_amd.Solver(A_all.data_ptr(), dtype=np_dtype, shape=(m * world, n), device_ptr=True, device=local) as s1:
+                    r1 = s1.solve(f_all, g_all)
+                    st1 = s1.stats()
+                del A_all
+                torch.cuda.empty_cache()
+                unsharded = _parity(res, r1["x"], r1["optval"], r1["iterations"] + 1,
+                                    "the same %d x %d problem solved UNSHARDED on rank 0's GPU by the engine (which is pinned to "
+                                    "the compiled reference at N = 1): the row-sharded RCCL solve must land on it"
+                                    % (m * world, n))
+                unsharded["unsharded_it_per_s"] = (r1["iterations"] + 1) / max(st1["t_loop_s"], 1e-9)
+            except Exception as e:   # never take the line down
+                unsharded = {"error": repr(e)[:300]}
+        env.barrier()
 
     line = None
     if rank == 0:
@@ -433,9 +575,9 @@ def run_config(env, name, with_cpu):
             projector = "CGLS (LDS-gather SpMV, device-resident CG loop)"
         else:
             kernel = "stream_rows2_kernel<FusedIterOp> (the one pass over A per iteration)"
-            kernel_key = "stream_rows2_kernel<float"
-            one_pass = 4.0 * (m * n + 0.5 * n * n)  # A once + the lower triangle of W = L^-1
-            two_pass = 4.0 * (2.0 * m * n + n * n)  # the reference algorithm
+            kernel_key = "stream_rows2_kernel<%s" % ("double" if cfg["dtype"] == "f64" else "float")
+            one_pass = esize * (m * n + 0.5 * n * n)  # A once + the lower triangle of W = L^-1
+            two_pass = esize * (2.0 * m * n + n * n)  # the reference algorithm
             iteration = {"bytes_model": "one-pass engine: A once + the lower triangle of W per iteration",
                          "bytes": one_pass, "frac": one_pass * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
                          "passes_over_A_per_iteration": st["matvecs"] / max(steps_total, 1),
@@ -445,27 +587,30 @@ def run_config(env, name, with_cpu):
                                                         "roofline fraction",
                              "ratio_to_hbm_peak": two_pass * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}}
             wname = "solve_lasso" if cfg["kind"] == "dense_lasso" else "solve_logistic"
-            workload = ("%s dense fp32 A=%dx%d per GPU, lambda=%g, default tolerances (BASELINE.json configs[%d]%s)"
-                        % (wname, m, n, cfg["lambd"], cfg["cfg_index"],
+            workload = ("%s dense %s A=%dx%d per GPU, lambda=%g, default tolerances (BASELINE.json configs[%d]%s%s)"
+                        % (wname, "fp64" if cfg["dtype"] == "f64" else "fp32", m, n, cfg["lambd"], cfg["cfg_index"],
+                           " with the matrix widened to the reference Python layer's dtype, python/pogs/graph.py:281-288"
+                           if cfg["dtype"] == "f64" else "",
                            "" if world == 1 else "; row-sharded %dx%d" % (m * world, n)))
             projector = "direct (MFMA Gram + Cholesky)"
             if args.projector == "cgls":
                 passes = st["matvecs"] / max(steps_total, 1)
                 kernel = "stream_rows_kernel (every pass over A of the loop: A p, A^T r, A x of CGLS and the residual passes)"
-                kernel_key = "stream_rows_kernel<float"
-                iteration = {"bytes_model": "passes over A per iteration x 4 m n bytes (matrix-free CGLS projector)",
+                kernel_key = "stream_rows_kernel<%s" % ("double" if cfg["dtype"] == "f64" else "float")
+                iteration = {"bytes_model": "passes over A per iteration x s m n bytes (matrix-free CGLS projector)",
                              "passes_over_A_per_iteration": passes, "cg_per_iteration": st["cg_iters"] / max(steps_total, 1),
-                             "bytes": passes * 4.0 * m * n, "frac": passes * 4.0 * m * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}
+                             "bytes": passes * esize * m * n, "frac": passes * esize * m * n * args.steps / elapsed / 1e9 / HBM_PEAK_GBS}
                 projector = "CGLS on the dense matrix (matrix-free)"
                 workload += " [--projector cgls]"
         traffic, traffic_src, traffic_fresh = (pmc_traffic(name, kernel_key)
                                                if (m, n) == (cfg["m"], cfg["n"]) and args.projector == "default"
                                                else (None, None, None))
         line = {
-            "metric": "admm_iterations_per_sec_%s_fp32 (per-GPU shard, summed over GPUs)" % cfg["kind"],
+            "metric": "admm_iterations_per_sec_%s_%s (per-GPU shard, summed over GPUs)"
+                      % (cfg["kind"], "fp64" if cfg["dtype"] == "f64" else "fp32"),
             "value": its, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
             "windows": windows, "window_s": times,
             "config": {"workload": workload, "name": name, "rows_per_gpu": m, "cols": n, "projector": projector,
                        "parallelism": "row-shard x%d" % world, "rccl_nranks": nranks_comm},
@@ -483,15 +628,28 @@ def run_config(env, name, with_cpu):
             "time_to_converge_s": init_s + solve_s, "init_s": init_s, "loop_s": st_solve["t_loop_s"],
             "first_handle_of_the_process": {"init_s": init_cold_s, "time_to_converge_s": init_cold_s + solve_s,
                                             "note": "the process's first solver handle also pays for HIP stream creation and "
-                                                    "code-object loading; init_s / time_to_converge_s are a second handle's"},
+                                                    "code-object loading (and takes its device memory from the HIP runtime, not from "
+                                                    "the library's pool); init_s / time_to_converge_s are a second handle's"},
+            "time_to_converge_includes": "the one-time setup with its two default-on shortcuts -- the fp32 Gram product as a "
+                                         "two-way fp16 split on the matrix cores (POGS_AMD_GRAM=fp32: native fp32 MFMA) and "
+                                         "Sinkhorn-Knopp's common-factor tail in closed form (POGS_AMD_SK_FULL=1: all 50 passes); "
+                                         "both are held against the exact path at full size in tests/test_gpu_fullsize.py",
             "solve_iterations": res["iterations"] + 1, "solve_status": res["status"],
             "exact_residual_iters": st_solve["exact_iters"],
             "setup_ms": {k: st_solve[k] for k in ("equil_ms", "normest_ms", "gram_ms", "chol_ms", "trtri_ms")},
         }
         if not sparse:
             line["gram_tflops"] = st_solve["gram_flops"] / max(st_solve["gram_ms"], 1e-9) / 1e9
-    solver.close()
-    if rank == 0 and with_cpu:
+        if cycles is not None:
+            line["handle_cycles"] = cycles
+        if fixture is not None:
+            try:
+                line["parity_vs_reference"] = parity_from_fixture(cfg, fixture, res)
+            except Exception as e:
+                line["parity_vs_reference"] = {"error": repr(e)[:300]}
+        elif unsharded is not None:
+            line["parity_vs_reference"] = unsharded
+    if rank == 0 and with_cpu and cfg["dtype"] == "f32":
         try:
             if sparse:
                 A_host = A
@@ -499,13 +657,18 @@ def run_config(env, name, with_cpu):
                 A_host = A.cpu().numpy()
             del A   # the GPU copy is not needed any more; the reference gets the host copy
             torch.cuda.empty_cache()
-            fx = fixture_c2() if (name == "c2" and (m, n) == (cfg["m"], cfg["n"])) else None
-            line["cpu_baseline"], parity = cpu_baseline(cfg, A_host, f, g, args, res, fx)
-            if parity is not None:
-                line["parity_vs_reference"] = parity
+            line["cpu_baseline"], live = cpu_baseline(name, cfg, A_host, f, g, args, res)
+            if live is not None and "parity_vs_reference" in line:
+                line["parity_vs_reference"]["live_cpu_run"] = live
+            elif live is not None:
+                line["parity_vs_reference"] = live
         except Exception as e:  # the baseline must never take the bench line down
             line["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": os.cpu_count(), "kind": "none",
                                     "sample": "failed: %r" % (e,)}
+    A = None
+    if sparse:
+        csr_dev = None
+    torch.cuda.empty_cache()
     return line
 
 
@@ -519,15 +682,16 @@ def main():
     env = Env(args)
     head = args.config or "c2"
     line = run_config(env, head, with_cpu=env.world == 1 and not args.no_cpu_baseline)
-    # the driver's invocation (no --config, one GPU): c3 and c4 under the same clock, GPU legs only
+    # the driver's invocation (no --config, one GPU): c3, c4 (with their CPU legs) and c2 in fp64 under the same clock
     if args.config is None and env.world == 1 and not args.no_secondary and not (args.m or args.n) \
             and args.projector == "default":
-        keep = ("value", "unit", "ms_per_step", "steps", "windows", "window_s", "config", "roofline", "time_to_converge_s", "init_s",
-                "solve_iterations", "solve_status", "setup_ms")
+        keep = ("metric", "value", "unit", "dtype", "ms_per_step", "steps", "windows", "window_s", "config", "roofline",
+                "time_to_converge_s", "init_s", "handle_cycles", "solve_iterations", "solve_status", "setup_ms", "gram_tflops",
+                "parity_vs_reference", "cpu_baseline")
         sec = {}
-        for name in ("c3", "c4"):
+        for name in ("c3", "c4", "c2f64"):
             try:
-                d = run_config(env, name, with_cpu=False)
+                d = run_config(env, name, with_cpu=not args.no_cpu_baseline)
                 sec[name] = {k: d[k] for k in keep if k in d}
             except Exception as e:
                 sec[name] = {"value": None, "error": repr(e)[:300]}

@@ -214,6 +214,26 @@ void PogsAmdDestroy(PogsAmdSolver *s);
 /* Last error message of the calling thread ("" if none). */
 const char *PogsAmdLastError(void);
 
+/* Device memory pool.  The reference builds and destroys its solver inside every one-shot call
+ * (src/interface_c/pogs_c.cpp:19-20, 67-68), i.e. its working set is allocated and freed per
+ * call; on the GPU that costs map / first-touch / unmap stalls of 0.1-0.3 s at 5 GB.  The
+ * library therefore keeps the device blocks of destroyed handles (and of finished PogsD/PogsS
+ * calls) in a per-device cache and hands them to the next handle.  At most POGS_AMD_POOL_MB
+ * (environment; default a quarter of the device's memory, 0 = no caching) stay idle per device;
+ * an allocation that fails is retried after the cache has been emptied. */
+typedef struct PogsAmdPoolInfo {
+  unsigned long long mallocs;   /* blocks taken from the HIP runtime                    */
+  unsigned long long reuses;    /* blocks taken from the cache                          */
+  unsigned long long frees;     /* blocks given back to the HIP runtime                 */
+  double malloc_ms, free_ms;    /* host time spent inside hipMalloc / hipFree           */
+  size_t cached_bytes;          /* idle in the cache now                                */
+  size_t live_bytes;            /* in use by handles now                                */
+  size_t peak_cached_bytes;
+} PogsAmdPoolInfo;
+int PogsAmdPoolStats(int device, PogsAmdPoolInfo *out);
+/* Gives the idle blocks of `device` (-1: every device) back to the HIP runtime. */
+int PogsAmdPoolTrim(int device, size_t *freed_bytes);
+
 /* ---------------------------------------------------------------------------
  * Part 3 -- building blocks exported for parity tests (device pointers unless
  * noted).  Not needed by a drop-in caller.

@@ -20,9 +20,12 @@ LIB_PATH = os.path.join(_PKG, "libpogs_amd.so")
 # after this library was loaded (torch_loaded_first below).
 TORCH_LOADED_FIRST = "torch" in sys.modules
 if not TORCH_LOADED_FIRST and os.environ.get("POGS_AMD_TORCH_PRELOAD", "0") == "1":
-    import torch  # noqa: F401
+    try:
+        import torch  # noqa: F401
 
-    TORCH_LOADED_FIRST = True
+        TORCH_LOADED_FIRST = True
+    except ImportError:   # a machine without torch: nothing to preload, pure ctypes callers still work
+        pass
 
 
 def check_device_pointer_interop():
@@ -122,11 +125,38 @@ lib.PogsAmdProject.argtypes = [c_void_p, c_void_p, c_void_p, c_double, c_void_p,
 lib.PogsAmdMul.argtypes = [c_void_p, c_char, c_double, c_void_p, c_double, c_void_p]
 lib.PogsAmdRandUniform.argtypes = [c_int, c_size_t, c_void_p]
 
+
+class PogsAmdPoolInfo(ctypes.Structure):
+    _fields_ = [("mallocs", ctypes.c_ulonglong), ("reuses", ctypes.c_ulonglong), ("frees", ctypes.c_ulonglong),
+                ("malloc_ms", c_double), ("free_ms", c_double), ("cached_bytes", c_size_t), ("live_bytes", c_size_t),
+                ("peak_cached_bytes", c_size_t)]
+
+
+lib.PogsAmdPoolStats.argtypes = [c_int, ctypes.POINTER(PogsAmdPoolInfo)]
+lib.PogsAmdPoolTrim.argtypes = [c_int, ctypes.POINTER(c_size_t)]
+
+
+def pool_stats(device=-1):
+    """Counters of the library's device memory pool (include/pogs_amd.h: PogsAmdPoolInfo)."""
+    info = PogsAmdPoolInfo()
+    if lib.PogsAmdPoolStats(device, ctypes.byref(info)) != 0:
+        raise RuntimeError(last_error())
+    return {k: getattr(info, k) for k, _ in info._fields_}
+
+
+def pool_trim(device=-1):
+    """Give the idle device blocks of the pool back to the HIP runtime; returns the bytes freed."""
+    freed = c_size_t(0)
+    if lib.PogsAmdPoolTrim(device, ctypes.byref(freed)) != 0:
+        raise RuntimeError(last_error())
+    return freed.value
+
 # Every symbol include/pogs_amd.h declares (checked by tests/test_abi.py).
 ABI_SYMBOLS = [
     "PogsD", "PogsS", "PogsSparseD", "PogsSparseS",
     "PogsAmdDistUniqueId", "PogsAmdCreateDense", "PogsAmdCreateSparse", "PogsAmdSolve", "PogsAmdBeginRun",
     "PogsAmdIterate", "PogsAmdSetWarmStart", "PogsAmdGetStats", "PogsAmdResetStats", "PogsAmdDestroy", "PogsAmdLastError",
+    "PogsAmdPoolStats", "PogsAmdPoolTrim",
     "PogsAmdProxEval", "PogsAmdFuncEval", "PogsAmdProjSubgradEval", "PogsAmdGetEquil", "PogsAmdProject", "PogsAmdMul", "PogsAmdRandUniform",
 ]
 

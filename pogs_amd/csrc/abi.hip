@@ -371,6 +371,28 @@ void PogsAmdDestroy(PogsAmdSolver *s) {
 
 const char *PogsAmdLastError(void) { return g_last_error.c_str(); }
 
+int PogsAmdPoolStats(int device, PogsAmdPoolInfo *out) {
+  return guarded([&]() {
+    POGS_CHECK(out, "null argument");
+    int dev = device;
+    if (dev < 0) POGS_HIP_CHECK(hipGetDevice(&dev));
+    const PoolCounters c = DevicePool::get().counters(dev);
+    out->mallocs = c.mallocs; out->reuses = c.reuses; out->frees = c.frees;
+    out->malloc_ms = c.malloc_ms; out->free_ms = c.free_ms;
+    out->cached_bytes = c.cached_bytes; out->live_bytes = c.live_bytes;
+    out->peak_cached_bytes = c.peak_cached_bytes;
+    return 0;
+  });
+}
+
+int PogsAmdPoolTrim(int device, size_t *freed_bytes) {
+  return guarded([&]() {
+    const size_t b = DevicePool::get().trim(device);
+    if (freed_bytes) *freed_bytes = b;
+    return 0;
+  });
+}
+
 int PogsAmdProxEval(int dtype, size_t n, const int *h, const void *a, const void *b, const void *c, const void *d,
                     const void *e, double rho, const void *in, void *out) {
   return guarded([&]() {

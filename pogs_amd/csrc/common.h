@@ -2,7 +2,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <cstdlib>
 
 #include <cstddef>
 #include <cstdint>
@@ -39,7 +45,210 @@ struct Error : std::runtime_error {
     }                                                                             \
   } while (0)
 
-// RAII device buffer.
+// ---- device memory pool --------------------------------------------------------------------
+// The reference constructs and destroys its solver inside every PogsD/PogsS call
+// (src/interface_c/pogs_c.cpp:19-20), so a caller of the one-shot ABI -- and of
+// PogsAmdCreate/Destroy in a loop -- allocates and frees the whole working set (C2: 5.6 GB) per
+// call.  On this runtime a fresh hipMalloc of that size costs tens of milliseconds, its first
+// touch 100-180 ms more (page tables are populated lazily), and hipFree unmaps synchronously: the
+// round-3 driver run saw 0.28 s of such stalls in the second handle of a process.  Blocks
+// therefore go back to a per-device cache instead of the runtime and the next handle takes them
+// from there: no map / unmap, no first touch.
+//
+//  * size classes: requests are rounded up (512 B to 4 KB, 4 KB to 1 MB, 2 MB above) and a cached
+//    block is taken when it is at most 1/8 larger than the rounded request;
+//  * ordering: a block may be released while work that uses it is still in flight (hipFree would
+//    have waited for the device).  Releases are numbered; an acquire that picks a block released
+//    after the last device-wide wait began waits for the device once, which covers every block
+//    released up to then;
+//  * bound: at most POGS_AMD_POOL_MB of idle memory per device (default 1/4 of the device's
+//    memory; 0 turns the pool off), largest-first eviction; an allocation that fails is retried
+//    after the cache has been emptied; PogsAmdPoolTrim() empties it on request.
+struct PoolCounters {
+  unsigned long long mallocs = 0, reuses = 0, frees = 0;
+  double malloc_ms = 0, free_ms = 0;
+  size_t cached_bytes = 0, live_bytes = 0, peak_cached_bytes = 0;
+};
+
+class DevicePool {
+ public:
+  static DevicePool &get() {
+    static DevicePool *p = new DevicePool;   // never destroyed: handles may outlive static destruction
+    return *p;
+  }
+  void *acquire(size_t bytes) {
+    if (!bytes) return nullptr;
+    int dev = 0;
+    POGS_HIP_CHECK(hipGetDevice(&dev));
+    const size_t want = size_class(bytes);
+    bool need_sync = false;
+    unsigned long long upto = 0;
+    void *ptr = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      PerDevice &pd = dev_[dev & (kMaxPoolDevices - 1)];
+      auto it = pd.idle.lower_bound(want);
+      if (it != pd.idle.end() && it->first <= want + want / 8) {
+        ptr = it->second.p;
+        need_sync = it->second.stamp > pd.synced_seq;
+        upto = pd.release_seq;
+        live_[ptr] = Live{it->first, dev};   // the block keeps the size it was allocated with
+        pd.c.cached_bytes -= it->first;
+        pd.c.live_bytes += it->first;
+        pd.c.reuses++;
+        pd.idle.erase(it);
+      }
+    }
+    ptr = ptr ? finish_reuse(dev, ptr, need_sync, upto) : fresh(dev, want);
+    // POGS_AMD_POOL_POISON=1 (test aid): every block starts as NaN bytes, so that code which counts
+    // on fresh memory being zero fails the same way on its first handle as on a recycled block
+    static const bool poison = [] { const char *e = std::getenv("POGS_AMD_POOL_POISON"); return e && e[0] == '1'; }();
+    if (poison) {
+      POGS_HIP_CHECK(hipMemset(ptr, 0xFF, bytes));
+      POGS_HIP_CHECK(hipDeviceSynchronize());
+    }
+    return ptr;
+  }
+  void release(void *p) {
+    if (!p) return;
+    std::unique_lock<std::mutex> lock(mu_);
+    auto it = live_.find(p);
+    if (it == live_.end()) {   // not ours (should not happen): hand it to the runtime
+      lock.unlock();
+      (void)hipFree(p);
+      return;
+    }
+    const Live lv = it->second;
+    live_.erase(it);
+    PerDevice &pd = dev_[lv.device & (kMaxPoolDevices - 1)];
+    pd.c.live_bytes -= lv.bytes;
+    const size_t cap = capacity(lv.device, lock);
+    if (lv.bytes > cap) {
+      lock.unlock();
+      timed_free(lv.device, p, pd);
+      return;
+    }
+    Idle id;
+    id.p = p;
+    id.stamp = ++pd.release_seq;
+    pd.idle.emplace(lv.bytes, id);
+    pd.c.cached_bytes += lv.bytes;
+    // over the bound: give the largest idle blocks back to the runtime
+    std::vector<void *> evict;
+    while (pd.c.cached_bytes > cap && !pd.idle.empty()) {
+      auto last = std::prev(pd.idle.end());
+      if (last->second.p == p && pd.idle.size() > 1) {   // prefer to keep what was just released
+        auto before = std::prev(last);
+        last = before;
+      }
+      pd.c.cached_bytes -= last->first;
+      evict.push_back(last->second.p);
+      pd.idle.erase(last);
+    }
+    pd.c.peak_cached_bytes = std::max(pd.c.peak_cached_bytes, pd.c.cached_bytes);
+    lock.unlock();
+    for (void *q : evict) timed_free(lv.device, q, pd);
+  }
+  // gives every idle block of `device` (-1: all devices) back to the runtime; returns the bytes freed
+  size_t trim(int device) {
+    std::vector<std::pair<int, void *>> out;
+    size_t bytes = 0;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      for (int d = 0; d < kMaxPoolDevices; ++d) {
+        if (device >= 0 && d != (device & (kMaxPoolDevices - 1))) continue;
+        PerDevice &pd = dev_[d];
+        for (auto &kv : pd.idle) { out.emplace_back(d, kv.second.p); bytes += kv.first; }
+        pd.idle.clear();
+        pd.c.cached_bytes = 0;
+      }
+    }
+    for (auto &dp : out) timed_free(dp.first, dp.second, dev_[dp.first]);
+    return bytes;
+  }
+  PoolCounters counters(int device) {
+    std::lock_guard<std::mutex> lock(mu_);
+    return dev_[device & (kMaxPoolDevices - 1)].c;
+  }
+
+ private:
+  static constexpr int kMaxPoolDevices = 64;
+  struct Idle { void *p; unsigned long long stamp; };
+  struct Live { size_t bytes; int device; };
+  struct PerDevice {
+    std::multimap<size_t, Idle> idle;
+    PoolCounters c;
+    size_t cap = static_cast<size_t>(-1);   // -1: not read yet
+    // every release takes the next release_seq; blocks stamped <= synced_seq were released before a
+    // device-wide wait began, i.e. nothing in flight can still touch them
+    unsigned long long release_seq = 0, synced_seq = 0;
+  };
+  std::mutex mu_;
+  PerDevice dev_[kMaxPoolDevices];
+  std::unordered_map<void *, Live> live_;
+
+  static size_t size_class(size_t bytes) {
+    const size_t g = bytes <= 4096 ? 512 : bytes <= (1u << 20) ? 4096 : (2u << 20);
+    return (bytes + g - 1) / g * g;
+  }
+  static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+  // idle bytes the pool may hold on a device (called with mu_ held)
+  size_t capacity(int device, std::unique_lock<std::mutex> &) {
+    PerDevice &pd = dev_[device & (kMaxPoolDevices - 1)];
+    if (pd.cap == static_cast<size_t>(-1)) {
+      if (const char *e = std::getenv("POGS_AMD_POOL_MB")) {
+        pd.cap = static_cast<size_t>(std::max(0.0, std::atof(e)) * 1048576.0);
+      } else {
+        size_t free_b = 0, total_b = 0;
+        pd.cap = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? total_b / 4 : (static_cast<size_t>(16) << 30);
+      }
+    }
+    return pd.cap;
+  }
+  void *finish_reuse(int dev, void *ptr, bool need_sync, unsigned long long upto) {
+    if (need_sync) {
+      // the block (and possibly others) was released with work in flight: one wait covers every
+      // block released before it began
+      POGS_HIP_CHECK(hipDeviceSynchronize());
+      std::lock_guard<std::mutex> lock(mu_);
+      PerDevice &pd = dev_[dev & (kMaxPoolDevices - 1)];
+      pd.synced_seq = std::max(pd.synced_seq, upto);
+    }
+    return ptr;
+  }
+  void *fresh(int dev, size_t want) {
+    void *p = nullptr;
+    const double t0 = now_ms();
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipErrorOutOfMemory) {
+      (void)hipGetLastError();
+      trim(dev);
+      e = hipMalloc(&p, want);
+    }
+    const double dt = now_ms() - t0;
+    POGS_HIP_CHECK(e);
+    std::lock_guard<std::mutex> lock(mu_);
+    PerDevice &pd = dev_[dev & (kMaxPoolDevices - 1)];
+    pd.c.mallocs++;
+    pd.c.malloc_ms += dt;
+    pd.c.live_bytes += want;
+    live_[p] = Live{want, dev};
+    return p;
+  }
+  void timed_free(int dev, void *p, PerDevice &pd) {
+    const double t0 = now_ms();
+    (void)hipFree(p);
+    const double dt = now_ms() - t0;
+    std::lock_guard<std::mutex> lock(mu_);
+    pd.c.frees++;
+    pd.c.free_ms += dt;
+    (void)dev;
+  }
+};
+
+// RAII device buffer (memory from the DevicePool).
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
@@ -57,10 +266,10 @@ struct DevBuf {
   void alloc(size_t count) {
     release();
     n = count;
-    if (count) POGS_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+    if (count) p = static_cast<T *>(DevicePool::get().acquire(count * sizeof(T)));
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) DevicePool::get().release(p);
     p = nullptr;
     n = 0;
   }

@@ -335,8 +335,19 @@ class DenseSolver final : public SolverBase {
     // equilibration passes read the caller's buffer and its last pass writes the scaled matrix straight into
     // A_ (equilibrate()); the caller's buffer is never written.  4 GB less to copy at C2 (1.5 ms).
     const char *ae = std::getenv("POGS_AMD_ALIAS_INPUT");
-    const bool may_alias = mem == POGS_AMD_DEVICE && !(ae && ae[0] == '0') &&
-                           (reinterpret_cast<uintptr_t>(A) % 16) == 0;
+    bool may_alias = mem == POGS_AMD_DEVICE && !(ae && ae[0] == '0') &&
+                     (reinterpret_cast<uintptr_t>(A) % 16) == 0;
+    if (may_alias) {
+      // only a buffer that lives on THIS handle's device is read in place: one on another GPU (or
+      // host-mapped memory) goes through the runtime's copy as before
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, A) != hipSuccess) {
+        (void)hipGetLastError();
+        may_alias = false;
+      } else {
+        may_alias = attr.type == hipMemoryTypeDevice && attr.device == ctx_.device;
+      }
+    }
     if (tmode_) {
       // stored matrix = A^T, n rows of m: column-major input already is that; row-major is transposed
       if (lda_ != static_cast<size_t>(m_)) A_.zero(s);

@@ -14,12 +14,18 @@
 // unpack kernel); the one-pass dense iteration fills its pack buffer straight from the producing
 // kernels and calls allreduce() on it (dense_solver.h).  No ncclGroupStart/End anywhere.
 //
-// Test transport (only with POGS_AMD_TEST_TRANSPORT=1 in the environment; otherwise such an id
+// Test transport (only with POGS_AMD_TEST_TRANSPORT set in the environment; otherwise such an id
 // is refused): a unique id that starts with "POGSLOCAL:" selects an in-process communicator
-// instead of RCCL -- the ranks are threads of one process (each with its own solver, possibly
-// on the same GPU), buffers are staged through the host and summed in rank order.  It exists
-// so that the row-sharded decomposition of the engine itself can be verified on a single GPU
-// (RCCL refuses two ranks on one device); it is not a performance path.
+// instead of RCCL -- the ranks are threads of one process, each with its own solver, on the same
+// GPU.  It exists so that the row-sharded decomposition of the engine itself can be verified on a
+// single GPU (RCCL refuses two ranks on one device); it is not a performance path.
+//   POGS_AMD_TEST_TRANSPORT=1     stream-ordered, like ncclAllReduce: every rank copies its buffer
+//       into a device slot on ITS stream and records an event; the threads meet (host barrier, no
+//       stream is waited for); every rank makes its stream wait for the peers' events and sums the
+//       slots in rank order with a kernel.  The host never waits for the device, so a kernel that
+//       reads the result too early, or overwrites an operand too soon, shows up as a wrong answer.
+//   POGS_AMD_TEST_TRANSPORT=host  round 1's form: buffers staged through the host and summed there
+//       (hipStreamSynchronize on both sides of the exchange).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -45,6 +51,8 @@ class DistComm {
   // In-place sum all-reduce on `stream`.  No-ops when not initialised.
   void allreduce(float *buf, size_t count, hipStream_t stream) const;
   void allreduce(double *buf, size_t count, hipStream_t stream) const;
+  // out-of-place: out = sum over ranks of in (in is not written; in != out)
+  void allreduce(const double *in, double *out, size_t count, hipStream_t stream) const;
   // A vector and one / two scalar ranges as ONE all-reduce of a packed fp64 buffer.
   template <typename T>
   void allreduce2(T *buf, size_t count, double *scalars, size_t nscalars, hipStream_t stream);
@@ -66,7 +74,7 @@ class DistComm {
   static void unique_id(char *out);  // fresh id (rank 0)
 
  private:
-  void reduce_raw(void *buf, size_t count, int dtype, hipStream_t stream) const;
+  void reduce_raw(const void *in, void *out, size_t count, int dtype, hipStream_t stream) const;
   int rank_ = 0, world_ = 1;
   void *comm_ = nullptr;
   void *local_ = nullptr;   // std::shared_ptr<LocalGroup>* (test transport)

@@ -76,11 +76,24 @@ constexpr char kLocalTag[] = "POGSLOCAL:";
 
 struct LocalGroup {
   int world = 0;
+  bool host_staged = false;   // POGS_AMD_TEST_TRANSPORT=host
   std::mutex mu;
   std::condition_variable cv;
   int arrived = 0;
   unsigned long long gen = 0;
-  std::vector<std::vector<unsigned char>> slots;
+  std::vector<std::vector<unsigned char>> slots;   // host-staged form
+  // stream-ordered form: one device slot and two events per rank
+  std::vector<void *> dslot;
+  std::vector<size_t> dcap;
+  std::vector<hipEvent_t> ready, done;
+  std::vector<int> device;
+  std::vector<unsigned long long> calls;   // collectives each rank has taken part in
+
+  ~LocalGroup() {
+    for (void *p : dslot) if (p) (void)hipFree(p);
+    for (hipEvent_t e : ready) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+  }
 
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
@@ -102,7 +115,7 @@ struct LocalGroup {
   }
 };
 
-std::shared_ptr<LocalGroup> local_group(const std::string &key, int world) {
+std::shared_ptr<LocalGroup> local_group(const std::string &key, int world, bool host_staged) {
   static std::mutex mu;
   static std::map<std::string, std::weak_ptr<LocalGroup>> groups;
   std::lock_guard<std::mutex> lk(mu);
@@ -110,7 +123,14 @@ std::shared_ptr<LocalGroup> local_group(const std::string &key, int world) {
   if (!g) {
     g = std::make_shared<LocalGroup>();
     g->world = world;
+    g->host_staged = host_staged;
     g->slots.resize(world);
+    g->dslot.assign(world, nullptr);
+    g->dcap.assign(world, 0);
+    g->ready.assign(world, nullptr);
+    g->done.assign(world, nullptr);
+    g->device.assign(world, -1);
+    g->calls.assign(world, 0);
     groups[key] = g;
   }
   POGS_CHECK(g->world == world, "local communicator: ranks disagree on the world size");
@@ -118,11 +138,11 @@ std::shared_ptr<LocalGroup> local_group(const std::string &key, int world) {
 }
 
 template <typename T>
-void local_allreduce(LocalGroup &g, int rank, T *buf, size_t count, hipStream_t stream) {
+void local_allreduce_host(LocalGroup &g, int rank, const T *in, T *out, size_t count, hipStream_t stream) {
   const size_t bytes = count * sizeof(T);
   std::vector<unsigned char> &mine = g.slots[rank];
   mine.resize(bytes);
-  POGS_HIP_CHECK(hipMemcpyAsync(mine.data(), buf, bytes, hipMemcpyDeviceToHost, stream));
+  POGS_HIP_CHECK(hipMemcpyAsync(mine.data(), in, bytes, hipMemcpyDeviceToHost, stream));
   POGS_HIP_CHECK(hipStreamSynchronize(stream));
   g.barrier();
   std::vector<T> sum(count, static_cast<T>(0));
@@ -132,8 +152,75 @@ void local_allreduce(LocalGroup &g, int rank, T *buf, size_t count, hipStream_t 
     for (size_t i = 0; i < count; ++i) sum[i] += p[i];
   }
   g.barrier();   // nobody overwrites a slot that is still being read
-  POGS_HIP_CHECK(hipMemcpyAsync(buf, sum.data(), bytes, hipMemcpyHostToDevice, stream));
+  POGS_HIP_CHECK(hipMemcpyAsync(out, sum.data(), bytes, hipMemcpyHostToDevice, stream));
   POGS_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+// out[i] = slot_0[i] + slot_1[i] + ... in rank order (every rank forms the identical sum)
+constexpr int kLocalMaxWorld = 16;
+struct LocalSlots {
+  const void *p[kLocalMaxWorld];
+};
+template <typename T>
+__global__ void __launch_bounds__(256) local_sum_kernel(LocalSlots slots, int world, size_t count, T *out) {
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += static_cast<size_t>(gridDim.x) * 256) {
+    T v = static_cast<T>(0);
+    for (int r = 0; r < world; ++r) v += static_cast<const T *>(slots.p[r])[i];
+    out[i] = v;
+  }
+}
+
+// Stream-ordered exchange (dist.h): no call in here waits for a stream.  Per collective and rank:
+//   wait (on the stream) for the peers' `done` of the previous collective -- my slot may still be read;
+//   copy in -> own slot, record `ready`
+//   ---- host barrier: every `ready` has been RECORDED (not necessarily reached) ----
+//   wait (on the stream) for every peer's `ready`; sum kernel over the slots -> out; record `done`
+//   ---- host barrier: every `done` has been recorded ----
+template <typename T>
+void local_allreduce_stream(LocalGroup &g, int rank, const T *in, T *out, size_t count, hipStream_t stream) {
+  POGS_CHECK(g.world <= kLocalMaxWorld, "local communicator: at most 16 ranks");
+  const size_t bytes = count * sizeof(T);
+  int dev = 0;
+  POGS_HIP_CHECK(hipGetDevice(&dev));
+  if (!g.ready[rank]) {
+    POGS_HIP_CHECK(hipEventCreateWithFlags(&g.ready[rank], hipEventDisableTiming));
+    POGS_HIP_CHECK(hipEventCreateWithFlags(&g.done[rank], hipEventDisableTiming));
+    g.device[rank] = dev;
+  }
+  if (bytes > g.dcap[rank]) {
+    // the slot grows (the first collective of each size): drain the device first -- a peer's sum
+    // kernel of the previous collective may still read the old slot
+    POGS_HIP_CHECK(hipDeviceSynchronize());
+    if (g.dslot[rank]) POGS_HIP_CHECK(hipFree(g.dslot[rank]));
+    g.dslot[rank] = nullptr;
+    POGS_HIP_CHECK(hipMalloc(&g.dslot[rank], bytes));
+    g.dcap[rank] = bytes;
+  }
+  if (g.calls[rank] > 0) {
+    for (int r = 0; r < g.world; ++r)
+      if (r != rank) POGS_HIP_CHECK(hipStreamWaitEvent(stream, g.done[r], 0));
+  }
+  POGS_HIP_CHECK(hipMemcpyAsync(g.dslot[rank], in, bytes, hipMemcpyDeviceToDevice, stream));
+  POGS_HIP_CHECK(hipEventRecord(g.ready[rank], stream));
+  g.barrier();
+  LocalSlots slots;
+  for (int r = 0; r < g.world; ++r) {
+    POGS_CHECK(g.device[r] == dev, "local communicator (stream-ordered form): all ranks must use one device");
+    POGS_CHECK(g.dcap[r] >= bytes, "local communicator: ranks disagree on the element count");
+    slots.p[r] = g.dslot[r];
+    if (r != rank) POGS_HIP_CHECK(hipStreamWaitEvent(stream, g.ready[r], 0));
+  }
+  const unsigned grid = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(1024, (count + 255) / 256)));
+  hipLaunchKernelGGL(local_sum_kernel<T>, dim3(grid), dim3(256), 0, stream, slots, g.world, count, out);
+  POGS_HIP_CHECK(hipEventRecord(g.done[rank], stream));
+  ++g.calls[rank];
+  g.barrier();
+}
+
+template <typename T>
+void local_allreduce(LocalGroup &g, int rank, const T *in, T *out, size_t count, hipStream_t stream) {
+  if (g.host_staged) local_allreduce_host(g, rank, in, out, count, stream);
+  else local_allreduce_stream(g, rank, in, out, count, stream);
 }
 
 }  // namespace
@@ -184,9 +271,9 @@ void DistComm::init(int rank, int world, const char *unique_id) {
   world_ = world;
   if (std::strncmp(unique_id, kLocalTag, sizeof(kLocalTag) - 1) == 0) {
     const char *tt = std::getenv("POGS_AMD_TEST_TRANSPORT");
-    POGS_CHECK(tt && tt[0] == '1', "the in-process test transport needs POGS_AMD_TEST_TRANSPORT=1");
+    POGS_CHECK(tt && (tt[0] == '1' || tt[0] == 'h'), "the in-process test transport needs POGS_AMD_TEST_TRANSPORT=1");
     const std::string key(unique_id, strnlen(unique_id, kUniqueIdBytes));
-    local_ = new std::shared_ptr<LocalGroup>(local_group(key, world));
+    local_ = new std::shared_ptr<LocalGroup>(local_group(key, world, tt[0] == 'h'));
     return;
   }
   UniqueId id;
@@ -216,24 +303,27 @@ const char *DistComm::async_error() const {
   return api().GetErrorString ? api().GetErrorString(e) : "asynchronous RCCL error";
 }
 
-void DistComm::reduce_raw(void *buf, size_t count, int dtype, hipStream_t stream) const {
+void DistComm::reduce_raw(const void *in, void *out, size_t count, int dtype, hipStream_t stream) const {
   if (count == 0 || !active()) return;
   if (aborted_) throw Error("the RCCL communicator of this handle was aborted (a collective timed out or failed)");
   ++ncoll_;
   if (local_) {
     LocalGroup &g = **static_cast<std::shared_ptr<LocalGroup> *>(local_);
-    if (dtype == kNcclFloat) local_allreduce(g, rank_, static_cast<float *>(buf), count, stream);
-    else local_allreduce(g, rank_, static_cast<double *>(buf), count, stream);
+    if (dtype == kNcclFloat) local_allreduce(g, rank_, static_cast<const float *>(in), static_cast<float *>(out), count, stream);
+    else local_allreduce(g, rank_, static_cast<const double *>(in), static_cast<double *>(out), count, stream);
     return;
   }
-  check(api().AllReduce(buf, buf, count, dtype, kNcclSum, comm_, stream), "ncclAllReduce");
+  check(api().AllReduce(in, out, count, dtype, kNcclSum, comm_, stream), "ncclAllReduce");
 }
 
 void DistComm::allreduce(float *buf, size_t count, hipStream_t stream) const {
-  reduce_raw(buf, count, kNcclFloat, stream);
+  reduce_raw(buf, buf, count, kNcclFloat, stream);
 }
 void DistComm::allreduce(double *buf, size_t count, hipStream_t stream) const {
-  reduce_raw(buf, count, kNcclDouble, stream);
+  reduce_raw(buf, buf, count, kNcclDouble, stream);
+}
+void DistComm::allreduce(const double *in, double *out, size_t count, hipStream_t stream) const {
+  reduce_raw(in, out, count, kNcclDouble, stream);
 }
 
 template <typename T>

@@ -227,10 +227,7 @@ struct Ctx {
   }
   // scalars that the next fetch takes from a packed all-reduce buffer (consumed by that fetch)
   void set_overlay(const ScalarOverlay &ov) { overlay = ov; }
-  // A kernel of the caller publishes the block itself (cg_fused.h: fin_publish): begin_publish
-  // hands out the sequence number it must raise, wait_publish polls for it.
-  unsigned long long begin_publish() { return ++fetch_seq; }
-  unsigned long long *host_seq_dev() const { return reinterpret_cast<unsigned long long *>(S_host_dev + kNumSlots); }
+  // polls the host-mapped sequence word until the publishing launch has raised it to `want`
   const double *wait_publish(unsigned long long want) {
     unsigned long long *seqp = reinterpret_cast<unsigned long long *>(S_host.p + kNumSlots);
     unsigned spins = 0, idle_seen = 0, checks = 0;
@@ -323,11 +320,18 @@ struct Ctx {
     const double t1 = wall_s();
     POGS_HIP_CHECK(hipStreamSynchronize(stream));
     const double t2 = wall_s();
-    std::fprintf(stderr, "[pogs_amd trace] %-28s host +%8.3f ms, drain +%8.3f ms\n", label,
-                 (t1 - tmark_last) * 1e3, (t2 - t1) * 1e3);
+    // what the phase took from / gave to the HIP runtime (DevicePool, common.h): a phase that
+    // stalls in hipMalloc / hipFree shows here, a first-touch stall shows as drain time
+    const PoolCounters pc = DevicePool::get().counters(device);
+    std::fprintf(stderr, "[pogs_amd trace] %-28s host +%8.3f ms, drain +%8.3f ms | pool: +%llu malloc %.3f ms, +%llu reuse, "
+                 "+%llu free %.3f ms\n", label, (t1 - tmark_last) * 1e3, (t2 - t1) * 1e3,
+                 pc.mallocs - tmark_pool.mallocs, pc.malloc_ms - tmark_pool.malloc_ms, pc.reuses - tmark_pool.reuses,
+                 pc.frees - tmark_pool.frees, pc.free_ms - tmark_pool.free_ms);
+    tmark_pool = pc;
     tmark_last = wall_s();
   }
   double tmark_last = 0;
+  PoolCounters tmark_pool;
   bool poisoned = false;   // set when an error left the stream / communicator in an unknown state
   // an exception escaped a solve on this context: with row shards the peers are (or will be) inside
   // a collective this rank no longer takes part in -- abort the communicator so that they fail too,

@@ -57,6 +57,18 @@ struct SpAxpbyOp {  // y[i] = alpha * dot + beta * yin[i]
 };
 
 template <typename T>
+struct SpStoreOp {  // y[i] = dot, no sums: the local part of a row-sharded A^T product, before its all-reduce
+  static constexpr int NS = 0;
+  T *y;
+  template <int N>
+  __device__ __forceinline__ void row(int i, T dot, double (&)[N]) const { y[i] = dot; }
+  struct In {};
+  __device__ __forceinline__ In load(int) const { return In{}; }
+  template <int N>
+  __device__ __forceinline__ void apply(int i, T dot, const In &, double (&)[N]) const { y[i] = dot; }
+};
+
+template <typename T>
 struct SpAxpbyNormOp {  // y[i] = alpha * dot + beta * yin[i]; s0 += y[i]^2
   static constexpr int NS = 1;
   T alpha, beta;
@@ -927,13 +939,40 @@ class SparseSolver final : public SolverBase {
     sp_cgp_off_ = sp_cgx_off_ + cgreg;
     sp_pre_off_ = sp_cgp_off_ + cgreg;   // prox-step sums (deferred on one GPU)
     ctx_.ensure_spart(sp_pre_off_ + vb * 3 + 8);
-    // device-resident CGLS loop (cg_fused.h): one GPU, both copies in the tiled layout
+    // device-resident CGLS loop (cg_fused.h): both copies in the tiled layout; POGS_AMD_CG=h keeps
+    // round 2's host-polled loop (cgls_project), which is also what the plain-CSR fallback runs
     const char *cg_env = std::getenv("POGS_AMD_CG");
-    fused_cg_ = !multi_ && A_.sell_ready && At_.sell_ready && !(cg_env && cg_env[0] == 'h') && ctx_.poll_fetch;
+    fused_cg_ = A_.sell_ready && At_.sell_ready && !(cg_env && cg_env[0] == 'h') && ctx_.poll_fetch;
+    if (multi_) {
+      // every rank must take the same path (the collectives of the two loops differ): all or none
+      DevBuf<double> flag(1);
+      const double mine = fused_cg_ ? 0.0 : 1.0;
+      POGS_HIP_CHECK(hipMemcpyAsync(flag.p, &mine, sizeof(double), hipMemcpyHostToDevice, s));
+      ctx_.dist.allreduce(flag.p, 1, s);
+      double any = 0;
+      POGS_HIP_CHECK(hipMemcpyAsync(&any, flag.p, sizeof(double), hipMemcpyDeviceToHost, s));
+      POGS_HIP_CHECK(hipStreamSynchronize(s));
+      if (any != 0.0) fused_cg_ = false;
+    }
     if (fused_cg_) {
       // scalar records of the loop's products: one region for A^T products, one for A products
       cg_rec_cap_ = static_cast<size_t>(std::max({A_.nrr * A_.ncg, At_.nrr * At_.ncg, kCgfBlocks})) * 2;
-      cg_rec_.alloc(cg_rec_cap_ * 2);
+      if (multi_) {
+        // row shards: the |q|^2 records of the ranks are summed record by record (one all-reduce of the
+        // record array, no folding launch), so the ranks agree on its length -- the largest -- and a
+        // rank's unused tail stays zero; the sums land in a third region
+        DevBuf<double> caps(static_cast<size_t>(ctx_.dist.world()));
+        caps.zero(s);
+        const double mine = static_cast<double>(cg_rec_cap_);
+        POGS_HIP_CHECK(hipMemcpyAsync(caps.p + ctx_.dist.rank(), &mine, sizeof(double), hipMemcpyHostToDevice, s));
+        ctx_.dist.allreduce(caps.p, caps.n, s);
+        std::vector<double> all(caps.n);
+        POGS_HIP_CHECK(hipMemcpyAsync(all.data(), caps.p, caps.n * sizeof(double), hipMemcpyDeviceToHost, s));
+        POGS_HIP_CHECK(hipStreamSynchronize(s));
+        for (double v : all) cg_rec_cap_ = std::max(cg_rec_cap_, static_cast<size_t>(v));
+      }
+      cg_rec_.alloc(cg_rec_cap_ * (multi_ ? 3 : 2));
+      cg_rec_.zero(s);
       const char *ys = std::getenv("POGS_AMD_YSYNC");
       if (ys) ysync_ = std::max(0, std::atoi(ys));
     }
@@ -1313,28 +1352,49 @@ class SparseSolver final : public SolverBase {
     std::vector<size_t> &ev = fused_events_;
     ev.clear();
     size_t e;
+    // Row shards: q = A p and r are this rank's rows, x, p, s are
+    // replicated.  The two sums a CG step needs over all ranks travel on the stream, between the
+    // launches that produce and consume them -- |q|^2 as the array of per-block records (summed
+    // record by record; every block of U1 then adds the records up as on one GPU), A^T r as the
+    // n-vector of local column sums, after which the row functor runs on the totals -- so a step
+    // stays device-resident: 2 collectives, 0 host polls.
+    double *rec_a_sum = multi_ ? cg_rec_.p + 2 * cg_rec_cap_ : rec_a;
+    const int nrec_a_sum = static_cast<int>(cg_rec_cap_);
+    auto at_product = [&](auto op, int run_if_done) {   // s-type products: returns the number of records in rec_t
+      if (!multi_) return spmv_cg(At_, cg_r_.p, op, rec_t, run_if_done, &e);
+      spmv_cg(At_, cg_r_.p, SpStoreOp<T>{tsum_.p}, rec_t, run_if_done, &e);
+      ctx_.dist.allreduce(tsum_.p, n_, s);
+      const int nrec = cgf_blocks(n_);
+      hipLaunchKernelGGL((cgf_reduce_kernel<T, decltype(op)>), dim3(nrec), dim3(kCgfTpb), 0, s, tsum_.p, n_, 1, op, rec_t,
+                         S, run_if_done);
+      return nrec;
+    };
     // s = A^T r - shift x ; p = s ; |s_0|^2 records                           (cgls.h:236-245)
-    const int nrec_s0 = spmv_cg(At_, cg_r_.p, SpCgInitOp<T>{static_cast<T>(shift), x, cg_s_.p, cg_p_.p}, rec_t, -1, &e);
+    const int nrec_s0 = at_product(SpCgInitOp<T>{static_cast<T>(shift), x, cg_s_.p, cg_p_.p}, -1);
     const int gv = cgf_blocks(std::max(n_, m_)), gp = cgf_blocks(n_);
     int enq = 0;
     auto step = [&]() {
       // q = A p, |q|^2 records                                               (cgls.h:257-260)
-      const int nrec_q = spmv_cg(A_, cg_p_.p, SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p}, rec_a, 0, &e);
+      int nrec_q = spmv_cg(A_, cg_p_.p, SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p}, rec_a, 0, &e);
       ev.push_back(e);
+      if (multi_) {
+        ctx_.dist.allreduce(rec_a, rec_a_sum, static_cast<size_t>(nrec_a_sum), s);
+        nrec_q = nrec_a_sum;
+      }
       // alpha ; x += alpha p ; r -= alpha q ; y_new += alpha q ; |x|^2        (:262-277, 298)
       CgfStepA<T> a;
       a.n = n_; a.m = m_; a.S = S;
       a.first = enq == 0; a.gslot = enq & 1;
       a.rec_s0 = rec_t; a.nrec_s0 = nrec_s0;
       a.rec_p = rec_p; a.nrec_p = gp;
-      a.rec_q = rec_a; a.nrec_q = nrec_q;
+      a.rec_q = rec_a_sum; a.nrec_q = nrec_q;
       a.shift = shift; a.eps = kEps;
       a.p = cg_p_.p; a.x = x; a.q = cg_q_.p; a.r = cg_r_.p;
       a.ycur = y_[cur_].p; a.ynew = ysync ? nullptr : y_[nw].p;
       a.rec_x = rec_x;
       hipLaunchKernelGGL(cgf_step_a_kernel<T>, dim3(gv), dim3(kCgfTpb), 0, s, a);
       // s = A^T r - shift x ; |s|^2 records                                  (:281-286)
-      const int nrec_s = spmv_cg(At_, cg_r_.p, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, rec_t, 0, &e);
+      const int nrec_s = at_product(SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, 0);
       ev.push_back(e);
       // beta, gamma, the stopping test ; p = s + beta p ; |p|^2              (:288-305)
       CgfStepB<T> b;
@@ -1356,17 +1416,28 @@ class SparseSolver final : public SolverBase {
       c.part = cpart; c.blocks_x = bx;
       hipLaunchKernelGGL(cgf_close_kernel<T>, dim3(ysync ? bx : bx + bm), dim3(kVecTpb), 0, s, c);
       ctx_.queue_sum(SumJob{pa.partials, bx, 3, S + kGapX});
-      ctx_.queue_sum(SumJob{pa.partials + static_cast<size_t>(bx) * 3, bm, 3, S + kGapY});
       ctx_.queue_sum(SumJob{cpart, bx, 2, S + kDXprev2});
-      if (!ysync) ctx_.queue_sum(SumJob{cpart + static_cast<size_t>(bx) * 2, bm, 2, S + kDYprev2});
+      if (!multi_) {
+        ctx_.queue_sum(SumJob{pa.partials + static_cast<size_t>(bx) * 3, bm, 3, S + kGapY});
+        if (!ysync) ctx_.queue_sum(SumJob{cpart + static_cast<size_t>(bx) * 2, bm, 2, S + kDYprev2});
+      } else {
+        // the y-side sums are over this rank's rows: slots kGapY .. kDY12 are adjacent, one all-reduce
+        static_assert(kWY2 == kGapY + 1 && kHY2 == kGapY + 2 && kDYprev2 == kGapY + 3 && kDY12 == kGapY + 4, "slot order");
+        SumJob j[2] = {{pa.partials + static_cast<size_t>(bx) * 3, bm, 3, S + kGapY},
+                       {cpart + static_cast<size_t>(bx) * 2, bm, 2, S + kDYprev2}};
+        launch_sum_jobs(j, ysync ? 1 : 2, s);
+        ctx_.dist.allreduce(S + kGapY, ysync ? 3 : 5, s);
+      }
       return ctx_.fetch_scalars();
     };
     const int ahead = std::max(1, std::min(cg_pred_, 500));
     for (int k = 0; k < ahead; ++k) step();
     const double *Sh = close();
+    int more = 1;
     while (Sh[kFcDone] == 0.0) {   // the loop needed more steps than the previous projection
-      step();
+      for (int k = 0; k < more && enq < 500; ++k) step();
       Sh = close();
+      more = std::min(2 * more, 64);   // a growing chunk per host poll, not one step per poll
     }
     const int steps = static_cast<int>(Sh[kFcSteps]);
     cg_pred_ = std::max(1, steps);
@@ -1377,6 +1448,7 @@ class SparseSolver final : public SolverBase {
     if (ysync) {
       // y = A x fused with the y-half bookkeeping                             (projector_cgls.cpp:78)
       spmv<false>(A_, x, nullptr, SpTailOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p}, S + kDYprev2, 0, true);
+      reduce_y_scalars(S + kDYprev2, 2);
       Sh = ctx_.fetch_scalars();
     }
     return Sh;

@@ -65,7 +65,7 @@ def _fsum(fv, v):
     return float(np.sum(c * out + d * v + 0.5 * e * v * v))
 
 
-def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, count_collectives=False, **solve_kw):
+def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, count_collectives=False, transport="1", **solve_kw):
     """Solves with `world` ranks inside this process: one thread + one Solver per rank, rows split
     evenly, joined by the engine's in-process test communicator ("POGSLOCAL:" unique id, see
     pogs_amd/csrc/dist.h).  Verifies the engine's own row-sharded decomposition on ONE GPU.
@@ -75,7 +75,9 @@ def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, count_collectiv
 
     import numpy as np
 
-    os.environ["POGS_AMD_TEST_TRANSPORT"] = "1"   # the in-process communicator is refused without it
+    # the in-process communicator is refused without it; "1": stream-ordered (device slots + events, no
+    # stream is ever waited for), "host": staged through the host (pogs_amd/csrc/dist.h)
+    os.environ["POGS_AMD_TEST_TRANSPORT"] = transport
     m = A.shape[0]
     uid = (b"POGSLOCAL:" + os.urandom(8).hex().encode()).ljust(128, b"\0")
     bounds = np.linspace(0, m, world + 1).astype(int)
@@ -103,6 +105,50 @@ def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, count_collectiv
         t.start()
     for t in threads:
         t.join(600)
+    assert not errors, errors
+    assert all(r is not None for r in results)
+    return results, bounds
+
+
+def run_sharded_oracle(A, f, g, world, dtype, **solve_kw):
+    """The ORACLE's row-sharded entry (oracle/pogs_oracle.cpp: OraclePogsShard* / OraclePogsSparseShard*)
+    with `world` ranks as threads of this process and an in-test sum in rank order as the collective.
+    Returns (per-rank result dicts, bounds) with the same row split as run_row_sharded."""
+    import threading
+
+    import oracle_binding as ob
+
+    m = A.shape[0]
+    bounds = np.linspace(0, m, world + 1).astype(int)
+    bar = threading.Barrier(world)
+    slots = [None] * world
+    results, errors = [None] * world, []
+
+    def make_allreduce(r):
+        def allreduce(arr):
+            slots[r] = arr.copy()
+            bar.wait(600)
+            total = slots[0].copy()
+            for q in range(1, world):
+                total += slots[q]
+            bar.wait(600)   # nobody overwrites a slot that is still being read
+            arr[:] = total
+        return allreduce
+
+    def work(r):
+        try:
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            results[r] = ob.oracle_solve_shard(A[lo:hi], m, soa(f.slice(lo, hi)), soa(g), make_allreduce(r), dtype=dtype,
+                                               **solve_kw)
+        except Exception as e:  # pragma: no cover - surfaced below
+            errors.append((r, e))
+            bar.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(900)
     assert not errors, errors
     assert all(r is not None for r in results)
     return results, bounds

@@ -14,6 +14,9 @@ _ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 _ORACLE_DIR = os.path.join(_ROOT, "oracle")
 _ORACLE_SO = os.path.join(_ORACLE_DIR, "liboracle.so")
 _REF_SO = os.path.join(_ORACLE_DIR, "_ref", "libpogs_cpu.so")
+# the same six reference sources against scipy's OpenBLAS (oracle/Makefile: ref_openblas): TIMING ONLY,
+# bench.py's "best configuration" CPU column -- parity stays pinned to the MKL build above
+_REF_SO_OPENBLAS = os.path.join(_ORACLE_DIR, "_ref", "libpogs_cpu_openblas.so")
 
 
 class OracleInfo(ctypes.Structure):
@@ -46,6 +49,8 @@ def build_oracle(force=False):
 
 def build_ref():
     """Build the real reference if its sources are present (build container only)."""
+    if os.path.isdir("/root/reference/src") and not os.path.exists(_REF_SO_OPENBLAS):
+        subprocess.call(["make", "-C", _ORACLE_DIR, "ref_openblas"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if os.path.exists(_REF_SO):
         return _REF_SO
     if not os.path.isdir("/root/reference/src"):
@@ -185,8 +190,8 @@ def oracle_set_threads(n=None):
     return n
 
 
-def ref_available():
-    return os.path.exists(_REF_SO)
+def ref_available(blas="mkl"):
+    return os.path.exists(_REF_SO_OPENBLAS if blas == "openblas" else _REF_SO)
 
 
 class RefRun:
@@ -260,7 +265,7 @@ def ref_env_note():
 
 
 def ref_start(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0,
-              adaptive_rho=True, gap_stop=True, order=1, threads=None):
+              adaptive_rho=True, gap_stop=True, order=1, threads=None, blas="mkl"):
     """Start the compiled reference (PogsD/S, PogsSparseD/S) in a CLEAN subprocess and return a
     RefRun (None if the reference is not available); RefRun.finish() collects the result.
 
@@ -273,7 +278,7 @@ def ref_start(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, ma
     import tempfile
     import time
 
-    if not ref_available():
+    if not ref_available(blas):
         return None
     sparse = hasattr(A, "indptr")
     td = tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -294,8 +299,12 @@ def ref_start(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, ma
         env = dict(os.environ)
         env.pop("PYTHONPATH", None)
         nthr = str(threads if threads else ref_threads())
-        env.update(MKL_NUM_THREADS=nthr, OMP_NUM_THREADS=nthr)
+        env.update(MKL_NUM_THREADS=nthr, OMP_NUM_THREADS=nthr, OPENBLAS_NUM_THREADS=nthr)
         env.update(REF_ENV)
+        if blas == "openblas":
+            env["POGS_REF_SO"] = _REF_SO_OPENBLAS
+        else:
+            env.pop("POGS_REF_SO", None)
         cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_runner.py"), td.name]
         proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     except Exception:
@@ -305,11 +314,12 @@ def ref_start(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, ma
 
 
 def ref_solve(A, f, g, dtype=np.float64, rho=1.0, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0,
-              adaptive_rho=True, gap_stop=True, order=1, timeout=None, threads=None):
+              adaptive_rho=True, gap_stop=True, order=1, timeout=None, threads=None, blas="mkl"):
     """ref_start + finish.  Returns None if the reference is not available; raises
     subprocess.TimeoutExpired on timeout."""
     run = ref_start(A, f, g, dtype=dtype, rho=rho, abs_tol=abs_tol, rel_tol=rel_tol, max_iter=max_iter,
-                    verbose=verbose, adaptive_rho=adaptive_rho, gap_stop=gap_stop, order=order, threads=threads)
+                    verbose=verbose, adaptive_rho=adaptive_rho, gap_stop=gap_stop, order=order, threads=threads,
+                    blas=blas)
     return None if run is None else run.finish(timeout)
 
 

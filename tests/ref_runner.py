@@ -12,7 +12,8 @@ import time
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REF_SO = os.path.join(HERE, "..", "oracle", "_ref", "libpogs_cpu.so")
+# POGS_REF_SO: another build of the same reference sources (oracle/_ref/libpogs_cpu_openblas.so, timing only)
+REF_SO = os.environ.get("POGS_REF_SO") or os.path.join(HERE, "..", "oracle", "_ref", "libpogs_cpu.so")
 
 
 def main(td):

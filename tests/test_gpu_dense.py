@@ -672,7 +672,7 @@ def test_row_sharded_engine_matches_single_rank(dtype, world):
     (threads + the in-process test communicator): same trajectory and solution as the
     unsharded solve and as the sharded oracle."""
     pogs = _pogs()
-    from helpers import run_row_sharded
+    from helpers import run_row_sharded, run_sharded_oracle
     from pogs_amd import synth
 
     m, n = 3001, 257
@@ -681,6 +681,24 @@ def test_row_sharded_engine_matches_single_rank(dtype, world):
     with pogs.Solver(A, dtype=dtype) as s:
         one = s.solve(f, g)
     res, bounds = run_row_sharded(pogs, A, f, g, world, dtype, count_collectives=True)
+    # the ORACLE: unsharded (pinned to the compiled reference) and its own row-sharded entry with an
+    # in-test sum in rank order as the collective -- same tolerances as the unsharded tests of this file
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype)
+    want_sh, _ = run_sharded_oracle(A, f, g, world, dtype)
+    for r, out in enumerate(res):
+        lo, hi = bounds[r], bounds[r + 1]
+        for w, wy, wl in ((want, want["y"][lo:hi], want["l"][lo:hi]), (want_sh[r], want_sh[r]["y"], want_sh[r]["l"])):
+            assert w["status"] == out["status"] == 0
+            if dtype == np.float64:
+                assert abs(int(out["iterations"]) - int(w["iterations"])) <= 2
+                otol = 1e-6
+            else:
+                assert abs(int(out["iterations"]) - int(w["iterations"])) <= max(3, w["iterations"] // 10)
+                otol = _xtol32(out["iterations"], w["iterations"], loose=2e-4)
+            assert relerr(out["x"], w["x"]) < otol
+            assert relerr(out["y"], wy) < otol * 10
+            assert relerr(out["l"], wl) < otol * 100
+            assert out["optval"] == pytest.approx(w["optval"], rel=max(otol, 1e-6))
     tol = 1e-9 if dtype == np.float64 else _xtol32(res[0]["iterations"], one["iterations"], loose=2e-4)
     # ONE all-reduce per iteration (a second one only when the speculation
     # missed and the iteration needed its own pass), + the objective's at the end

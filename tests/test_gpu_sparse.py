@@ -435,33 +435,82 @@ def test_plain_csr_kernel_still_matches(monkeypatch):
 
 @pytest.mark.parametrize("dtype,world", [(np.float64, 2), (np.float32, 3)])
 def test_row_sharded_sparse_engine_matches_single_rank(dtype, world):
-    """CSR row blocks over several ranks (threads + the in-process test
-    communicator, one GPU): CGLS with all-reduced A^T products and row sums follows the unsharded
-    solve and the sharded oracle (tests/test_dist_gloo.py checks that decomposition on CPU)."""
+    """CSR row blocks over several ranks (threads + the in-process,
+    stream-ordered test communicator, one GPU), the device-resident CGLS loop with its two all-reduces
+    per step.  Held against the ORACLE -- the unsharded restatement (oracle_solve, pinned to the
+    compiled reference) and its row-sharded entry with an in-test sum as the collective
+    (projector_cgls.cpp:59-78, cgls.h:200-323 with the A^T products and |q|^2 summed over the ranks) --
+    and, as a consistency check, against the unsharded engine."""
     pogs = _pogs()
-    from helpers import run_row_sharded
+    from helpers import run_row_sharded, run_sharded_oracle
     from pogs_amd import synth
 
     m, n = 4001, 900
     A, b, _ = synth.csr_lasso(m, n, 15, seed=12, dtype=dtype)
     f, g = pogs.graph.lasso_functions(b, 0.1, n)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype)
+    want_sh, _ = run_sharded_oracle(A.tocsr(), f, g, world, dtype)
     with pogs.Solver(A, dtype=dtype) as s:
         one = s.solve(f, g)
     res, bounds = run_row_sharded(pogs, A.tocsr(), f, g, world, dtype)
-    # fp32: 2e-5 on the same trajectory, tolerance-sized when the inexact CGLS projections (whose
-    # A^T products are summed in another order across shards) stop the solves a few iterations apart
-    d_it = abs(int(res[0]["iterations"]) - int(one["iterations"]))
-    tol = 1e-7 if dtype == np.float64 else (2e-5 if d_it == 0 else min(5e-4, 1e-4 * (1 + d_it)))
+    assert want["status"] == 0 and all(w["status"] == 0 for w in want_sh)
+
+    def tol_for(it_a, it_b):
+        # fp32: 2e-5 on the same trajectory, tolerance-sized when the inexact CGLS projections (whose
+        # A^T products are summed in another order across shards) stop the solves a few iterations apart
+        d_it = abs(int(it_a) - int(it_b))
+        return 1e-7 if dtype == np.float64 else (2e-5 if d_it == 0 else min(5e-4, 1e-4 * (1 + d_it)))
+
+    it_slack = 1 if dtype == np.float64 else 5
     for r, out in enumerate(res):
-        assert out["status"] == one["status"] == 0
-        assert abs(int(out["iterations"]) - int(one["iterations"])) <= (1 if dtype == np.float64 else 5)
-        assert relerr(out["x"], one["x"]) < tol
         lo, hi = bounds[r], bounds[r + 1]
+        assert out["status"] == 0
+        # the oracle, unsharded: the same tolerances as the unsharded engine tests of this file
+        tol = tol_for(out["iterations"], want["iterations"])
+        assert abs(int(out["iterations"]) - int(want["iterations"])) <= it_slack
+        assert relerr(out["x"], want["x"]) < tol
+        assert relerr(out["y"], want["y"][lo:hi]) < tol * 10
+        assert relerr(out["l"], want["l"][lo:hi]) < tol * 100
+        assert out["optval"] == pytest.approx(want["optval"], rel=max(tol, 1e-6 if dtype == np.float64 else 2e-4))
+        # the oracle's own row-sharded run, rank by rank
+        ws = want_sh[r]
+        tol = tol_for(out["iterations"], ws["iterations"])
+        assert abs(int(out["iterations"]) - int(ws["iterations"])) <= it_slack
+        assert relerr(out["x"], ws["x"]) < tol
+        assert relerr(out["y"], ws["y"]) < tol * 10
+        # and the unsharded engine
+        tol = tol_for(out["iterations"], one["iterations"])
+        assert abs(int(out["iterations"]) - int(one["iterations"])) <= it_slack
+        assert relerr(out["x"], one["x"]) < tol
         assert relerr(out["y"], one["y"][lo:hi]) < tol * 10
-        assert out["optval"] == pytest.approx(one["optval"], rel=max(tol, 1e-7))
     for out in res[1:]:
         assert out["iterations"] == res[0]["iterations"]
         assert np.array_equal(out["x"], res[0]["x"])
+
+
+@pytest.mark.parametrize("mode", ["host", "cg_h"])
+def test_row_sharded_sparse_other_transport_and_loop(monkeypatch, mode):
+    """The same sharded solve with the host-staged form of the test transport (stream order then plays
+    no role: a difference from the stream-ordered run would be an ordering bug) and with round 2's
+    host-polled CG loop (POGS_AMD_CG=h, also what the plain-CSR fallback runs): same solution."""
+    pogs = _pogs()
+    from helpers import run_row_sharded
+    from pogs_amd import synth
+
+    m, n = 4001, 900
+    A, b, _ = synth.csr_lasso(m, n, 15, seed=12, dtype=np.float64)
+    f, g = pogs.graph.lasso_functions(b, 0.1, n)
+    base, _ = run_row_sharded(pogs, A.tocsr(), f, g, 2, np.float64)
+    if mode == "host":
+        monkeypatch.setenv("POGS_AMD_TEST_TRANSPORT", "host")
+        other, _ = run_row_sharded(pogs, A.tocsr(), f, g, 2, np.float64, transport="host")
+        assert other[0]["iterations"] == base[0]["iterations"]
+        assert np.array_equal(other[0]["x"], base[0]["x"])      # both sum in rank order: the same bits
+    else:
+        monkeypatch.setenv("POGS_AMD_CG", "h")
+        other, _ = run_row_sharded(pogs, A.tocsr(), f, g, 2, np.float64)
+        assert abs(int(other[0]["iterations"]) - int(base[0]["iterations"])) <= 1
+        assert relerr(other[0]["x"], base[0]["x"]) < 1e-7
 
 
 def test_sparse_one_rank_rccl_path():
