@@ -756,6 +756,171 @@ __global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_
       }
 }
 
+
+// The 256 x 256 tile with the two wavefronts of every SIMD HALF A PHASE APART.
+//
+// gram_f16p_kernel<2, 4, 4, 2> meets at one barrier per 32-row step, after which all eight
+// wavefronts first read their fragments from LDS (16 KB + 8 KB each: 192 KB per step, ~1500 LDS
+// cycles at 128 B/clk) and then all multiply (48 MFMAs of 32 cycles each, two wavefronts per SIMD:
+// ~3070 cycles): the matrix pipes idle while the LDS is read and the LDS idles while they run --
+// 1536 + 3072 = 4608 cycles per step is what round 3's counters show (MFMA busy 62 %), not the
+// 3072 the products need.  Here a phase is 16 image rows (half a step: 12 fragment reads, 24 MFMAs
+// per wavefront) in two parts with a raw s_barrier after each,
+//
+//     R: request the phase's fragments                      | barrier |
+//     M: issue this wavefront's copies for phase p + 3; wait for the fragments; 24 MFMAs | barrier |
+//
+// and the wavefronts of workgroup row 1 (wavefronts 4-7: the SECOND wavefront of each SIMD) run
+// the same program one barrier late (one extra barrier before their loop, one after for row 0 --
+// every wavefront executes the same number).  Between two barriers one wavefront of a SIMD is in M
+// and the other in R: fragment reads and DMA writes overlap the other wavefront's products
+// (cdna_hip_programming.md section 5, "8-phase template": the per-phase role split).
+//
+// LDS: a ring of four phase slots of 32 KB, [operand A/B][part h/l][8-row group 0..1][256] x 16 B.
+// Copies (global_load_lds, 4 one-KB lines per wavefront and phase) are issued three phases ahead
+// and waited for with a counted vmcnt, never 0 inside the loop:
+//   RAW  the fragments of phase p are read in R(p); every wavefront has waited for its lines of
+//        phase p in R(p - 1) (vmcnt(4): only phase p + 1's four lines may still be in flight) and
+//        has then passed a barrier that the reader passed too -- for the late row the barrier after
+//        its R(p - 1) is the one before the early row's R(p).
+//   WAR  phase p + 3 lands in the slot of phase p - 1, whose fragment reads were retired
+//        (lgkmcnt(0) at the head of M(p - 1)) before the barrier that precedes this M(p) -- for
+//        either row.
+constexpr int kGramSlots = 4;   // ring of 32 KB phase slots: copies run three phases ahead (five slots = all 160 KB of
+                                // LDS, four phases ahead, measured: 29.9 against 28.3 ms for the phase at C2, not faster)
+template <int N> __device__ __forceinline__ void gram_wait_lines() {
+  static_assert(N == 4 || N == 8 || N == 12, "counted vmcnt");
+  if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) gram_f16s_kernel(GramF16PArgs g) {
+  constexpr int TILE = 256, TA = 4, TB = 2, WN = 4;
+  constexpr int SLOTS = kGramSlots, AHEAD = kGramSlots - 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gram_lds[];
+  typedef f16x8 Slot[2][2][2][TILE];   // 32 KB
+  Slot *sh = reinterpret_cast<Slot *>(gram_lds);
+  const int tm = (g.N + TILE - 1) / TILE;
+  const int ntiles = tm * (tm + 1) / 2;
+  const int nunits = ntiles * g.nslabs;
+  const int per_xcd = (nunits + kNumXcd - 1) / kNumXcd;
+  const int unit = static_cast<int>(blockIdx.x % kNumXcd) * per_xcd + static_cast<int>(blockIdx.x / kNumXcd);
+  if (unit >= nunits || static_cast<int>(blockIdx.x / kNumXcd) >= per_xcd) return;
+  const int ks = unit / ntiles, tile = unit % ntiles;
+  int ti, tj;
+  if (g.tile_map) {
+    const int e = g.tile_map[tile];
+    ti = e >> 16;
+    tj = e & 0xffff;
+  } else {
+    ti = static_cast<int>((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > tile) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    tj = tile - ti * (ti + 1) / 2;
+  }
+  const int i0 = ti * TILE, j0 = tj * TILE;
+  float *Cout = g.C + static_cast<size_t>(ks) * g.slab_stride;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int late = wave / WN;   // workgroup row 1 = the second wavefront of each SIMD
+  const int wm = late * (TA * 32), wn = (wave % WN) * (TB * 32);
+  const int r32 = lane & 31, kh = lane >> 5;
+
+  floatx16 acc[TA][TB];
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nph = g.kchunk / 16;   // phases of this unit (kchunk is a multiple of 32: even)
+  const size_t kg0 = static_cast<size_t>(ks) * (g.kchunk / 8);
+  // this wavefront's four lines of a phase: line q = wave * 4 + j of [op][part][group][4 x 64 columns]
+  const f16x8 *src_line[4];
+  int dst_off[4];   // in f16x8 units inside a slot
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = wave * 4 + j;
+    const int cq = q % 4, kg = (q / 4) % 2, part = (q / 8) % 2, op = q / 16;
+    const f16x8 *img = reinterpret_cast<const f16x8 *>(part ? g.L : g.H);
+    src_line[j] = img + (kg0 + kg) * g.npad + (op ? j0 : i0) + cq * 64 + lane;
+    dst_off[j] = ((op * 2 + part) * 2 + kg) * TILE + cq * 64;
+  }
+  const size_t phase_stride = static_cast<size_t>(2) * g.npad;   // two 8-row groups per phase
+  auto issue = [&](int ph) {
+    f16x8 *slot = reinterpret_cast<f16x8 *>(&sh[ph % SLOTS]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_line[j] + phase_stride * ph),
+                                       (__attribute__((address_space(3))) void *)(slot + dst_off[j]), 16, 0, 0);
+  };
+
+  // (units are thousands of rows long: nph > AHEAD always; shorter ones would only wait longer)
+#pragma unroll
+  for (int q = 0; q < AHEAD; ++q)
+    if (q < nph) issue(q);
+  if (nph >= AHEAD) gram_wait_lines<4 * (AHEAD - 1)>();
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // phase 0 is in LDS for everybody
+  if (late) __builtin_amdgcn_s_barrier();       // the late row starts one barrier behind
+  for (int p = 0; p < nph; ++p) {
+    // ---- R: the phase's fragments (one register set: the previous phase's products are done)
+    f16x8 A[TA][2], B[TB][2];
+    {
+      const Slot &S = sh[p % SLOTS];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int b = 0; b < TB; ++b) B[b][q] = S[1][q][kh][wn + b * 32 + r32];
+#pragma unroll
+        for (int a = 0; a < TA; ++a) A[a][q] = S[0][q][kh][wm + a * 32 + r32];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);          // the reads are requested BEFORE the barrier
+    // my lines of phase p + 1 have landed (only those of phases p + 2 .. p + AHEAD - 1, four each, may still be in flight)
+    if (p + AHEAD - 1 < nph) gram_wait_lines<4 * (AHEAD - 2)>();
+    else if (AHEAD > 3 && p + 2 < nph) gram_wait_lines<4>();   // tail: fewer phases behind this one
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- M
+    if (p + AHEAD < nph && !(g.ablate & 2)) issue(p + AHEAD);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    if (!(g.ablate & 1))
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int b = 0; b < TB; ++b) {
+        floatx16 c = acc[a][b];   // small products first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][0], B[b][1], c, 0, 0, 0);   // h l
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][1], B[b][0], c, 0, 0, 0);   // l h
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][0], B[b][0], c, 0, 0, 0);   // h h
+        acc[a][b] = c;
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (!late) __builtin_amdgcn_s_barrier();      // same number of barriers for every wavefront
+  const float inv2 = 1.0f / (g.scale * g.scale);
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm + a * 32 + (r / 4) * 8 + kh * 4 + (r % 4);
+        const int col = j0 + wn + b * 32 + r32;
+        if (row < g.N && col < g.N) {
+          float *c = Cout + static_cast<size_t>(row) * g.ldc + col;
+          const float v = acc[a][b][r] * inv2;
+          *c = g.accumulate ? *c + v : v;
+        }
+      }
+}
+
 }  // namespace
 
 void launch_split_f16(const float *P, size_t ld, int K, int N, int k0, int krows, int npad, float scale, void *H,
@@ -778,8 +943,22 @@ static void launch_gram_f16p_cfg(const GramF16PArgs &g, hipStream_t s) {
   hipLaunchKernelGGL((gram_f16p_kernel<WM, WN, TA, TB>), dim3(grid), dim3(WM * WN * 64), kLds, s, g);
 }
 
+static void launch_gram_f16s(const GramF16PArgs &g, hipStream_t s) {
+  constexpr int TILE = 256;
+  const int tm = (g.N + TILE - 1) / TILE;
+  const int nunits = tm * (tm + 1) / 2 * g.nslabs;
+  if (nunits <= 0) return;
+  constexpr int kLds = kGramSlots * 2 * 2 * 2 * TILE * 16;   // phase slots of 32 KB
+  static SmemGrants grants;
+  ensure_dynamic_smem(reinterpret_cast<const void *>(gram_f16s_kernel), kLds, grants);
+  const int grid = (nunits + kNumXcd - 1) / kNumXcd * kNumXcd;
+  hipLaunchKernelGGL(gram_f16s_kernel, dim3(grid), dim3(512), kLds, s, g);
+}
+
 void launch_gram_f16p(const GramF16PArgs &g, hipStream_t s) {
-  if (g.tile == 256) launch_gram_f16p_cfg<2, 4, 4, 2>(g, s);
+  static const bool lockstep = [] { const char *e = std::getenv("POGS_AMD_GRAM_LOCKSTEP"); return e && e[0] == '1'; }();
+  if (g.tile == 256 && !lockstep) launch_gram_f16s(g, s);
+  else if (g.tile == 256) launch_gram_f16p_cfg<2, 4, 4, 2>(g, s);
   else launch_gram_f16p_cfg<2, 2, 2, 2>(g, s);
 }
 
