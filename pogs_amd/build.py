@@ -14,6 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(_HERE, "libpogs_amd.so")
+# The reference's Python layer looks for `libpogs_cpu.so` in its package directory
+# (python/pogs/graph.py:29-67).  The build leaves an alias of that name next to the library: copied (or
+# linked) into the reference's `pogs/` directory it is picked up by the UNMODIFIED loader
+# (INTEGRATION.md section 1).
+ALIAS = os.path.join(_HERE, "libpogs_cpu.so")
 SOURCES = ["abi.hip", "sparse.hip", "gemm.hip", "vec_kernels.hip", "dist.hip"]
 # dense_plan.hip is compiled once per arithmetic type and streaming shape (csrc/stream.h:
 # POGS_STREAM_PLANS) plus the windowed form -- one small code object per shape, see dense_plan.hip
@@ -67,10 +72,22 @@ def _compile(job):
     return obj
 
 
+def _alias():
+    try:
+        if os.path.islink(ALIAS) or os.path.exists(ALIAS):
+            if os.path.islink(ALIAS) and os.readlink(ALIAS) == os.path.basename(LIB):
+                return
+            os.remove(ALIAS)
+        os.symlink(os.path.basename(LIB), ALIAS)
+    except OSError:
+        pass   # a file system without symlinks: the alias is a convenience, not a dependency
+
+
 def build(force=False, verbose=False):
     """Compile (if stale) and return the path of libpogs_amd.so."""
     dep = _newest_dep()
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= dep:
+        _alias()
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     todo = []
@@ -96,6 +113,7 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    _alias()
     return LIB
 
 

@@ -108,6 +108,7 @@ int guarded(F &&fn, PogsAmdSolver *h = nullptr) {
   };
   try {
     g_last_error.clear();
+    if (h && h->impl) h->impl->on_entry();
     return fn();
   } catch (const std::exception &e) {
     return failed(e.what());

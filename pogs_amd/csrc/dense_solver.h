@@ -97,17 +97,16 @@ class DenseSolver final : public SolverBase {
     // object (once per process; ~2 ms now that there is one ~0.8 MB object per streaming shape).
     // On the first solver of a process (per arithmetic type) a helper thread asks for a kernel's
     // attributes right away, so that the load overlaps the stream creation and the upload of A:
-    // ~2 ms of the cold time to converge at C2 (0.1483 -> 0.1462 s).  POGS_AMD_PRELOAD=0 turns it off.
+    // ~2 ms of the cold time to converge at C2 (0.1483 -> 0.1462 s).
     struct Joiner {
       std::thread t;
       ~Joiner() { if (t.joinable()) t.join(); }
     } preload;
     {
-      const char *pe = std::getenv("POGS_AMD_PRELOAD");
       int dev = opt ? opt->device : -1;
       if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = -1;
       static std::atomic<bool> preloaded{false};
-      if (!(pe && pe[0] == '0') && dev >= 0 && !preloaded.exchange(true))
+      if (dev >= 0 && !preloaded.exchange(true))
         preload.t = std::thread([dev] {
           hipFuncAttributes fa;
           if (hipSetDevice(dev) != hipSuccess) return;
@@ -168,6 +167,7 @@ class DenseSolver final : public SolverBase {
 
   int dtype() const override { return sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64; }
   int device() const override { return ctx_.device; }
+  void on_entry() override { ctx_.on_entry(); }
   void on_error() override { ctx_.on_error(); }
   PogsAmdStats &stats() override { return ctx_.stats; }
 
@@ -515,14 +515,6 @@ class DenseSolver final : public SolverBase {
     }
   }
 
-  static bool w_onepass() {   // POGS_AMD_WPASS=2: the two triangular products W, U of the reference's two trsv
-    static const bool on = [] { const char *e = std::getenv("POGS_AMD_WPASS"); return !(e && e[0] == '2'); }();
-    return on;
-  }
-  static bool defer_allowed() {   // POGS_AMD_DEFER=0: one launch per sum, as on row shards
-    static const bool on = [] { const char *e = std::getenv("POGS_AMD_DEFER"); return !(e && e[0] == '0'); }();
-    return on;
-  }
   // Scalar sums of the one-pass iteration wait for its closing launch (single GPU); everywhere
   // else they run at once.
   void sum_now_or_later(const SumJob &j) {
@@ -570,8 +562,7 @@ class DenseSolver final : public SolverBase {
     const char *sk_env = std::getenv("POGS_AMD_SK_FULL");
     const bool sk_probe = !(sk_env && sk_env[0] == '1');
     double *mark = sk_probe ? ctx_.S.p + kSkMark : nullptr;
-    const char *sk_ulps = std::getenv("POGS_AMD_SK_ULPS");   // tuning aid
-    const T sk_tol = (sk_ulps ? std::atoi(sk_ulps) : (std::is_same<T, float>::value ? 16 : 64)) * std::numeric_limits<T>::epsilon();
+    const T sk_tol = (std::is_same<T, float>::value ? 16 : 64) * std::numeric_limits<T>::epsilon();
     double r_ref = 0, gamma = 0, gamma_prev = 0;
     bool extrapolate = false, was_uniform = false;
     // after pass k (0-based): true if it was a pure common-factor pass; keeps r_ref current
@@ -867,7 +858,6 @@ class DenseSolver final : public SolverBase {
       int ksplit = 1;
       while (ksplit < 32 && kdim / (ksplit * 2) >= 2048 && (kdim / ksplit > 6400 || tiles * ksplit < 16LL * ctx_.num_cu * 3))
         ksplit *= 2;
-      if (const char *ev = std::getenv("POGS_AMD_KSPLIT")) ksplit = std::max(1, std::atoi(ev));   // tuning aid
       GemmArgs<T> g{k_, k_, kdim, A_.p, lda_, A_.p, lda_, G, ld, static_cast<T>(1), static_cast<T>(0)};
       g.kchunk = ksplit > 1 ? static_cast<int>(round_up((kdim + ksplit - 1) / ksplit, 32)) : 0;
       g.csplit_stride = slab;
@@ -898,73 +888,51 @@ class DenseSolver final : public SolverBase {
         split16 = std::isfinite(scale16) && scale16 > 0;
       }
       if (split16) {
-        constexpr int kRows = 1024;
-        const int nchunks = (kdim + kRows - 1) / kRows;
-        const bool presplit = !(gsel && gsel[0] == 's');   // POGS_AMD_GRAM=s: split inside the product kernel
-        int nslabs_used = std::min(4, nchunks);
-        if (presplit) {
-          // four K ranges at a time are split into two fp16 images in operand order (168 MB at C2,
-          // 60 us), which the product kernel copies straight into LDS (gemm.h)
-          // four units per tile and launch into the four slabs; the K dimension is cut into equal units
-          // of at most ~12800 rows (C2: 2 launches x 4 units of 12512 rows): long units pay the
-          // accumulator read-add-write, the prologue and the first-copy latency less often, equal ones
-          // leave no mostly-empty unit at the end -- measured at C2, rows per unit -> Gram phase:
-          // 4096 -> 33.9 ms, 6272 -> 31.8, 8352 -> 31.4, 12512 -> 30.9, 25024 -> 31.0 (scripts/gram_urows_probe.sh)
-          constexpr int kUnitCap = 12800;
-          const int launches = (kdim + 4 * kUnitCap - 1) / (4 * kUnitCap);
-          int chains = 0;   // (env only)
-          // 256 x 256 workgroup tiles (half the operand bytes per product of the 128 tile; one
-          // accumulator set, i.e. a unit is ONE MFMA chain) where the Gram matrix
-          // has enough of them to fill the chip; measured at C2 31.8 against 33.9 ms of kernel time,
-          // no difference at n = 5000 (C3).  Chain length: 1024 .. 16384 rows give the same 106
-          // iterations at C2 and x within 6e-7 of each other (scripts/gram_chain_probe.py), the
-          // same distance the native fp32 product is at.
-          int tile = k_ >= 8192 ? 256 : 128;
-          if (const char *ev = std::getenv("POGS_AMD_GRAM_TILE")) tile = std::atoi(ev) == 256 ? 256 : 128;   // tuning aid
-          if (const char *ev = std::getenv("POGS_AMD_GRAM_CHAINS")) chains = std::max(1, std::min(16, std::atoi(ev)));
-          int urows = static_cast<int>(round_up(static_cast<size_t>((kdim + 4 * launches - 1) / (4 * launches)), 32));
-          if (chains > 0) urows = kRows * chains;
-          if (const char *ev = std::getenv("POGS_AMD_GRAM_UROWS")) urows = static_cast<int>(round_up(static_cast<size_t>(std::max(32, std::atoi(ev))), 32));   // tuning aid
-          const int nunits = (kdim + urows - 1) / urows;
-          const int npad = static_cast<int>(round_up(k_, tile));
-          DevBuf<unsigned char> img(static_cast<size_t>(2) * (4 * urows) * npad * 2);
-          unsigned char *H = img.p, *L = img.p + static_cast<size_t>(4 * urows) * npad * 2;
-          ctx_.tmark("  gram: images allocated");
-          GramF16PArgs gp{H, L, npad, k_, reinterpret_cast<float *>(G), ld, 4, urows, slab, 0, g.tile_map, scale16};
-          gp.tile = tile;
-          gp.flush_rows = kRows;
-          if (const char *ev = std::getenv("POGS_AMD_GRAM_ABLATE")) gp.ablate = std::atoi(ev);   // measurement aid
-          if (const char *ev = std::getenv("POGS_AMD_GRAM_FLUSH")) gp.flush_rows = std::max(0, std::atoi(ev));   // tuning aid: 0 = one chain per unit
-          DevBuf<int> tmap256;
-          if (tile == 256) {
-            gp.tile_map = nullptr;
-            if (k_ > 16 * 256) {
-              const std::vector<int> order = gram_tile_order(k_, 256);
-              tmap256.alloc(order.size());
-              POGS_HIP_CHECK(hipMemcpyAsync(tmap256.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, s));
-              ctx_.sync();   // order is a host temporary
-              gp.tile_map = tmap256.p;
-            }
-          }
-          for (int u0 = 0; u0 < nunits; u0 += 4) {
-            gp.nslabs = std::min(4, nunits - u0);
-            gp.accumulate = u0 > 0 ? 1 : 0;
-            launch_split_f16(reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, u0 * urows, gp.nslabs * urows, npad,
-                             scale16, H, L, s);
-            launch_gram_f16p(gp, s);
-          }
-          nslabs_used = std::min(4, nunits);
-          ctx_.sync();   // img is freed at scope exit
-        } else {
-          GramF16Args gb{reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, reinterpret_cast<float *>(G), ld, 4,
-                         kRows, 0, slab, 0, g.tile_map, scale16};
-          for (int c0 = 0; c0 < nchunks; c0 += 4) {
-            gb.ks0 = c0;
-            gb.nslabs = std::min(4, nchunks - c0);
-            gb.accumulate = c0 > 0 ? 1 : 0;
-            launch_gram_f16(gb, s);
+        // The K dimension is cut into equal units of at most ~12800 rows, four per launch into the
+        // four slabs (C2: 2 launches x 4 units of 12512 rows): long units pay the accumulator
+        // read-add-write, the prologue and the first-copy latency less often, equal ones leave no
+        // mostly-empty unit at the end.  The rows of a launch are first written as two fp16 images
+        // in operand order (launch_split_f16: 168 MB per 4096 rows at C2), which the product kernel
+        // copies straight into LDS (gemm.h).
+        // 256 x 256 workgroup tiles (half the operand bytes per product of the 128 tile; one
+        // accumulator set, i.e. a unit is ONE MFMA chain -- chains of 1024 .. 16384 rows give the same
+        // 106 iterations at C2 and x within 6e-7 of each other, the distance the native fp32 product
+        // is at) where the Gram matrix has enough of them to fill the chip; the 128 tile below, with
+        // 1024-row chains added to a second register set.  POGS_AMD_GRAM_TILE=128 forces the 128
+        // tile (regression sweep of tests/test_gpu_dense.py).
+        constexpr int kRows = 1024, kUnitCap = 12800;
+        const int launches = (kdim + 4 * kUnitCap - 1) / (4 * kUnitCap);
+        int tile = k_ >= 8192 ? 256 : 128;
+        if (const char *ev = std::getenv("POGS_AMD_GRAM_TILE")) tile = std::atoi(ev) == 256 ? 256 : 128;
+        const int urows = static_cast<int>(round_up(static_cast<size_t>((kdim + 4 * launches - 1) / (4 * launches)), 32));
+        const int nunits = (kdim + urows - 1) / urows;
+        const int npad = static_cast<int>(round_up(k_, tile));
+        DevBuf<unsigned char> img(static_cast<size_t>(2) * (4 * urows) * npad * 2);
+        unsigned char *H = img.p, *L = img.p + static_cast<size_t>(4 * urows) * npad * 2;
+        ctx_.tmark("  gram: images allocated");
+        GramF16PArgs gp{H, L, npad, k_, reinterpret_cast<float *>(G), ld, 4, urows, slab, 0, g.tile_map, scale16};
+        gp.tile = tile;
+        gp.flush_rows = kRows;
+        DevBuf<int> tmap256;
+        if (tile == 256) {
+          gp.tile_map = nullptr;
+          if (k_ > 16 * 256) {
+            const std::vector<int> order = gram_tile_order(k_, 256);
+            tmap256.alloc(order.size());
+            POGS_HIP_CHECK(hipMemcpyAsync(tmap256.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, s));
+            ctx_.sync();   // order is a host temporary
+            gp.tile_map = tmap256.p;
           }
         }
+        for (int u0 = 0; u0 < nunits; u0 += 4) {
+          gp.nslabs = std::min(4, nunits - u0);
+          gp.accumulate = u0 > 0 ? 1 : 0;
+          launch_split_f16(reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, u0 * urows, gp.nslabs * urows, npad,
+                           scale16, H, L, s);
+          launch_gram_f16p(gp, s);
+        }
+        const int nslabs_used = std::min(4, nunits);
+        ctx_.sync();   // img is freed at scope exit
         launch_sum_slabs<T>(G, slab, nslabs_used, G, ld, k_, s);
         ksplit = 0;   // skip the fp32 rounds below
         POGS_HIP_CHECK(hipMemsetAsync(G + slab, 0, 3 * slab * sizeof(T), s));
@@ -1279,11 +1247,8 @@ class DenseSolver final : public SolverBase {
       // (2) projection: x = (G + I)^{-1} (xtemp + A^T ytemp), y = A x   (projector_direct_dense.cpp:122-127)
       gemv_t_partials(ytemp_.p);
       finish_cols(StoreColOp<T>{1, 0, rhs_.p, n_}, nullptr, kGapY, 3);   // with shards: gap/norm sums ride along
-      if (w_onepass())
-        solve_gram_onepass(rhs_.p, xtemp_.p, ProjTailSumColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_},
-                           ctx_.S.p + kDXprev2);
-      else
-        solve_gram(rhs_.p, xtemp_.p, ProjTailOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p}, ctx_.S.p + kDXprev2);
+      solve_gram_onepass(rhs_.p, xtemp_.p, ProjTailSumColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_},
+                         ctx_.S.p + kDXprev2);
       StreamArgs<T> a = argsA();
       a.xin = x_[nw].p;
       ctx_.stream_timer.begin(s);
@@ -1295,13 +1260,9 @@ class DenseSolver final : public SolverBase {
     } else {
       // (2') m <= n: t = (A A^T + I)^{-1} (A xtemp - ytemp); x = xtemp - A^T t; y = ytemp + t   (:128-135)
       t_mul_n(xtemp_.p, nullptr, ResidOp<T>{ytemp_.p, rhs_.p}, nullptr);
-      if (w_onepass())
-        solve_gram_onepass(rhs_.p, static_cast<const T *>(nullptr),
-                           ProjTailAddColOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p, m_},
-                           ctx_.S.p + kDYprev2);
-      else
-        solve_gram(rhs_.p, static_cast<const T *>(nullptr),
-                   ProjTailAddOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p}, ctx_.S.p + kDYprev2);
+      solve_gram_onepass(rhs_.p, static_cast<const T *>(nullptr),
+                         ProjTailAddColOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p, m_},
+                         ctx_.S.p + kDYprev2);
       t_mul_t(tmpn_.p, ProjTailColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_}, ctx_.S.p + kDXprev2);
     }
     if (!use_cgls_) ctx_.stats.matvecs += 2;
@@ -1368,7 +1329,7 @@ class DenseSolver final : public SolverBase {
       bool &flag;
       DeferGuard(bool &f, bool on) : flag(f) { flag = on; }
       ~DeferGuard() { flag = false; }
-    } defer_guard(defer_sums_, defer_allowed());
+    } defer_guard(defer_sums_, true);
     const bool spec = spec_valid_;
     double *pre_part = ctx_.spart.p + sp_pre_off_;              // [by][3] y-half prox sums (non-speculated iterations)
     double *pc_part = pre_part + static_cast<size_t>(by) * 3;    // [gridC][4] pre_cols sums
@@ -1427,11 +1388,8 @@ class DenseSolver final : public SolverBase {
       sum_now_or_later(SumJob{pc_part, gridC, 1, ctx_.S.p + kExactS2, 4, 3});
     }
     // x = (G + I)^{-1} (xtemp + A^T yhat)
-    if (w_onepass())
-      solve_gram_onepass(rhs_.p, xtemp_.p, ProjTailSumColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_},
-                         ctx_.S.p + kDXprev2);
-    else
-      solve_gram(rhs_.p, xtemp_.p, ProjTailOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p}, ctx_.S.p + kDXprev2);
+    solve_gram_onepass(rhs_.p, xtemp_.p, ProjTailSumColOp<T>{x_[nw].p, x_[cur_].p, x12_.p, xtemp_.p, n_},
+                       ctx_.S.p + kDXprev2);
     // (D) the pass over A
     {
       StreamArgs2<T> a2{A_.p, lda_, m_, n_pad_, x_[nw].p, x12_.p, colpart_.p, colpart2_.p, ctx_.spart.p};
@@ -1558,12 +1516,8 @@ class DenseSolver final : public SolverBase {
       SumJob j{sp, reduce_cols_grid(scols_pad_, Vec16<T>::N), 1, ctx_.S.p + kExactR2};
       launch_sum_jobs(&j, 1, s);
     }
-    if (w_onepass())
-      solve_gram_onepass(rhs_.p, static_cast<const T *>(nullptr),
-                         ProjTailAddColOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p, m_}, ctx_.S.p + kDYprev2);
-    else
-      solve_gram(rhs_.p, static_cast<const T *>(nullptr),
-                 ProjTailAddOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p}, ctx_.S.p + kDYprev2);
+    solve_gram_onepass(rhs_.p, static_cast<const T *>(nullptr),
+                       ProjTailAddColOp<T>{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, tmpn_.p, m_}, ctx_.S.p + kDYprev2);
     // (D) the pass over T
     {
       StreamArgs2<T> a2{A_.p, lda_, srows_, scols_pad_, tmpn_.p, uvec_.p, colpart_.p, colpart2_.p, ctx_.spart.p};
@@ -1625,10 +1579,6 @@ class DenseSolver final : public SolverBase {
   // the reference's per-iteration line (pogs.cpp:382-388); every rank evaluates (the objective
   // sum is a collective on row shards), rank 0 prints
   void log_iteration(unsigned verbose) {
-    static const bool trace = std::getenv("POGS_AMD_ITERTRACE") != nullptr;   // debugging aid: every iteration, full precision
-    if (trace)
-      std::printf("T %5u rho %.9e r %.9e s %.9e gap %.9e epri %.9e edua %.9e\n", ctl_.k, (double)ctl_.rho, (double)ctl_.nrm_r,
-                  (double)ctl_.nrm_s, (double)ctl_.gap, (double)ctl_.eps_pri, (double)ctl_.eps_dua);
     if (!wants_iter_line(verbose, ctl_)) return;
     const double obj = eval_objective();
     if (ctx_.dist.rank() == 0) print_iter_line(ctl_, obj);

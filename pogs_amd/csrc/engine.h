@@ -133,8 +133,8 @@ struct PhaseTimer {
   }
 };
 
-// Streams and the host-mapped scalar mirror are recycled across solver handles of a process
-// (POGS_AMD_RECYCLE=0 turns that off): a one-shot solve creates and destroys a handle per
+// Streams and the host-mapped scalar mirror are recycled across solver handles of a process:
+// a one-shot solve creates and destroys a handle per
 // call, and stream / mapped-host churn costs milliseconds per call plus occasional
 // tens-of-milliseconds stalls inside the runtime.  Entries are never destroyed (a handful
 // of streams and 4 KB blocks per device for the life of the process).
@@ -145,11 +145,6 @@ struct CtxResources {
 };
 inline std::mutex &ctx_pool_mutex() { static std::mutex *m = new std::mutex; return *m; }
 inline std::vector<CtxResources> &ctx_pool() { static auto *v = new std::vector<CtxResources>; return *v; }
-inline bool ctx_recycle() {
-  static const bool on = [] { const char *e = std::getenv("POGS_AMD_RECYCLE"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
 struct Ctx {
   int device = 0;
   int num_cu = 256;
@@ -169,7 +164,7 @@ struct Ctx {
     hipDeviceProp_t prop;
     POGS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (ctx_recycle()) {
+    {
       std::lock_guard<std::mutex> lock(ctx_pool_mutex());
       auto &pool = ctx_pool();
       for (size_t i = 0; i < pool.size(); ++i)
@@ -192,10 +187,9 @@ struct Ctx {
     pub_counter.zero(stream);
     std::memset(S_host.p, 0, (kNumSlots + 1) * sizeof(double));
     {
-      const char *fe = std::getenv("POGS_AMD_FETCH");
-      poll_fetch = !(fe && fe[0] == 'm');
       void *dp = nullptr;
-      if (poll_fetch && hipHostGetDevicePointer(&dp, S_host.p, 0) == hipSuccess && dp) S_host_dev = static_cast<double *>(dp);
+      poll_fetch = true;
+      if (hipHostGetDevicePointer(&dp, S_host.p, 0) == hipSuccess && dp) S_host_dev = static_cast<double *>(dp);
       else poll_fetch = false;
     }
     std::memset(&stats, 0, sizeof(stats));
@@ -212,8 +206,8 @@ struct Ctx {
   // Brings the scalar block to the host and waits for everything enqueued so far.  Default: a
   // one-wave kernel writes the block into the host-mapped mirror and then a sequence word the
   // host polls (the stream is in order, so seeing the word means all earlier work is done);
-  // that saves the copy-engine round trip and the synchronize call of the plain path
-  // (POGS_AMD_FETCH=memcpy), which is also the fallback if the poll sees no progress.
+  // that saves the copy-engine round trip and the synchronize call of the plain copy, which is
+  // the fallback if the mirror has no device address or the poll sees no progress.
   // Deferred scalar sums: jobs queued here run in the launch that publishes the scalar block
   // (sum_publish_kernel), so an iteration ends with one small launch instead of one per sum plus
   // the publish.  Whoever queues a job keeps its partials untouched until the next fetch.
@@ -336,8 +330,13 @@ struct Ctx {
   // an exception escaped a solve on this context: with row shards the peers are (or will be) inside
   // a collective this rank no longer takes part in -- abort the communicator so that they fail too,
   // and never hand this stream to another solver
+  // Only when a collective of the failing call was (or may have been) enqueued: an argument or state
+  // check that throws before any exchange leaves the peers nothing to wait for, and must not cost the
+  // handle (and theirs) its communicator.
+  unsigned long long coll_mark = 0;
+  void on_entry() { coll_mark = dist.collectives(); }
   void on_error() {
-    if (dist.active()) {
+    if (dist.active() && dist.collectives() != coll_mark) {
       dist.abort();
       poisoned = true;
     }
@@ -348,7 +347,7 @@ struct Ctx {
     // a stream that faulted (or was left inside a failed collective) must not be handed to the
     // next solver: recycle it only if it drains cleanly
     const bool healthy = !poisoned && hipStreamSynchronize(stream) == hipSuccess;
-    if (ctx_recycle() && healthy) {
+    if (healthy) {
       std::lock_guard<std::mutex> lock(ctx_pool_mutex());
       CtxResources r;
       r.stream = stream;
@@ -616,7 +615,9 @@ struct SolverBase {
   virtual void project(const void *x0, const void *y0, double tol, void *x, void *y) = 0;
   virtual void mul(char trans, double alpha, const void *x, double beta, void *y) = 0;
   virtual PogsAmdStats &stats() = 0;
-  // an exception left one of the entry points: see guarded() in abi.hip
+  // guarded() in abi.hip: on_entry() when an entry point starts working on the handle, on_error()
+  // when an exception leaves it
+  virtual void on_entry() {}
   virtual void on_error() {}
 };
 

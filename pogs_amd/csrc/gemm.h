@@ -47,36 +47,23 @@ struct GemmArgs {
   int ktri = 0;
 };
 
-// G += / = P^T P (lower 128 x 128 tiles) for a K-major fp32 operand P (K rows of N, leading
-// dimension ld) on the fp16 matrix cores at fp32 accuracy: gfx950 has no reduced-precision fast
-// path for fp32 inputs, but a scaled operand a s (s a power of two that puts the largest entry
-// near 2^14) splits into two fp16 numbers h + l with 22 significant bits, and the three products
-// hh, hl, lh carry everything above 2^-22 relative -- accumulated in fp32 by
-// v_mfma_f32_32x32x16_f16 and unscaled by 1 / s^2.  The MFMA accumulate truncates, so a chain
-// drifts in proportion to its length: a unit covers `kchunk` (<= ~1024) rows and adds into its
-// slab tile (accumulate) -- short chains joined by IEEE adds come out more exact than a
-// sequential fp32 sum.  Slab ks of this launch takes rows [(ks0 + ks) kchunk, (ks0 + ks + 1) kchunk).
-struct GramF16Args {
-  const float *P; size_t ld; int K, N;
-  float *C; size_t ldc;           // slab 0 of this launch
-  int nslabs, kchunk, ks0; size_t slab_stride;
-  int accumulate;                 // 0: C = product, 1: C += product
-  const int *tile_map;            // optional, see gram_tile_order
-  float scale;                    // power of two; scale * max|P| must stay below 65504
-};
-void launch_gram_f16(const GramF16Args &g, hipStream_t s);
 // Asks the runtime for a kernel of gemm.hip, which makes it load that code object (helper thread
 // of DenseSolver's constructor).
 void preload_gemm_code();
 
-// The same product from operands split ahead of time.  launch_split_f16 writes rows
-// [k0, k0 + krows) of P (zeros past K, zeros in columns [N, npad)) as two fp16 images H and L in
-// MFMA-operand order: [k / 8][npad][8], i.e. 16 bytes = eight consecutive k of one column, columns
-// contiguous -- a wavefront's async global->LDS copy of 64 columns is one 1 KB line and lands in
-// LDS exactly as the matrix cores read it.  launch_gram_f16p then only copies (no staging
-// registers, no LDS stores, no conversion) and multiplies.  npad: a multiple of 128; krows: a
-// multiple of 32; unit u of the launch covers image rows [u kchunk, (u + 1) kchunk), kchunk a
-// multiple of 32 (and of flush_rows), and goes to slab u.
+// G += / = P^T P (lower tiles) for a K-major fp32 operand P (K rows of N, leading dimension ld) on
+// the fp16 matrix cores at fp32 accuracy: gfx950 has no reduced-precision fast path for fp32
+// inputs, but a scaled operand a s (s a power of two that puts the largest entry near 2^14) splits
+// into two fp16 numbers h + l with 22 significant bits, and the three products hh, hl, lh carry
+// everything above 2^-22 relative -- accumulated in fp32 by v_mfma_f32_32x32x16_f16 and unscaled
+// by 1 / s^2.
+// launch_split_f16 writes rows [k0, k0 + krows) of P (zeros past K, zeros in columns [N, npad)) as
+// two fp16 images H and L in MFMA-operand order: [k / 8][npad][8], i.e. 16 bytes = eight
+// consecutive k of one column, columns contiguous -- a wavefront's async global->LDS copy of 64
+// columns is one 1 KB line and lands in LDS exactly as the matrix cores read it.  launch_gram_f16p
+// then only copies (no staging registers, no LDS stores, no conversion) and multiplies.  npad: a
+// multiple of the tile; krows: a multiple of 32; unit u of the launch covers image rows
+// [u kchunk, (u + 1) kchunk), kchunk a multiple of 32 (and of flush_rows), and goes to slab u.
 void launch_split_f16(const float *P, size_t ld, int K, int N, int k0, int krows, int npad, float scale,
                       void *H, void *L, hipStream_t s);
 struct GramF16PArgs {
@@ -88,7 +75,6 @@ struct GramF16PArgs {
   float scale;
   int tile = 128;                 // workgroup tile: 128 (4 waves) or 256 (8 waves); tile_map must match
   int flush_rows = 0;             // 128 tile: rows per MFMA chain inside a unit (0: the whole kchunk)
-  int ablate = 0;                 // measurement aid: 1 = no MFMAs, 2 = no global->LDS copies (results are garbage)
 };
 void launch_gram_f16p(const GramF16PArgs &g, hipStream_t s);
 

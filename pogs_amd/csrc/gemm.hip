@@ -445,144 +445,6 @@ __device__ __forceinline__ void split8_f16(const float (&v)[8], float sc, f16x8 
   }
 }
 
-constexpr int GBK = 16;   // rows per k-tile: one 32x32x16 MFMA step
-
-// 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles of 32 x 32.  Thread t stages column t & 127,
-// k-group t >> 7 (8 consecutive rows): 8 coalesced dword loads per operand panel, split in
-// registers, two 16-byte LDS stores in operand order [part][k / 8][column].  Four workgroups
-// per CU (128 VGPRs, 32 KB of LDS each): the loop is not software-pipelined beyond one
-// register stage, the resident waves hide the rest.
-__global__ void __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2))) gram_f16_kernel(GramF16Args g) {
-  __shared__ __attribute__((aligned(16))) f16x8 sh[2][2][2][2][BM];
-  const int tm = (g.N + BM - 1) / BM;
-  const int ntiles = tm * (tm + 1) / 2;
-  const int nunits = ntiles * g.nslabs;
-  const int per_xcd = (nunits + kNumXcd - 1) / kNumXcd;
-  const int unit = static_cast<int>(blockIdx.x % kNumXcd) * per_xcd + static_cast<int>(blockIdx.x / kNumXcd);
-  if (unit >= nunits || static_cast<int>(blockIdx.x / kNumXcd) >= per_xcd) return;
-  const int ks = unit / ntiles, tile = unit % ntiles;
-  int ti, tj;
-  if (g.tile_map) {
-    const int e = g.tile_map[tile];
-    ti = e >> 16;
-    tj = e & 0xffff;
-  } else {
-    ti = static_cast<int>((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
-    while (ti * (ti + 1) / 2 > tile) --ti;
-    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-    tj = tile - ti * (ti + 1) / 2;
-  }
-  const int i0 = ti * BM, j0 = tj * BM;
-  const int kbeg = (g.ks0 + ks) * g.kchunk;
-  const int kend = min(g.K, kbeg + g.kchunk);
-  float *Cout = g.C + static_cast<size_t>(ks) * g.slab_stride;
-  const bool diag = ti == tj;
-
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int li = t & 127, lk8 = t >> 7;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int r32 = lane & 31, kh = lane >> 5;
-
-  floatx16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  // Two register stages, both in flight: a step first splits and stores the panel of k-tile
-  // i + 1 (requested two steps ago), re-issues the freed registers for tile i + 3, and then
-  // multiplies tile i -- so every load has two full steps to land.  Loads are unconditional
-  // (clamped addresses, no branches around them): columns past N only feed outputs that are never
-  // stored, and rows past kend exist in the last tile only.
-  float ra[2][8], rb[2][8];
-  // Buffer loads: one descriptor over this unit's K range (base and size are scalars), the
-  // column as the 32-bit lane offset, the row as a scalar offset -- no 64-bit lane addresses, and
-  // rows past kend fall outside the descriptor and read as zero.
-  const int voff_a = min(i0 + li, g.N - 1) * 4, voff_b = min(j0 + li, g.N - 1) * 4;
-  const int lk8u = __builtin_amdgcn_readfirstlane(lk8);   // wave-uniform: row offsets stay scalar
-  const unsigned row_bytes = static_cast<unsigned>(g.ld) * 4u;
-  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(g.P + static_cast<size_t>(kbeg) * g.ld), 0,
-      static_cast<int>(static_cast<unsigned>(kend - kbeg) * row_bytes), 0x00020000);
-  auto gload = [&](float (&va)[8], float (&vb)[8], int k0) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int soff = static_cast<int>(static_cast<unsigned>(k0 - kbeg + lk8u * 8 + q) * row_bytes);
-      va[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_a, soff, 0));
-      vb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_b, soff, 0));
-    }
-  };
-  auto lstore = [&](int st, const float (&va)[8], const float (&vb)[8]) {
-    f16x8 h, l;
-    split8_f16(va, g.scale, h, l);
-    sh[st][0][0][lk8][li] = h; sh[st][0][1][lk8][li] = l;
-    split8_f16(vb, g.scale, h, l);   // diagonal tiles stage the same panel twice: 1 tile in 40, no branch
-    sh[st][1][0][lk8][li] = h; sh[st][1][1][lk8][li] = l;
-  };
-  constexpr int bop = 1;
-  auto compute = [&](int st) {
-    f16x8 A[2][2], B[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        A[a][p] = sh[st][0][p][kh][wm + a * 32 + r32];
-        B[a][p] = sh[st][bop][p][kh][wn + a * 32 + r32];
-      }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        floatx16 c = acc[a][b];   // small products first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][0], B[b][1], c, 0, 0, 0);   // h l
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][1], B[b][0], c, 0, 0, 0);   // l h
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][0], B[b][0], c, 0, 0, 0);   // h h
-        acc[a][b] = c;
-      }
-  };
-  const int nk = (kend - kbeg + GBK - 1) / GBK;
-  if (nk > 0) {
-    // tiles past the end load as zero (k >= kend in the masked branch)
-    gload(ra[0], rb[0], kbeg);
-    lstore(0, ra[0], rb[0]);
-    gload(ra[0], rb[0], kbeg + GBK);
-    gload(ra[1], rb[1], kbeg + 2 * GBK);
-    __syncthreads();
-#define POGS_GRAM_STEP(J)                                          \
-    if (kt + (J) >= nk) break;                                     \
-    lstore(((J) + 1) & 1, ra[(J) & 1], rb[(J) & 1]);               \
-    gload(ra[(J) & 1], rb[(J) & 1], kbeg + (kt + (J) + 3) * GBK);  \
-    compute((J) & 1);                                              \
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-      POGS_GRAM_STEP(0)
-      POGS_GRAM_STEP(1)
-    }
-#undef POGS_GRAM_STEP
-  }
-  const float inv2 = 1.0f / (g.scale * g.scale);
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i0 + wm + a * 32 + (r / 4) * 8 + kh * 4 + (r % 4);
-        const int col = j0 + wn + b * 32 + r32;
-        if (row < g.N && col < g.N) {
-          float *c = Cout + static_cast<size_t>(row) * g.ldc + col;
-          const float v = acc[a][b][r] * inv2;
-          *c = g.accumulate ? *c + v : v;
-        }
-      }
-}
-
-}  // namespace
-
-namespace {
-
 constexpr int PBK = 32;   // image rows per step of the pre-split kernel: four 8-row groups, two MFMA k-steps
 
 __global__ void __launch_bounds__(256) split_f16_kernel(const float *P, size_t ld, int K, int N, int k0, int npad,
@@ -716,8 +578,8 @@ __global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_
     // the stage about to be refilled has been read by all
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (i + 1 < nsteps && !(g.ablate & 2)) issue((i + 1) & 1, i + 1);
-    if (!(g.ablate & 1)) compute(i & 1);
+    if (i + 1 < nsteps) issue((i + 1) & 1, i + 1);
+    compute(i & 1);
     if (TWO && --until_flush == 0) {
       until_flush = fsteps;
 #pragma unroll
@@ -885,10 +747,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) g
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // ---- M
-    if (p + AHEAD < nph && !(g.ablate & 2)) issue(p + AHEAD);
+    if (p + AHEAD < nph) issue(p + AHEAD);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    if (!(g.ablate & 1))
 #pragma unroll
     for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -956,23 +817,13 @@ static void launch_gram_f16s(const GramF16PArgs &g, hipStream_t s) {
 }
 
 void launch_gram_f16p(const GramF16PArgs &g, hipStream_t s) {
-  static const bool lockstep = [] { const char *e = std::getenv("POGS_AMD_GRAM_LOCKSTEP"); return e && e[0] == '1'; }();
-  if (g.tile == 256 && !lockstep) launch_gram_f16s(g, s);
-  else if (g.tile == 256) launch_gram_f16p_cfg<2, 4, 4, 2>(g, s);
+  if (g.tile == 256) launch_gram_f16s(g, s);
   else launch_gram_f16p_cfg<2, 2, 2, 2>(g, s);
 }
 
 void preload_gemm_code() {
   hipFuncAttributes fa;
   (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(split_f16_kernel));
-}
-
-void launch_gram_f16(const GramF16Args &g, hipStream_t s) {
-  const int tm = (g.N + BM - 1) / BM;
-  const int nunits = tm * (tm + 1) / 2 * g.nslabs;
-  if (nunits <= 0) return;
-  const int grid = (nunits + kNumXcd - 1) / kNumXcd * kNumXcd;
-  hipLaunchKernelGGL(gram_f16_kernel, dim3(grid), dim3(GT), 0, s, g);
 }
 
 std::vector<int> gram_tile_order(int n, int tile) {

@@ -575,6 +575,7 @@ class SparseSolver final : public SolverBase {
 
   int dtype() const override { return sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64; }
   int device() const override { return ctx_.device; }
+  void on_entry() override { ctx_.on_entry(); }
   void on_error() override { ctx_.on_error(); }
   PogsAmdStats &stats() override { return ctx_.stats; }
 
@@ -800,7 +801,7 @@ class SparseSolver final : public SolverBase {
     //   mostly hit L2)  +  partial sums rr * 8 (written, then read by reduce_parts) when there are groups.
     // Candidates are built to fill k rounds of ~250 workgroups exactly: for g groups, nrr = k * 250 / g
     // row ranges of rows / nrr rows each (shorter than the LDS limit).  Calibrated on C4 (forced
-    // configurations, scripts/sell_cfg_probe.sh: 8128 rows x 1 group +1.9 %, 12288 x 3 +9 %, A^T 8064 x 4
+    // configurations (round 2, forced through tuning switches since removed): 8128 rows x 1 group +1.9 %, 12288 x 3 +9 %, A^T 8064 x 4
     // +4 %, 16384 x 16 +3 % against the 16384 x 2 / x 8 the rule above picks there); a candidate replaces
     // that choice only when the model sees more than 5 % in it -- matrices whose row count leaves the
     // LDS-limit height with many groups (1.4e6 rows: 14 groups, 1204 workgroups; 4157 GB/s).
@@ -824,13 +825,6 @@ class SparseSolver final : public SolverBase {
           const double c = path_bytes(rr, g);
           if (c < best_c * (1 - 1e-3)) { best_c = c; rr_rows = rr; ncg = g; }
         }
-    }
-    {   // tuning aids: POGS_AMD_SELL_RR_TALL / _NCG_TALL for the copy with more rows than columns, _WIDE for the other
-      const bool tall = M.nrows >= M.ncols;
-      if (const char *ev = std::getenv(tall ? "POGS_AMD_SELL_RR_TALL" : "POGS_AMD_SELL_RR_WIDE"))
-        rr_rows = std::min(RRMAX, static_cast<int>(round_up(static_cast<size_t>(std::max(64, std::atoi(ev))), 64)));
-      if (const char *ev = std::getenv(tall ? "POGS_AMD_SELL_NCG_TALL" : "POGS_AMD_SELL_NCG_WIDE"))
-        ncg = std::max(1, std::min(ncb, std::atoi(ev)));
     }
     const int nrr = (M.nrows + rr_rows - 1) / rr_rows;
     const long long ntiles = static_cast<long long>(nrr) * ncb;

@@ -447,14 +447,6 @@ __global__ void __launch_bounds__(TPB) stream_tri_kernel(StreamArgs<T> a, Op op)
     }
   }
 }
-inline bool tri_phases_enabled() {   // POGS_AMD_TRI_PHASES=0: the plain row-streaming kernel on triangles too
-  static const bool on = [] {
-    const char *e = std::getenv("POGS_AMD_TRI_PHASES");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-
 // (Measured and not kept: one row per step for the dot + column-sum form at 256 x 10 -- 154 VGPRs,
 // three workgroups per CU.  The triangular W sweep stayed at 40.7 us, the full passes got slower
 // (Sinkhorn-Knopp pass 614 -> 653 us) and the second stage had 50 % more partials to add.)
@@ -526,7 +518,7 @@ void launch_stream_plain(const StreamPlan &p, const StreamArgs<T> &a, const Op &
       constexpr int R_ = RowsPerStep<DOT, ACC, TPB_>::value;                                    \
       /* (1024, 8): 128 VGPRs per thread -- the phased kernel spills 26-45 of them, the plain one 17-21 */ \
       if constexpr (DOT && ACC && !SQ && TRI == kLower && !(TPB_ == 1024 && NV_ == 8)) {        \
-        if (a.col0 == 0 && tri_phases_enabled()) {                                              \
+        if (a.col0 == 0) {                                              \
           hipLaunchKernelGGL((stream_tri_kernel<T, TPB_, NV_, R_, Op>), dim3(grid), dim3(TPB_), 0, s, a, op); \
           return;                                                                               \
         }                                                                                       \

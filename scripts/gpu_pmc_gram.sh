@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmc_gram_$tag
 rm -rf $O; mkdir -p $O
-for c in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+for c in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
   n=$(echo $c | tr " " "_")
   env "$@" rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$n -o g -- python $R/scripts/quick_c2.py > $O/$n.log 2>&1
 done

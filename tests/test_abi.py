@@ -123,3 +123,15 @@ def test_header_is_plain_c_and_a_c_caller_links(tmp_path):
     r = subprocess.run(["ldd", exe], capture_output=True, text=True)
     assert "libpogs_amd.so" in r.stdout
     assert subprocess.run([exe], capture_output=True).returncode == 2      # usage error, before any GPU call
+
+
+def test_the_build_leaves_a_libpogs_cpu_alias_the_reference_loader_finds():
+    """python/pogs/graph.py:29-67 looks for `libpogs_cpu.so` in its package directory: the build leaves
+    that name next to libpogs_amd.so (pogs_amd/build.py), and what it points to exports the four
+    graph-form entry points the reference's bindings declare (graph.py:167-233)."""
+    alias = os.path.join(ROOT, "pogs_amd", "libpogs_cpu.so")
+    assert os.path.exists(alias), "pogs_amd/build.py did not create the alias"
+    assert os.path.samefile(alias, os.path.join(ROOT, "pogs_amd", "libpogs_amd.so"))
+    lib = ctypes.CDLL(alias)
+    for sym in ("PogsD", "PogsS", "PogsSparseD", "PogsSparseS"):
+        getattr(lib, sym)

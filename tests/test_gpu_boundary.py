@@ -255,3 +255,59 @@ def test_cvxpy_front_end_runs_the_engine():
             assert np.all(x >= -1e-9)
     want = pogs.solve_lasso(A, b, 0.15, abs_tol=1e-6, rel_tol=1e-6)
     assert np.array_equal(cases["lasso"].variables()[0].value, want["x"])
+
+
+_REF_LOADER_SCRIPT = r"""
+# What python/pogs/graph.py does, restated: find `libpogs_cpu.so` next to the package file
+# (graph.py:29-67, first candidate), CDLL it, declare PogsD as graph.py:167-198 does, and make the call
+# of graph.py:352-381 -- nothing of this repository is imported.
+import ctypes, json, os, sys
+import numpy as np
+pkg_dir = sys.argv[1]
+path = os.path.join(pkg_dir, "libpogs_cpu.so")
+assert os.path.exists(path)
+lib = ctypes.CDLL(path)
+D = ctypes.POINTER(ctypes.c_double); I = ctypes.POINTER(ctypes.c_int)
+lib.PogsD.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, D] + [D] * 5 + [I] + [D] * 5 + [I] + [
+    ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
+    D, D, D, D, ctypes.POINTER(ctypes.c_uint)]
+lib.PogsD.restype = ctypes.c_int
+np.random.seed(0)                                   # README.md:55-59 (C1)
+A = np.ascontiguousarray(np.random.randn(500, 300)); b = np.random.randn(500); lam = 0.1
+m, n = A.shape
+def arr(v, k): return np.full(k, v, np.float64)
+f = [arr(1, m), b.copy(), arr(1, m), arr(0, m), arr(0, m)]; fh = np.full(m, 14, np.int32)   # kSquare (graph.py:428)
+g = [arr(1, n), arr(0, n), arr(lam, n), arr(0, n), arr(0, n)]; gh = np.full(n, 0, np.int32)  # kAbs    (graph.py:431)
+x = np.zeros(n); y = np.zeros(m); l = np.zeros(m); ov = ctypes.c_double(); it = ctypes.c_uint()
+p = lambda a: a.ctypes.data_as(D)
+st = lib.PogsD(1, m, n, p(A), *[p(a) for a in f], fh.ctypes.data_as(I), *[p(a) for a in g], gh.ctypes.data_as(I),
+               1.0, 1e-4, 1e-4, 2500, 0, 1, 1, p(x), p(y), p(l), ctypes.byref(ov), ctypes.byref(it))
+print(json.dumps(dict(status=st, iterations=it.value, optval=ov.value, x=x.tolist())))
+"""
+
+
+def test_the_reference_loader_restated_picks_up_the_alias_and_solves_c1(tmp_path):
+    """A `pogs/` package directory that holds nothing but the alias `libpogs_cpu.so`: the reference's
+    loader logic (restated, no import of this repository) finds it, binds PogsD with the reference's
+    own argtypes and gets configs[0]'s golden answer -- status 0, 100 iterations, optval
+    91.76711931681265 (tests/golden/reference_outputs.npz)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    pkg = tmp_path / "pogs"
+    pkg.mkdir()
+    os.symlink(os.path.join(ROOT, "pogs_amd", "libpogs_cpu.so"), pkg / "libpogs_cpu.so")
+    script = tmp_path / "caller.py"
+    script.write_text(_REF_LOADER_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, str(script), str(pkg)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["status"] == 0 and out["iterations"] + 1 == 100
+    assert out["optval"] == pytest.approx(91.76711931681265, rel=1e-9)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "reference_outputs.npz"))
+    assert out["iterations"] == int(gold["c1_f64_iterations"]) and out["status"] == int(gold["c1_f64_status"])
+    assert relerr(np.array(out["x"]), gold["c1_f64_x"]) < 1e-9

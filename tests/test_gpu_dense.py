@@ -894,7 +894,7 @@ def test_degenerate_inputs_fp32_with_equilibration_shortcut():
             assert abs(obj(got["x"]) - obj(want["x"])) <= otol * abs(obj(want["x"])), tag
     # The sixteen-decade case runs ~770 iterations with the fp32 dual residual bound (a norm of
     # DIFFERENCES of successive iterates, known to 1e-4 .. 2e-3 relative in fp32: measured per iteration
-    # for this engine's two iteration paths against the oracle, scripts/dbg_iter_trace.py) sitting
+    # for this engine's two iteration paths against the oracle in round 2, profiles/NOTES_r01_r03.md) sitting
     # within 0.3 % of the adaptive-rho threshold xi * eps_dua around iteration 630.  Whether that one
     # comparison fires is decided by rounding: the one-pass iteration takes the rho update there, the
     # three-pass one (POGS_AMD_FUSED=0), the oracle and the reference do not; until then all four agree

@@ -42,7 +42,8 @@ lo, hi = int(bounds[rank]), int(bounds[rank + 1])
 with pogs_amd.Solver(A[lo:hi], dtype=dtype, device=int(os.environ["LOCAL_RANK"]), dist=(rank, world, m, uid)) as s:
     r = s.solve(f.slice(lo, hi), g)
     coll = s.stats().get("collectives")
-out = dict(rank=rank, status=int(r["status"]), iterations=int(r["iterations"]), optval=float(r["optval"]),
+    comm = s.stats().get("comm_nranks")
+out = dict(comm_nranks=comm, rank=rank, status=int(r["status"]), iterations=int(r["iterations"]), optval=float(r["optval"]),
            x=r["x"].astype(np.float64).tolist(), lo=lo, hi=hi, y=r["y"].astype(np.float64).tolist(), collectives=coll)
 if rank == 0:
     with pogs_amd.Solver(A, dtype=dtype, device=0) as s:
@@ -83,6 +84,27 @@ def test_two_rank_rccl_matches_single_rank(tmp_path, kind, dtype):
     res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
     one = res[0]["one"]
     tol = 1e-9 if dtype == "float64" else 2e-4
+    # the communicator really has two ranks (ncclCommCount), and the result is the ORACLE's -- the CPU
+    # restatement pinned to the compiled reference -- not only the unsharded engine's
+    assert all(r["comm_nranks"] == 2 for r in res), [r["comm_nranks"] for r in res]
+    import oracle_binding as ob
+    from helpers import soa
+    from pogs_amd import graph as G
+    from pogs_amd import synth
+
+    npdt = np.dtype(dtype).type
+    if kind == "dense":
+        A, b, _ = synth.dense_lasso(4001, 300, seed=5, dtype=npdt)
+    else:
+        A, b, _ = synth.csr_lasso(6000, 900, 12, seed=5, dtype=npdt)
+    f, g = G.lasso_functions(b, 0.1, A.shape[1])
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=npdt)
+    assert want["status"] == 0
+    otol = 1e-6 if dtype == "float64" else 2e-4
+    for r in res:
+        xw = np.asarray(want["x"], np.float64)
+        assert np.linalg.norm(np.array(r["x"]) - xw) <= otol * np.linalg.norm(xw)
+        assert abs(r["iterations"] - int(want["iterations"])) <= max(3, int(want["iterations"]) // 10)
     assert res[0]["iterations"] == res[1]["iterations"]
     assert res[0]["x"] == res[1]["x"]          # replicated state took identical decisions
     for r in res:
