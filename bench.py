@@ -364,6 +364,39 @@ def pmc_traffic(name, kernel_substr):
         return None, None, None
 
 
+def unsharded_parity(cfg, m, n, world, dev, local, res, shard_b_sums):
+    """Rank 0, after the timed region of an N > 1 run: regenerates every rank's rows (torch_rows with the
+    ranks' seeds, on this device), checks them against the sums of b the ranks reported, solves the whole
+    (m world) x n problem UNSHARDED on this GPU and holds the row-sharded result `res` against it."""
+    import numpy as np
+    import torch
+
+    import pogs_amd
+    from pogs_amd import graph as G
+
+    np_dtype = np.float64 if cfg["dtype"] == "f64" else np.float32
+    A_all = torch.empty((m * world, n), dtype=torch.float64 if cfg["dtype"] == "f64" else torch.float32, device=dev)
+    b_parts = []
+    for r in range(world):
+        Ar, br = torch_rows(cfg, m, n, r, dev)
+        # the regenerated rows are the rank's own
+        assert abs(float(br.sum()) - shard_b_sums[r]) <= 1e-9 * max(1.0, abs(shard_b_sums[r])), "rank %d's rows differ" % r
+        A_all[r * m:(r + 1) * m] = Ar
+        b_parts.append(br)
+        del Ar
+    f_all, g_all = functions(cfg, G, np.concatenate(b_parts), n)
+    with pogs_amd.Solver(A_all.data_ptr(), dtype=np_dtype, shape=(m * world, n), device_ptr=True, device=local) as s1:
+        r1 = s1.solve(f_all, g_all)
+        st1 = s1.stats()
+    del A_all
+    torch.cuda.empty_cache()
+    par = _parity(res, r1["x"], r1["optval"], r1["iterations"] + 1,
+                  "the same %d x %d problem solved UNSHARDED on rank 0's GPU by the engine (which is pinned to the compiled "
+                  "reference at N = 1): the row-sharded RCCL solve must land on it" % (m * world, n))
+    par["unsharded_it_per_s"] = (r1["iterations"] + 1) / max(st1["t_loop_s"], 1e-9)
+    return par
+
+
 class Env:
     """What every configuration of a run shares: ranks, device, the process group."""
 
@@ -529,25 +562,7 @@ def run_config(env, name, with_cpu):
         dist.all_gather(sums, bsum)
         if rank == 0 and float(m) * world * n * esize <= UNSHARDED_CHECK_MAX_BYTES:
             try:
-                parts = [torch_rows(cfg, m, n, r, dev) for r in range(world)]
-                for r in range(world):   # the regenerated rows are the ranks' own
-                    assert abs(float(parts[r][1].sum()) - float(sums[r].item())) <= 1e-9 * max(1.0, abs(float(sums[r].item()))), r
-                A_all = torch.cat([pp[0] for pp in parts], 0)
-                if cfg["dtype"] == "f64":
-                    A_all = A_all.double()
-                b_all = np.concatenate([pp[1] for pp in parts])
-                del parts
-                f_all, g_all = functions(cfg, G, b_all, n)
-                with pogs_amd.Solver(A_all.data_ptr(), dtype=np_dtype, shape=(m * world, n), device_ptr=True, device=local) as s1:
-                    r1 = s1.solve(f_all, g_all)
-                    st1 = s1.stats()
-                del A_all
-                torch.cuda.empty_cache()
-                unsharded = _parity(res, r1["x"], r1["optval"], r1["iterations"] + 1,
-                                    "the same %d x %d problem solved UNSHARDED on rank 0's GPU by the engine (which is pinned to "
-                                    "the compiled reference at N = 1): the row-sharded RCCL solve must land on it"
-                                    % (m * world, n))
-                unsharded["unsharded_it_per_s"] = (r1["iterations"] + 1) / max(st1["t_loop_s"], 1e-9)
+                unsharded = unsharded_parity(cfg, m, n, world, dev, local, res, [float(v.item()) for v in sums])
             except Exception as e:   # never take the line down
                 unsharded = {"error": repr(e)[:300]}
         env.barrier()

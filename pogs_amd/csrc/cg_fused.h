@@ -78,12 +78,14 @@ __device__ __forceinline__ void cgf_sum(const double *p, int count, double (&out
 }
 
 // s_j = (A^T r)_j - shift xcg_j ; p_j = s_j ; |s|^2                        (cgls.h:236-245)
+// u (row shards, else null): keeps (A^T r)_j, the start of the recurrence of CgfStepA
 template <typename T>
 struct SpCgInitOp {
   static constexpr int NS = 1;
   T shift;
   const T *x;
   T *s, *p;
+  T *u = nullptr;
   template <int N>
   __device__ __forceinline__ void row(int j, T dot, double (&acc)[N]) const { apply(j, dot, load(j), acc); }
   struct In { T x; };
@@ -91,6 +93,7 @@ struct SpCgInitOp {
   template <int N>
   __device__ __forceinline__ void apply(int j, T dot, const In &in, double (&acc)[N]) const {
     const T v = dot - shift * in.x;
+    if (u) u[j] = dot;
     s[j] = v;
     p[j] = v;
     acc[0] += static_cast<double>(v) * v;
@@ -160,6 +163,11 @@ struct CgfStepA {
   const T *q; T *r;
   const T *ycur; T *ynew;    // ynew == nullptr: the y recurrence is off (explicit product at the end)
   double *rec_x;             // [blocks]
+  // Row shards (u != nullptr): u = A^T r over ALL ranks is kept by recurrence -- t = A^T q (the
+  // all-reduced product of this step, which travelled together with the |q|^2 records): u -= alpha t,
+  // s = u - shift x, |s|^2 records.  One collective per CG step instead of two (|q|^2, then A^T r).
+  T *u; const T *t; T *s;
+  double *rec_s;             // [blocks]
 };
 // U1: alpha = gamma / (|q|^2 + shift |p|^2) (cgls.h:262-271); x += alpha p, r -= alpha q (:274-277),
 // y_new = (first ? y_warm : y_new) + alpha q; partial |x|^2 (:298)
@@ -209,10 +217,25 @@ __global__ void __launch_bounds__(kCgfTpb) cgf_step_a_kernel(CgfStepA<T> a) {
   const T alpha = static_cast<T>(alpha_d), neg_alpha = static_cast<T>(-alpha_d);
   const int stride = gridDim.x * kCgfTpb, t0 = blockIdx.x * kCgfTpb + threadIdx.x;
   double acc[1] = {0.0};
-  for (int i = t0; i < a.n; i += stride) {
-    const T v = a.x[i] + alpha * a.p[i];
-    a.x[i] = v;
-    acc[0] += static_cast<double>(v) * v;
+  double acc_s[1] = {0.0};
+  if (a.u) {
+    const T sh = static_cast<T>(a.shift);
+    for (int i = t0; i < a.n; i += stride) {
+      const T v = a.x[i] + alpha * a.p[i];
+      a.x[i] = v;
+      acc[0] += static_cast<double>(v) * v;
+      const T un = a.u[i] + neg_alpha * a.t[i];
+      a.u[i] = un;
+      const T sv = un - sh * v;                  // cgls.h:281-286 with A^T r from the recurrence
+      a.s[i] = sv;
+      acc_s[0] += static_cast<double>(sv) * sv;
+    }
+  } else {
+    for (int i = t0; i < a.n; i += stride) {
+      const T v = a.x[i] + alpha * a.p[i];
+      a.x[i] = v;
+      acc[0] += static_cast<double>(v) * v;
+    }
   }
   if (a.ynew) {
     const T *ysrc = a.first ? a.ycur : a.ynew;
@@ -226,6 +249,11 @@ __global__ void __launch_bounds__(kCgfTpb) cgf_step_a_kernel(CgfStepA<T> a) {
   }
   dev::block_sum<1, kCgfTpb>(acc, s_red);
   if (threadIdx.x == 0) a.rec_x[blockIdx.x] = acc[0];
+  if (a.u) {
+    __syncthreads();
+    dev::block_sum<1, kCgfTpb>(acc_s, s_red);
+    if (threadIdx.x == 0) a.rec_s[blockIdx.x] = acc_s[0];
+  }
 }
 
 template <typename T>

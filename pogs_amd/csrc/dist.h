@@ -12,7 +12,9 @@
 // One collective per exchange: a vector and the scalar sums that travel with it are packed
 // into one fp64 staging buffer (allreduce2 / allreduce3: pack kernel, ONE ncclAllReduce,
 // unpack kernel); the one-pass dense iteration fills its pack buffer straight from the producing
-// kernels and calls allreduce() on it (dense_solver.h).  No ncclGroupStart/End anywhere.
+// kernels and calls allreduce() on it (dense_solver.h).  The one place where two buffers of different
+// type must travel at the same point (sparse.hip: a CG step's A^T q and its |q|^2 records) groups
+// the two calls (group_begin / group_end) so that they are still one launch.
 //
 // Test transport (only with POGS_AMD_TEST_TRANSPORT set in the environment; otherwise such an id
 // is refused): a unique id that starts with "POGSLOCAL:" selects an in-process communicator
@@ -53,6 +55,11 @@ class DistComm {
   void allreduce(double *buf, size_t count, hipStream_t stream) const;
   // out-of-place: out = sum over ranks of in (in is not written; in != out)
   void allreduce(const double *in, double *out, size_t count, hipStream_t stream) const;
+  // The all-reduces issued between group_begin() and group_end() are independent of each other and
+  // travel as ONE RCCL launch (ncclGroupStart / ncclGroupEnd): the n-vector and the record array of a
+  // row-sharded CG step (sparse.hip).  The test transport runs them one after the other.
+  void group_begin() const;
+  void group_end() const;
   // A vector and one / two scalar ranges as ONE all-reduce of a packed fp64 buffer.
   template <typename T>
   void allreduce2(T *buf, size_t count, double *scalars, size_t nscalars, hipStream_t stream);

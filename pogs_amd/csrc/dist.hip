@@ -34,6 +34,8 @@ struct RcclApi {
   int (*CommCount)(const ncclComm_t, int *) = nullptr;
   int (*CommGetAsyncError)(ncclComm_t, int *) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
 };
 
@@ -60,6 +62,8 @@ RcclApi &api() {
     a.CommGetAsyncError = reinterpret_cast<decltype(a.CommGetAsyncError)>(sym("ncclCommGetAsyncError"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
   });
   return a;
 }
@@ -314,6 +318,13 @@ void DistComm::reduce_raw(const void *in, void *out, size_t count, int dtype, hi
     return;
   }
   check(api().AllReduce(in, out, count, dtype, kNcclSum, comm_, stream), "ncclAllReduce");
+}
+
+void DistComm::group_begin() const {
+  if (comm_ && !aborted_) check(api().GroupStart(), "ncclGroupStart");
+}
+void DistComm::group_end() const {
+  if (comm_ && !aborted_) check(api().GroupEnd(), "ncclGroupEnd");
 }
 
 void DistComm::allreduce(float *buf, size_t count, hipStream_t stream) const {

@@ -920,7 +920,7 @@ class SparseSolver final : public SolverBase {
     f_.alloc(m_); g_.alloc(n_); fs_.alloc(m_); gs_.alloc(n_);
     cg_.alloc(kCgNumSlots);
     cg_.zero(s);
-    if (multi_) tsum_.alloc(n_);
+    if (multi_) { tsum_.alloc(n_); cg_u_.alloc(n_); cg_u_.zero(s); tsum_.zero(s); }
     spmv_grid_ = ctx_.num_cu * 8;
     const size_t vb = vec_blocks(n_) + vec_blocks(m_);
     size_t sg = static_cast<size_t>(spmv_grid_);   // workgroups that write scalar partials in one launch
@@ -965,7 +965,7 @@ class SparseSolver final : public SolverBase {
         POGS_HIP_CHECK(hipStreamSynchronize(s));
         for (double v : all) cg_rec_cap_ = std::max(cg_rec_cap_, static_cast<size_t>(v));
       }
-      cg_rec_.alloc(cg_rec_cap_ * (multi_ ? 3 : 2));
+      cg_rec_.alloc(cg_rec_cap_ * (multi_ ? 4 : 2));   // row shards: + the summed |q|^2 records, + |s|^2 records of U1
       cg_rec_.zero(s);
       const char *ys = std::getenv("POGS_AMD_YSYNC");
       if (ys) ysync_ = std::max(0, std::atoi(ys));
@@ -1346,36 +1346,48 @@ class SparseSolver final : public SolverBase {
     std::vector<size_t> &ev = fused_events_;
     ev.clear();
     size_t e;
-    // Row shards: q = A p and r are this rank's rows, x, p, s are
-    // replicated.  The two sums a CG step needs over all ranks travel on the stream, between the
-    // launches that produce and consume them -- |q|^2 as the array of per-block records (summed
-    // record by record; every block of U1 then adds the records up as on one GPU), A^T r as the
-    // n-vector of local column sums, after which the row functor runs on the totals -- so a step
-    // stays device-resident: 2 collectives, 0 host polls.
+    // Row shards: q = A p and r are this rank's rows; x, p, s and
+    // u = A^T r (summed over the ranks) are replicated.  A CG step needs two sums over all ranks, |q|^2
+    // and A^T r_new = u - alpha A^T q: with t = A^T q formed BEFORE alpha is known, both travel at the
+    // same point -- t as the n-vector of local column sums, |q|^2 as the array of per-block records
+    // (summed record by record; every block of U1 then adds the records up as on one GPU) -- in ONE
+    // grouped RCCL launch per step, on the stream, between the launches that produce and consume
+    // them: 0 host polls.  u is set by the explicit product at the start of every projection, so the
+    // recurrence u -= alpha t runs over the few steps of one projection only.
     double *rec_a_sum = multi_ ? cg_rec_.p + 2 * cg_rec_cap_ : rec_a;
+    double *rec_s2 = multi_ ? cg_rec_.p + 3 * cg_rec_cap_ : rec_t;
     const int nrec_a_sum = static_cast<int>(cg_rec_cap_);
-    auto at_product = [&](auto op, int run_if_done) {   // s-type products: returns the number of records in rec_t
-      if (!multi_) return spmv_cg(At_, cg_r_.p, op, rec_t, run_if_done, &e);
-      spmv_cg(At_, cg_r_.p, SpStoreOp<T>{tsum_.p}, rec_t, run_if_done, &e);
-      ctx_.dist.allreduce(tsum_.p, n_, s);
-      const int nrec = cgf_blocks(n_);
-      hipLaunchKernelGGL((cgf_reduce_kernel<T, decltype(op)>), dim3(nrec), dim3(kCgfTpb), 0, s, tsum_.p, n_, 1, op, rec_t,
-                         S, run_if_done);
-      return nrec;
-    };
-    // s = A^T r - shift x ; p = s ; |s_0|^2 records                           (cgls.h:236-245)
-    const int nrec_s0 = at_product(SpCgInitOp<T>{static_cast<T>(shift), x, cg_s_.p, cg_p_.p}, -1);
     const int gv = cgf_blocks(std::max(n_, m_)), gp = cgf_blocks(n_);
+    // s = A^T r - shift x ; p = s ; |s_0|^2 records                           (cgls.h:236-245)
+    int nrec_s0;
+    if (!multi_) {
+      nrec_s0 = spmv_cg(At_, cg_r_.p, SpCgInitOp<T>{static_cast<T>(shift), x, cg_s_.p, cg_p_.p}, rec_t, -1, &e);
+    } else {
+      spmv_cg(At_, cg_r_.p, SpStoreOp<T>{tsum_.p}, rec_t, -1, &e);
+      ctx_.dist.allreduce(tsum_.p, n_, s);
+      nrec_s0 = cgf_blocks(n_);
+      SpCgInitOp<T> init{static_cast<T>(shift), x, cg_s_.p, cg_p_.p};
+      init.u = cg_u_.p;
+      hipLaunchKernelGGL((cgf_reduce_kernel<T, SpCgInitOp<T>>), dim3(nrec_s0), dim3(kCgfTpb), 0, s, tsum_.p, n_, 1, init,
+                         rec_t, S, -1);
+    }
     int enq = 0;
     auto step = [&]() {
       // q = A p, |q|^2 records                                               (cgls.h:257-260)
       int nrec_q = spmv_cg(A_, cg_p_.p, SpAxpbyNormOp<T>{1, 0, nullptr, cg_q_.p}, rec_a, 0, &e);
       ev.push_back(e);
       if (multi_) {
+        // t = A^T q (this rank's rows), then t and the |q|^2 records over all ranks
+        spmv_cg(At_, cg_q_.p, SpStoreOp<T>{tsum_.p}, rec_s2, 0, &e);
+        ev.push_back(e);
+        ctx_.dist.group_begin();
+        ctx_.dist.allreduce(tsum_.p, n_, s);
         ctx_.dist.allreduce(rec_a, rec_a_sum, static_cast<size_t>(nrec_a_sum), s);
+        ctx_.dist.group_end();
         nrec_q = nrec_a_sum;
       }
       // alpha ; x += alpha p ; r -= alpha q ; y_new += alpha q ; |x|^2        (:262-277, 298)
+      // (row shards: also u -= alpha t ; s = u - shift x ; |s|^2, :281-286)
       CgfStepA<T> a;
       a.n = n_; a.m = m_; a.S = S;
       a.first = enq == 0; a.gslot = enq & 1;
@@ -1386,14 +1398,18 @@ class SparseSolver final : public SolverBase {
       a.p = cg_p_.p; a.x = x; a.q = cg_q_.p; a.r = cg_r_.p;
       a.ycur = y_[cur_].p; a.ynew = ysync ? nullptr : y_[nw].p;
       a.rec_x = rec_x;
+      a.u = multi_ ? cg_u_.p : nullptr; a.t = tsum_.p; a.s = cg_s_.p; a.rec_s = rec_s2;
       hipLaunchKernelGGL(cgf_step_a_kernel<T>, dim3(gv), dim3(kCgfTpb), 0, s, a);
-      // s = A^T r - shift x ; |s|^2 records                                  (:281-286)
-      const int nrec_s = at_product(SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, 0);
-      ev.push_back(e);
+      int nrec_s = gv;
+      if (!multi_) {
+        // s = A^T r - shift x ; |s|^2 records                                (:281-286)
+        nrec_s = spmv_cg(At_, cg_r_.p, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, rec_t, 0, &e);
+        ev.push_back(e);
+      }
       // beta, gamma, the stopping test ; p = s + beta p ; |p|^2              (:288-305)
       CgfStepB<T> b;
       b.n = n_; b.S = S; b.k = enq;
-      b.rec_s = rec_t; b.nrec_s = nrec_s;
+      b.rec_s = rec_s2; b.nrec_s = nrec_s;
       b.rec_x = rec_x; b.nrec_x = gv;
       b.tol = tol; b.maxit = 500;                                             // projector_cgls.cpp:17
       b.s = cg_s_.p; b.p = cg_p_.p; b.rec_p = rec_p;
@@ -1578,6 +1594,7 @@ class SparseSolver final : public SolverBase {
   bool first_is_A_ = true;
   bool multi_ = false;
   DevBuf<T> tsum_;   // row shards: this rank's A^T partial sums before the all-reduce
+  DevBuf<T> cg_u_;   // row shards, device-resident CG loop: A^T r over all ranks, kept by recurrence
   int spmv_grid_ = 2048;
   size_t sp_cgx_off_ = 0, sp_cgp_off_ = 0, sp_pre_off_ = 0;   // regions of ctx_.spart (alloc_state)
   unsigned long long timed_spmvs_ = 0;

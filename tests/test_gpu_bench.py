@@ -71,12 +71,41 @@ def test_default_invocation_carries_the_contract_fields_and_the_secondary_worklo
 def test_one_rank_rccl_path_runs_the_bench_command_at_the_plain_speed(plain, cfg):
     """rccl_nranks is what ncclCommCount reports; one rank's collectives are no-ops, so the line must
     come out within a few per cent of the plain run -- for c4 too since round 4: row shards run the
-    device-resident CGLS loop (two all-reduces per CG step on the stream, no host poll inside the
-    projection), which costs one extra small launch per A^T product."""
+    device-resident CGLS loop with ONE grouped all-reduce per CG step on the stream (t = A^T q and the
+    |q|^2 records; A^T r by recurrence) and no host poll inside the projection: measured on one box,
+    alternating, -1.5 / -2.2 / -1.9 % against the plain run (scripts/c4_one_rank.sh)."""
     d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--config", cfg],
                {"POGS_AMD_FORCE_DIST": "1"})
     ref = plain if cfg == "c2" else plain["secondary"][cfg]
     assert d["config"]["rccl_nranks"] == 1 and d["n_gpus"] == 1
     assert d["solve_status"] == 0 and abs(d["solve_iterations"] - ref["solve_iterations"]) <= 3
-    slack = 0.05 if cfg == "c2" else 0.06     # box-to-box noise is +-2 %; c4 pays ~15 us per iteration for the split A^T products
+    slack = 0.05 if cfg == "c2" else 0.045    # (the two runs are separate processes: +-1 % between them)
     assert d["value"] >= (1.0 - slack) * ref["value"], (d["value"], ref["value"])
+
+
+def test_the_n_gt_1_parity_leg_on_two_in_process_ranks():
+    """bench.py at N > 1: every rank draws its rows with torch_rows(seed 1000 + rank), rank 0 regenerates
+    all of them and solves the whole problem unsharded (unsharded_parity).  No node here, so the two ranks
+    are threads joined by the in-process, stream-ordered test communicator on one GPU -- the generator,
+    the regeneration check and the comparison are the bench's own code."""
+    import numpy as np
+    import torch
+
+    import bench
+    import pogs_amd
+    from helpers import run_row_sharded
+    from pogs_amd import graph as G
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    cfg, m, n, world = bench.CONFIGS["c2"], 12000, 1500, 2
+    dev = torch.device("cuda:0")
+    parts = [bench.torch_rows(cfg, m, n, r, dev) for r in range(world)]
+    A = np.concatenate([p[0].cpu().numpy() for p in parts])
+    b = np.concatenate([p[1] for p in parts])
+    f, g = bench.functions(cfg, G, b, n)
+    res, _ = run_row_sharded(pogs_amd, A, f, g, world, np.float32)
+    par = bench.unsharded_parity(cfg, m, n, world, dev, 0, res[0], [float(p[1].sum()) for p in parts])
+    assert par["rel_x"] < 1e-4 and abs(par["iterations_engine"] - par["iterations_reference"]) <= 3, par
+    with pytest.raises(AssertionError):      # rows that are not the rank's own are noticed
+        bench.unsharded_parity(cfg, m, n, world, dev, 0, res[0], [1.0, 2.0])
