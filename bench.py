@@ -242,8 +242,10 @@ def parity_from_fixture(cfg, fx, engine):
     return par
 
 
-# what the CPU leg runs per workload: (BLAS build of the compiled reference, iteration cap or None = to convergence)
-CPU_PLAN = {"c2": [("openblas", "cap"), ("mkl", "cap")], "c3": [("openblas", None)]}
+# what the CPU leg runs per workload: (BLAS build of the compiled reference, max_iter; None = the default 2500, "cap" =
+# --cpu-iters).  c2 with OpenBLAS gets 400 iterations: enough to converge where its fp32 build converges at all (154
+# iterations in the build container), 20 s if it does not.
+CPU_PLAN = {"c2": [("openblas", 400), ("mkl", "cap")], "c3": [("openblas", None)]}
 
 
 def cpu_baseline(name, cfg, A_host, f, g, args, engine):
@@ -256,11 +258,11 @@ def cpu_baseline(name, cfg, A_host, f, g, args, engine):
     scipy's OpenBLAS, which threads its gemv -- SURVEY.md section 8(d)'s "best configuration" for the
     dense path, BLAS threads = granted cores -- and against MKL, the build the oracle is pinned to,
     whose sgemv runs on ONE thread on the GPU box's AMD host (profiles/r03_ref_cpu_diagnosis.md).
-    The top-level fields are the best build's; `builds` holds each.  c2 is capped at --cpu-iters ADMM
-    iterations: the reference's fp32 build does not reach the default tolerances there on that host
-    and runs twenty minutes into max_iter (--cpu-full lifts the cap); its first iterations are its
-    cheapest (no exact-residual passes yet), so the cap flatters the CPU side.  c3 runs to
-    convergence.
+    The top-level fields are the best build's; `builds` holds each.  c2: the MKL build is capped at
+    --cpu-iters ADMM iterations -- on that host it does not reach the default tolerances and runs twenty
+    minutes into max_iter (--cpu-full lifts the caps); its first iterations are its cheapest (no
+    exact-residual passes yet), so the cap flatters the CPU side -- the OpenBLAS build gets 400
+    iterations, which is to convergence where it converges.  c3 runs to convergence.
     Sparse (c4): the OpenMP oracle port on the whole workload to convergence (`kind` "port": the
     reference's sparse path is single-threaded as built and needs 21 minutes,
     tests/golden/make_c4_reference.py), OpenMP threads = granted cores."""
@@ -291,7 +293,7 @@ def cpu_baseline(name, cfg, A_host, f, g, args, engine):
         if not ob.ref_available(blas):
             builds[blas] = {"value": None, "sample": "oracle/_ref build for %s missing" % blas}
             continue
-        cap_it = None if (cap is None or args.cpu_full) else args.cpu_iters
+        cap_it = None if (cap is None or args.cpu_full) else (args.cpu_iters if cap == "cap" else int(cap))
         t_start = time.time()
         try:
             r = ob.ref_solve(A_host, fs, gs, dtype=dt, verbose=1, timeout=args.cpu_budget_s, blas=blas,
