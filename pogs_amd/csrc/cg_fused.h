@@ -16,9 +16,11 @@
 //       p = s + beta p, partial |p|^2                                      cgf_step_b_kernel
 //
 // "Every block adds up the records itself": a scalar that needs a sum over the whole vector is
-// formed by EACH block of the consuming launch from the <= 512 per-block records the producing
-// launch left behind (4 KB from L2, the same order in every block, so all blocks hold the same
-// bits); block 0 also stores it for the host and for later launches.  No atomics, no fences, no
+// formed by EACH block of the consuming launch from the per-block records the producing launch left
+// behind -- at most kCgfBlocks = 512 from the loop's own launches and from a product with column
+// groups, one per row range from a product without them (more than 512 only beyond 8.4 million rows
+// at the full tile height: correct, the consumers just re-read more) -- 4 KB from L2, the same order
+// in every block, so all blocks hold the same bits; block 0 also stores it for the host and for later launches.  No atomics, no fences, no
 // "last block" -- an in-kernel finaliser behind a device counter was built first and measured:
 // its agent-scope release / acquire fences (L2 write-back / invalidate on a multi-XCD part) cost
 // 19 us per SpMV and its one-workgroup-per-row-range functor tail 10 us more.

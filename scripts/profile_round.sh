@@ -3,8 +3,8 @@
 #   bench.json                plain run (no profiler), with the CPU baseline
 #   kernel_stats.csv          rocprofv3 --kernel-trace --stats summary of the same command
 #   pmc_traffic.json          FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes, corrected)
-# usage: profile_round.sh <tag> [c2|c3|c4]       (then copy the three files into profiles/)
-tag=${1:-r03}
+# usage: profile_round.sh <tag> [c2|c3|c4|c2f64]       (then copy the three files into profiles/)
+tag=${1:-r04}
 cfg=${2:-c2}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_${tag}_${cfg}
