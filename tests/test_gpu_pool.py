@@ -160,3 +160,30 @@ def test_no_kernel_counts_on_fresh_memory_being_zero():
     r = subprocess.run([sys.executable, "-c", _POISON_SCRIPT % {"root": ROOT}], env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "POISON_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_POOL_OFF_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch  # noqa: F401
+import pogs_amd
+from pogs_amd import _lib, synth
+A, b, _ = synth.dense_lasso(3000, 400, seed=5, dtype=np.float32)
+r1 = pogs_amd.solve_lasso(A, b, 0.1, dtype=np.float32)
+r2 = pogs_amd.solve_lasso(A, b, 0.1, dtype=np.float32)
+st = _lib.pool_stats()
+assert np.array_equal(r1["x"], r2["x"]) and r1["status"] == 0
+assert st["reuses"] == 0 and st["cached_bytes"] == 0 and st["frees"] == st["mallocs"] > 0, st
+print("POOL_OFF_OK", st["mallocs"])
+"""
+
+
+def test_pool_can_be_turned_off():
+    """POGS_AMD_POOL_MB=0: every block goes back to the HIP runtime when it is released (the behaviour
+    before round 4), same results."""
+    _torch()
+    env = dict(os.environ, POGS_AMD_POOL_MB="0", POGS_AMD_TORCH_PRELOAD="1")
+    r = subprocess.run([sys.executable, "-c", _POOL_OFF_SCRIPT % {"root": ROOT}], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "POOL_OFF_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
