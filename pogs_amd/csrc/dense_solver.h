@@ -897,12 +897,14 @@ class DenseSolver final : public SolverBase {
         // 256 x 256 workgroup tiles (half the operand bytes per product of the 128 tile; one
         // accumulator set, i.e. a unit is ONE MFMA chain -- chains of 1024 .. 16384 rows give the same
         // 106 iterations at C2 and x within 6e-7 of each other, the distance the native fp32 product
-        // is at) where the Gram matrix has enough of them to fill the chip; the 128 tile below, with
+        // is at) from n = 4096 on; the 128 tile below, with
         // 1024-row chains added to a second register set.  POGS_AMD_GRAM_TILE=128 forces the 128
         // tile (regression sweep of tests/test_gpu_dense.py).
         constexpr int kRows = 1024, kUnitCap = 12800;
         const int launches = (kdim + 4 * kUnitCap - 1) / (4 * kUnitCap);
-        int tile = k_ >= 8192 ? 256 : 128;
+        // (measured with 200000 rows, phase in ms, 128 | 256 tile: n = 3072 7.5 | 7.9, 4096 12.6 | 12.2, 5000 18.5 | 16.7,
+        // 6144 25.9 | 21.8, 7168 34.4 | 30.0)
+        int tile = k_ >= 4096 ? 256 : 128;
         if (const char *ev = std::getenv("POGS_AMD_GRAM_TILE")) tile = std::atoi(ev) == 256 ? 256 : 128;
         const int urows = static_cast<int>(round_up(static_cast<size_t>((kdim + 4 * launches - 1) / (4 * launches)), 32));
         const int nunits = (kdim + urows - 1) / urows;

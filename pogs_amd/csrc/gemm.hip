@@ -2,6 +2,7 @@
 #include "gemm.h"
 
 #include <cmath>
+#include <type_traits>
 
 namespace pogs_amd {
 
@@ -39,7 +40,12 @@ template <typename T> struct TileVec {
 };
 
 // Loads a 128 (i) x 16 (k) operand tile into registers, zero-filling out of range.
-template <typename T, bool KMAJ>
+// FAST: the caller knows the whole tile is in range -- unconditional 16-byte loads.  With the
+// guarded form every load sits in its own branch and the compiler, unable to count the loads in
+// flight, waits `vmcnt(0)` before the tile is written to LDS: that also waits for the NEXT tile's
+// loads, issued a moment ago, i.e. it drains the prefetch every k-tile (fp64 Gram at C2: MFMA busy
+// 59 % at the full 2.38 GHz).  The unconditional form lets it wait for the older stage only.
+template <typename T, bool KMAJ, bool FAST = false>
 __device__ __forceinline__ void load_tile(const T *__restrict__ P, size_t ld, int i0, int k0, int ilim,
                                           int klim, typename Vec16<T>::type (&regs)[TileVec<T>::NVT]) {
   using V = typename Vec16<T>::type;
@@ -49,6 +55,13 @@ __device__ __forceinline__ void load_tile(const T *__restrict__ P, size_t ld, in
   for (int p = 0; p < TileVec<T>::NVT; ++p) {
     const int q = t + GT * p;
     T tmp[VEC];
+    if (FAST) {
+      const int per_row = KMAJ ? BM / VEC : BK / VEC;
+      const int r = q / per_row, c = (q % per_row) * VEC;
+      const T *src = KMAJ ? P + static_cast<size_t>(k0 + r) * ld + (i0 + c) : P + static_cast<size_t>(i0 + r) * ld + (k0 + c);
+      regs[p] = *reinterpret_cast<const V *>(src);
+      continue;
+    }
     if (KMAJ) {
       constexpr int per_row = BM / VEC;
       const int gk = k0 + q / per_row;
@@ -99,8 +112,8 @@ __device__ __forceinline__ void store_tile(T *sm, const typename Vec16<T>::type 
   }
 }
 
-template <typename T, bool A_KMAJ, bool B_KMAJ, bool LOWER, bool TWOLEVEL = false>
-__global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
+template <typename T, bool A_KMAJ, bool B_KMAJ, bool LOWER, bool TWOLEVEL>
+__device__ __forceinline__ void gemm_body(GemmArgs<T> g) {
   using V = typename Vec16<T>::type;
   using Acc = typename Mma<T>::Acc;
   // two LDS stages per operand: the next k-tile is written while the current one is read,
@@ -198,36 +211,46 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
   }
   const int acc_tiles = TWOLEVEL ? g.kacc / BK : 0;   // even
   int until_flush = acc_tiles;
-  for (int kt = 0; kt < nk; kt += 2) {
-    // even phase: LDS[0] = tile kt, stage 0 = tile kt+1 (in flight), request tile kt+2
-    load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg + (kt + 2) * BK, g.M, kend, ra1);
-    load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg + (kt + 2) * BK, g.N, kend, rb1);
-    POGS_GEMM_COMPUTE(sA[0], sB[0])
-    store_tile<T, A_KMAJ>(sA[1], ra0);
-    store_tile<T, B_KMAJ>(sB[1], rb0);
-    __syncthreads();
-    // odd phase: LDS[1] = tile kt+1, stage 1 = tile kt+2 (in flight), request tile kt+3
-    load_tile<T, A_KMAJ>(g.A, g.lda, i0, kbeg + (kt + 3) * BK, g.M, kend, ra0);
-    load_tile<T, B_KMAJ>(g.B, g.ldb, j0, kbeg + (kt + 3) * BK, g.N, kend, rb0);
-    POGS_GEMM_COMPUTE(sA[1], sB[1])
-    store_tile<T, A_KMAJ>(sA[0], ra1);
-    store_tile<T, B_KMAJ>(sB[0], rb1);
-    __syncthreads();
-    if (TWOLEVEL) {
-      until_flush -= 2;
-      if (until_flush == 0) {
-        until_flush = acc_tiles;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            tot[a][b] += acc[a][b];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0;
-          }
-      }
-    }
+  // Interior tiles (all 128 rows of both operand panels in range) run the pairs of k-tiles whose
+  // prefetched tiles kt + 2, kt + 3 lie wholly below kend with the unconditional loader; the last
+  // pairs and edge tiles take the guarded one.
+  const int nfull = (kend - kbeg) / BK;   // k-tiles wholly in range
+  const bool interior = i0 + BM <= g.M && j0 + BN <= g.N;
+  const int kt_fast = interior ? ((nfull - 3) & ~1) : 0;   // pairs kt < kt_fast prefetch tiles <= kt + 3 < nfull
+#define POGS_GEMM_PAIR(FAST_)                                                                          \
+  {                                                                                                      \
+    /* even phase: LDS[0] = tile kt, stage 0 = tile kt+1 (in flight), request tile kt+2 */              \
+    load_tile<T, A_KMAJ, FAST_>(g.A, g.lda, i0, kbeg + (kt + 2) * BK, g.M, kend, ra1);                   \
+    load_tile<T, B_KMAJ, FAST_>(g.B, g.ldb, j0, kbeg + (kt + 2) * BK, g.N, kend, rb1);                   \
+    POGS_GEMM_COMPUTE(sA[0], sB[0])                                                                      \
+    store_tile<T, A_KMAJ>(sA[1], ra0);                                                                   \
+    store_tile<T, B_KMAJ>(sB[1], rb0);                                                                   \
+    __syncthreads();                                                                                     \
+    /* odd phase: LDS[1] = tile kt+1, stage 1 = tile kt+2 (in flight), request tile kt+3 */             \
+    load_tile<T, A_KMAJ, FAST_>(g.A, g.lda, i0, kbeg + (kt + 3) * BK, g.M, kend, ra0);                   \
+    load_tile<T, B_KMAJ, FAST_>(g.B, g.ldb, j0, kbeg + (kt + 3) * BK, g.N, kend, rb0);                   \
+    POGS_GEMM_COMPUTE(sA[1], sB[1])                                                                      \
+    store_tile<T, A_KMAJ>(sA[0], ra1);                                                                   \
+    store_tile<T, B_KMAJ>(sB[0], rb1);                                                                   \
+    __syncthreads();                                                                                     \
+    if (TWOLEVEL) {                                                                                      \
+      until_flush -= 2;                                                                                  \
+      if (until_flush == 0) {                                                                            \
+        until_flush = acc_tiles;                                                                         \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                    \
+          _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                \
+            tot[a][b] += acc[a][b];                                                                      \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[a][b][r] = 0;                              \
+          }                                                                                              \
+      }                                                                                                  \
+    }                                                                                                    \
   }
+  int kt = 0;
+  if constexpr (!TWOLEVEL) {   // (the two-level form has no registers for a second copy of the loop: fp64 would spill)
+    for (; kt < kt_fast; kt += 2) POGS_GEMM_PAIR(true)
+  }
+  for (; kt < nk; kt += 2) POGS_GEMM_PAIR(false)
+#undef POGS_GEMM_PAIR
 #undef POGS_GEMM_COMPUTE
   if (TWOLEVEL) {
 #pragma unroll
@@ -251,6 +274,25 @@ __global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
           *c = v;
         }
       }
+}
+
+template <typename T, bool A_KMAJ, bool B_KMAJ, bool LOWER, bool TWOLEVEL = false>
+__global__ void __launch_bounds__(GT) gemm_kernel(GemmArgs<T> g) {
+  gemm_body<T, A_KMAJ, B_KMAJ, LOWER, TWOLEVEL>(g);
+}
+// The same body held to 256 registers, i.e. two workgroups per CU (2 x 72 KB of LDS): every fp64 form
+// with one accumulator set.  Left alone the fp64 body takes 384 .. 417 registers (256 + 128 accumulators)
+// and runs ONE wavefront per SIMD, so the matrix pipe idles whenever that wavefront reads LDS, stores a
+// tile or waits at the barrier -- the fp64 Gram product of C2 kept it busy 59 % of the time at the full
+// 2.38 GHz (it is not power-limited, unlike the fp16-split product).  Under the bound the K-major form
+// (the Gram product) fits without spilling; the row-major and mixed forms (Cholesky updates, triangular
+// inverse) spill 12 .. 23 registers and are faster all the same.  Measured at C2 in fp64 together with
+// the branch-free loader above: Gram 228 -> 155 ms (68 TFLOP/s = 0.86 of the fp64 matrix peak),
+// Cholesky 39.6 -> 29.1 ms, inverse 12.9 -> 9.9 ms.  The two-level form would spill 200+ and keeps
+// gemm_kernel.
+template <typename T, bool A_KMAJ, bool B_KMAJ, bool LOWER>
+__global__ void __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2))) gemm_kernel_w2(GemmArgs<T> g) {
+  gemm_body<T, A_KMAJ, B_KMAJ, LOWER, false>(g);
 }
 
 // The 16 steps j = 16 JB .. 16 JB + 15 of potrf_inv_kernel.  JB is a template parameter so
@@ -420,10 +462,12 @@ void launch_gemm_ab(bool lower, const GemmArgs<T> &g, hipStream_t s) {
   const int grid = (nt + kNumXcd - 1) / kNumXcd * kNumXcd;
   if (lower && gg.kacc > 0 && A_KMAJ == B_KMAJ) {
     hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, true, true>), dim3(grid), dim3(GT), 0, s, gg);
-  } else if (lower) {
-    hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, true>), dim3(grid), dim3(GT), 0, s, gg);
+  } else if constexpr (std::is_same<T, double>::value) {
+    if (lower) hipLaunchKernelGGL((gemm_kernel_w2<T, A_KMAJ, B_KMAJ, true>), dim3(grid), dim3(GT), 0, s, gg);
+    else hipLaunchKernelGGL((gemm_kernel_w2<T, A_KMAJ, B_KMAJ, false>), dim3(grid), dim3(GT), 0, s, gg);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, false>), dim3(grid), dim3(GT), 0, s, gg);
+    if (lower) hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, true>), dim3(grid), dim3(GT), 0, s, gg);
+    else hipLaunchKernelGGL((gemm_kernel<T, A_KMAJ, B_KMAJ, false>), dim3(grid), dim3(GT), 0, s, gg);
   }
 }
 

@@ -22,7 +22,9 @@ Solves problems of the form
 
 with ``f_i(v) = c h(a v - b) + d v + e v^2 / 2`` and ``h`` one of `Function`.
 """
+import atexit
 import ctypes
+import weakref
 from enum import IntEnum
 
 import numpy as np
@@ -290,6 +292,23 @@ def solve_nonneg_ls(A, b, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, verbose=0, 
 # Persistent handle (no counterpart in the reference's Python layer; its C++ API
 # reuses the factorisation through _done_init, src/cpu/pogs.cpp:113-114)
 # ---------------------------------------------------------------------------
+# Handles still alive when the interpreter shuts down are destroyed by an atexit callback -- while the
+# HIP runtime is certainly still there -- instead of by whatever order garbage collection and the C
+# runtime's own exit handlers happen to take (a handle's destructor synchronises its stream).
+_LIVE_SOLVERS = weakref.WeakSet()
+
+
+def _close_live_solvers():
+    for s in list(_LIVE_SOLVERS):
+        try:
+            s.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_live_solvers)
+
+
 class Solver:
     """Keeps the equilibrated matrix and its factorisation on the GPU across solves.
 
@@ -347,6 +366,7 @@ class Solver:
                                         ctypes.byref(opt), ctypes.byref(dist_s) if dist_s is not None else None)
         if st != 0:
             raise RuntimeError("pogs_amd: solver creation failed: " + _lib.last_error())
+        _LIVE_SOLVERS.add(self)
 
     def _coef(self, f, g):
         assert len(f) == self.m and len(g) == self.n
