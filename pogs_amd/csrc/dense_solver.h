@@ -864,7 +864,9 @@ class DenseSolver final : public SolverBase {
       // where K ranges stay longer than ~6.4k rows the unit itself sums in chunks
       const int klen = ksplit > 1 ? g.kchunk : kdim;
       const int nacc = (klen + 6399) / 6400;
-      g.kacc = nacc > 1 ? static_cast<int>(round_up((klen + nacc - 1) / nacc, 32)) : 0;
+      // (fp32 only: the chunks bound the rounding of a long fp32 sum; an fp64 sum over 1e5 rows is exact to 1e-11,
+      // and the one-level kernel runs two workgroups per CU where the two-level one has registers for one)
+      g.kacc = (nacc > 1 && std::is_same<T, float>::value) ? static_cast<int>(round_up((klen + nacc - 1) / nacc, 32)) : 0;
       DevBuf<int> tmap;
       if (k_ > 16 * 128 && k_ < 65536 * 128) {
         const std::vector<int> order = gram_tile_order(k_);
