@@ -1164,6 +1164,8 @@ class DenseSolver final : public SolverBase {
     cur_ = 0;
     zt_scale_ = 1;
     spec_valid_ = false;
+    exact_mode_ = false;
+    colparts_ = 0;
     proj_count_ = 0;
     ctl_.reset();
   }
@@ -1339,7 +1341,18 @@ class DenseSolver final : public SolverBase {
     double *pc_part = pre_part + static_cast<size_t>(by) * 3;    // [gridC][4] pre_cols sums
     double *tail = pack_.p ? pack_.p + 2 * static_cast<size_t>(n_pad_) : nullptr;   // row shards: 6 scalars
     const size_t pack_count = 2 * static_cast<size_t>(n_pad_) + 6;
-    int nparts = stream2_grid<2>(planA_, m_);
+    // Lean iterations (fp64 on one GPU).  With 16-byte vectors of two doubles the two-dot / two-accumulator
+    // pass has registers for ONE row per step and one workgroup per CU: nothing covers the row functor and
+    // the barriers, and it streams at 5.8 TB/s where the one-dot / one-accumulator form with two rows per
+    // step (Sinkhorn-Knopp's pass) reaches 7.0.  The exact residuals it carries are only ever USED once the
+    // approximate bounds fall below 10 x the tolerances (pogs.cpp:346-352) -- late in a solve, 11 of C2's 106
+    // iterations.  Until then the pass leaves them out; the first iteration whose bounds ask for them
+    // evaluates them in a pass of its own (the two-pass iteration's, below), drops the speculation so that
+    // the next iteration rebuilds both column-sum sets (PreAccOp), and from there on the full pass runs.
+    // Same arithmetic for everything that is used, so the same trajectory.
+    constexpr bool kLeanType = std::is_same<T, double>::value;
+    const bool lean = kLeanType && !multi_ && !exact_mode_;
+    int nparts = colparts_ > 0 ? colparts_ : stream2_grid<2>(planA_, m_);
     if (!spec) {
       // (A') y half of the prox / over-relaxation, then (B) the column sums A^T yhat_k and
       // A^T (y12 + c yt - yprev) in a pass of their own -- a speculated iteration has both from
@@ -1401,17 +1414,28 @@ class DenseSolver final : public SolverBase {
       // iteration's residuals stand in for this one's)
       ctl_.predict(&rho_pred_, &zs_pred_);
       ctx_.stream_timer.begin(s);
+      int grid = stream2_grid<2>(planA_, m_);
       if (fused_logistic_) {
         FusedIterOp<T, true> op{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, fview(), rho_pred_, ctl_.alpha(), zs_pred_,
                                 y12s_.p, ytemps_.p};
-        launch_stream2<T, 2, 2, Tag>(planA_, a2, op, s);
+        if constexpr (kLeanType) {
+          if (lean) { launch_stream2<T, 1, 1, Tag>(planA_, a2, op, s); grid = stream2_grid<1, 1>(planA_, m_); }
+          else launch_stream2<T, 2, 2, Tag>(planA_, a2, op, s);
+        } else {
+          launch_stream2<T, 2, 2, Tag>(planA_, a2, op, s);
+        }
       } else {
         FusedIterOp<T, false> op{y_[nw].p, y_[cur_].p, y12_.p, ytemp_.p, fview(), rho_pred_, ctl_.alpha(), zs_pred_,
                                  y12s_.p, ytemps_.p};
-        launch_stream2<T, 2, 2, Tag>(planA_, a2, op, s);
+        if constexpr (kLeanType) {
+          if (lean) { launch_stream2<T, 1, 1, Tag>(planA_, a2, op, s); grid = stream2_grid<1, 1>(planA_, m_); }
+          else launch_stream2<T, 2, 2, Tag>(planA_, a2, op, s);
+        } else {
+          launch_stream2<T, 2, 2, Tag>(planA_, a2, op, s);
+        }
       }
       ctx_.stream_timer.end(s);
-      const int grid = stream2_grid<2>(planA_, m_);
+      colparts_ = grid;
       const SumJob jd{ctx_.spart.p, grid, 3, ctx_.S.p + kDYprev2, 6, 0};
       const SumJob js{ctx_.spart.p, grid, 3, ctx_.S.p + kSpecGapY, 6, 3};
       if (!multi_) {
@@ -1440,7 +1464,27 @@ class DenseSolver final : public SolverBase {
       for (int q = 0; q < 3; ++q) S[kGapY + q] = spec_gap_[q];
     ctl_.set_pre(S);
     bool exact = false;
+    bool drop_spec = false;
     if (ctl_.set_approx(S, nrmA_)) {
+      if (lean) {
+        // the exact residuals of THIS iteration in a pass of their own (pogs.cpp:352-376; the same launches
+        // as the two-pass iteration's step (3)), column partials into the free second set
+        StreamArgs<T> a = argsA();
+        a.xin = x12_.p;
+        a.col_partials = colpart2_.p;
+        const int g1 = stream_grid<true, true>(planA_, srows_);
+        ctx_.stream_timer.begin(s);
+        launch_stream<T, true, true, false, kFull, Tag>(planA_, a, ExactRowOp<T>{y12_.p, yt_.p, y_[cur_].p, zt_scale_}, s);
+        ctx_.stream_timer.end(s);
+        sum_row_scalars(g1, 1, ctx_.S.p + kExactR2);
+        finish_cols(ExactColOp<T>{x12_.p, xt_.p, x_[cur_].p, zt_scale_, n_}, ctx_.S.p + kExactS2, kExactR2, 1, g1, colpart2_.p);
+        ctx_.stats.matvecs += 1;
+        const double *S2 = ctx_.fetch_scalars();
+        S[kExactR2] = S2[kExactR2];
+        S[kExactS2] = S2[kExactS2];
+        exact_mode_ = true;
+        drop_spec = true;   // the next iteration rebuilds both column-sum sets (the second one was never formed)
+      }
       ctl_.set_exact(S);
       exact = true;
     }
@@ -1451,7 +1495,7 @@ class DenseSolver final : public SolverBase {
     std::swap(yt_, ytemp_);            // yt = ytilde_{k+1}
     cur_ = nw;
     zt_scale_ = ctl_.adapt();
-    if (ctl_.rho == rho_pred_ && zt_scale_ == zs_pred_) {
+    if (!drop_spec && ctl_.rho == rho_pred_ && zt_scale_ == zs_pred_) {
       std::swap(ytemp_, ytemps_);      // ytemp = speculative yhat_{k+1}
       std::swap(y12_, y12s_);          // y12 = speculative y12_{k+1}
       for (int q = 0; q < 3; ++q) spec_gap_[q] = S[kSpecGapY + q];
@@ -1648,6 +1692,10 @@ class DenseSolver final : public SolverBase {
   DevBuf<T> A_, fac_, d_, e_, colpart_, colpart2_, y12s_, ytemps_;
   DevBuf<double> pack_;         // row shards, one-pass iteration: the packed all-reduce buffer
   bool fused_ok_ = false, fused_now_ = false, fused_logistic_ = false, spec_valid_ = false;
+  // fp64, one GPU, m > n: the pass leaves the exact residuals out (one dot product, one accumulator, two
+  // rows per step) until the approximate bounds first ask for them (iteration_fused)
+  bool exact_mode_ = false;
+  int colparts_ = 0;            // workgroups (= column partials) of the pass that filled colpart_ last
   bool warm_pending_ = false;
   std::vector<T> warm_x_, warm_l_;
   T rho_pred_ = 1, zs_pred_ = 1;

@@ -435,8 +435,10 @@ struct FusedIterOp {
     const T a = p.ycur - yn, b = h0 - yn;
     s[0] += static_cast<double>(a) * a;
     s[1] += static_cast<double>(b) * b;
-    const T r = XSIDE ? dot[1] + h0 + c_old * p.zt - p.ycur : dot[1] - h0;
-    s[2] += static_cast<double>(r) * r;
+    if constexpr (ND > 1) {   // (ND = 1: the pass without the exact residuals, dense_solver.h: lean iterations)
+      const T r = XSIDE ? dot[1] + h0 + c_old * p.zt - p.ycur : dot[1] - h0;
+      s[2] += static_cast<double>(r) * r;
+    }
     const T ztn = p.ytemp - yn;
     ytemp[i] = ztn;
     const T zts = zs * ztn;
@@ -458,7 +460,7 @@ struct FusedIterOp {
     s[4] += static_cast<double>(w) * w;
     s[5] += static_cast<double>(h) * h;
     u[0] = yh;
-    u[1] = XSIDE ? h : h + zts - yn;
+    if constexpr (NA > 1) u[1] = XSIDE ? h : h + zts - yn;
   }
   template <int NA>
   __device__ __forceinline__ void uonly(int, T (&)[NA]) const {}

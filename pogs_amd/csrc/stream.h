@@ -750,14 +750,17 @@ inline bool stream2_supported(const StreamPlan &p) {
 // Rows per workgroup step of the two-accumulator kernel: as many as the register file
 // allows (4*NV*(R + 1 + 2) + ~70 VGPRs <= 256), so the per-row functor latency (one lane per
 // row) is amortised over R rows.
-constexpr int stream2_rows_c(int nd, int nv) {
-  return nd > 0 ? (nv <= 2 ? 8 : nv <= 4 ? 4 : nv == 5 ? 2 : nv <= 6 ? 3 : nv <= 8 ? 2 : 1) : (nv <= 4 ? 8 : nv <= 8 ? 4 : 2);
+// (one dot product and one accumulator -- the pass without the exact residuals -- leave room for a
+// second row at 8 .. 10 vectors per thread: 4*NV*(R + 1 + 1) + ~70)
+constexpr int stream2_rows_c(int nd, int nv, int na = 2) {
+  return nd > 0 ? ((nd == 1 && na == 1 && nv > 8) ? 2 : (nv <= 2 ? 8 : nv <= 4 ? 4 : nv == 5 ? 2 : nv <= 6 ? 3 : nv <= 8 ? 2 : 1))
+                : (nv <= 4 ? 8 : nv <= 8 ? 4 : 2);
 }
-template <int ND>
-inline int stream2_rows(const StreamPlan &p) { return stream2_rows_c(ND, p.nv); }
-template <int ND>
+template <int ND, int NA = 2>
+inline int stream2_rows(const StreamPlan &p) { return stream2_rows_c(ND, p.nv, NA); }
+template <int ND, int NA = 2>
 inline int stream2_grid(const StreamPlan &p, int m) {
-  const int R = stream2_rows<ND>(p);
+  const int R = stream2_rows<ND, NA>(p);
   const int nblk = (m + R - 1) / R;
   const int gmax = ND > 0 ? p.grid_max : p.grid_dot;   // (the column-sum-only form keeps the two-per-CU grid)
   return nblk < gmax ? (nblk > 0 ? nblk : 1) : gmax;
@@ -766,11 +769,11 @@ inline int stream2_grid(const StreamPlan &p, int m) {
 template <typename T, int ND, int NA, typename Tag = AllPlans, typename Op>
 void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, hipStream_t s) {
   POGS_CHECK(stream2_supported(p), "plan not supported by the two-accumulator kernel");
-  const int grid = stream2_grid<ND>(p, a.m);
+  const int grid = stream2_grid<ND, NA>(p, a.m);
 #define POGS_STREAM2_CASE(TPB_, NV_)                                                            \
   if constexpr (Tag::has(TPB_, NV_) && TPB_ != 1024)                                            \
   if (p.tpb == TPB_ && p.nv == NV_) {                                                           \
-    constexpr int R_ = stream2_rows_c(ND, NV_);                                                 \
+    constexpr int R_ = stream2_rows_c(ND, NV_, NA);                                             \
     const size_t lds = (ND > 1) ? static_cast<size_t>(a.n_pad) * sizeof(T) : 0;                 \
     static SmemGrants grants;   /* per device; concurrent solvers share it */                   \
     ensure_dynamic_smem(reinterpret_cast<const void *>(&stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>), lds, grants); \
