@@ -26,10 +26,19 @@
 //   * bytes per non-zero: 4 (value) + 2 (local column) + 2 (tag) = the 8 of CSR (s + 4), no row
 //     offsets and no x traffic from HBM.
 //
-// Pipeline: a wavefront walks its batches (2 wave-rows each) of all tiles of the workgroup as one
-// sequence with 6 batches (36 loads) in flight, also across tile boundaries -- a fetch needs no
-// LDS -- and the x slice of the next tile waits in registers, requested one tile ahead, so a tile
-// boundary costs two barriers and the LDS stores, no memory latency.
+//   * in memory a tile is a sequence of STEPS: step b holds batch b (4 elements per lane) of each of
+//     the workgroup's 8 wavefronts side by side, so the workgroup reads 8 KB of values and 4 KB of
+//     each index array contiguously per step and walks forward through its tiles -- one
+//     sequential stream per array and workgroup instead of one per wavefront (round 4: 145 -> 142 us
+//     at C4; putting the three arrays into one stream gave nothing more).
+//
+// Pipeline: a wavefront walks its batches of all tiles of the workgroup as one sequence with 8
+// batches (24 loads) in flight, also across tile boundaries -- a fetch needs no LDS -- and the x
+// slice of the next tile waits in registers, requested one tile ahead, so a tile boundary costs two
+// barriers and the LDS stores, no memory latency.  What bounds the kernel is this load stream alone
+// (round 4, profiles/NOTES_r04.md: with the gathers and row-sum updates compiled out it takes 142.8
+// instead of 145.2 us; ring depths 4 / 6 / 8 are equal, 12 slower; the LDS reads of the next batch
+// requested ahead of this batch's stores: no change).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -64,7 +73,8 @@ struct SellView {
 
 // One batch = kSellUB consecutive elements of every lane's stream, stored lane-major: the values of
 // a lane are one 16-byte (fp32) vector, its local columns and row tags one 8-byte vector each, so a
-// wavefront fetches a batch with three fully coalesced wide loads.
+// wavefront fetches a batch with three fully coalesced wide loads; batch b of wavefront w of a tile
+// sits at element (first unit of the tile) * 64 + (b * 8 + w) * 256.
 template <typename T>
 struct SellBatch {
   T v[kSellUB];
@@ -250,13 +260,13 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
         f_cb = nx;
         f_nb = K / UB;
         f_b = 0;
-        f_e0 = (static_cast<size_t>(u0) + static_cast<size_t>(wave) * K) * 64 + lane * UB;
+        f_e0 = static_cast<size_t>(u0) * 64 + static_cast<size_t>(wave) * (UB * 64) + lane * UB;
       } else {
         f_b = f_nb > 0 ? f_nb - 1 : 0;   // past the end: the last batch again (never consumed)
         f_cb = cb1;
       }
     }
-    e0 = f_e0 + static_cast<size_t>(f_b) * (UB * 64);
+    e0 = f_e0 + static_cast<size_t>(f_b) * (kSellWaves * UB * 64);
     first = f_b == 0 && f_cb < cb1;
     ++f_b;
   };
@@ -472,10 +482,10 @@ __global__ void sell_fill_kernel(const T *val, const int *ind, const int *ptr, S
       const unsigned so = soff[idx];
       const int sidx = static_cast<int>(so >> kSellOffBits), off = static_cast<int>(so & ((1u << kSellOffBits) - 1));
       const int u0 = tile_unit[tile];
-      const int K = (tile_unit[tile + 1] - u0) / kSellWaves;
-      const int k_el = off + j;   // position in the lane's stream: batch k_el / UB, lane-major inside the batch
-      const size_t dst = (static_cast<size_t>(u0) + static_cast<size_t>(sidx >> 6) * K) * 64 +
-                         static_cast<size_t>(k_el / kSellUB) * (64 * kSellUB) + (sidx & 63) * kSellUB + (k_el % kSellUB);
+      const int k_el = off + j;   // position in the lane's stream: step k_el / UB, wavefront-, then lane-major inside the step
+      const size_t dst = static_cast<size_t>(u0) * 64 +
+                         (static_cast<size_t>(k_el / kSellUB) * kSellWaves + (sidx >> 6)) * (64 * kSellUB) +
+                         (sidx & 63) * kSellUB + (k_el % kSellUB);
       sval[dst] = val[k];
       if (dst_out) dst_out[k] = static_cast<unsigned>(dst);
       if (sloc) {
