@@ -23,3 +23,5 @@ for d in sorted(glob.glob("$O/*/")):
                 agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
         print({c: "%.4g" % (x / max(n[c], 1)) for c, x in agg.items()}, "launches", max(n.values()) if n else 0)
 PY
+# the raw per-launch counter tables are large (gpurun copies at most 64 MiB back): keep the logs only
+find $O -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
