@@ -19,9 +19,3 @@ SolverBase *POGS_CAT(make_dense_solver_, POGS_PLAN_NAME)(int ord, size_t m, size
   return make_dense_solver_t<POGS_PLAN_T, PlanTag>(ord, m, n, A, mem, opt, dist);
 }
 }  // namespace pogs_amd
-
-#ifdef POGS_STREAM_DBG_EXPORT
-extern "C" int PogsAmdDebugStreamTimes(unsigned long long *out, int n) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pogs_amd::g_stream_dbg), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
-}
-#endif

@@ -607,14 +607,8 @@ struct StreamArgs2 {
 // 0.35 us per step.  At the C3 shape the R * NV extra vector registers take the kernel from three
 // to two workgroups per CU and the pass from 0.692 to 0.715 ms: resident workgroups hide the
 // functor better than a prefetch does.)
-#ifdef POGS_STREAM_DBG
-static __device__ unsigned long long g_stream_dbg[4096];
-#endif
 template <typename T, int TPB, int NV, int R, int ND, int NA, typename Op>
 __global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op op) {
-#ifdef POGS_STREAM_DBG
-  if (threadIdx.x == 0 && blockIdx.x < 1024) g_stream_dbg[4 * blockIdx.x] = wall_clock64();
-#endif
   using V = typename Vec16<T>::type;
   constexpr int VEC = Vec16<T>::N;
   constexpr int NW = TPB / 64;
@@ -727,16 +721,6 @@ __global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op 
         for (int v = 0; v < NV; ++v) dev::vfma(acc[q][v], uu[q], av[r][v]);
     }
   }
-#ifdef POGS_STREAM_DBG
-  if (threadIdx.x == 0 && blockIdx.x < 1024) {
-    g_stream_dbg[4 * blockIdx.x + 1] = wall_clock64();
-    unsigned xcc, hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    g_stream_dbg[4 * blockIdx.x + 2] = xcc;
-    g_stream_dbg[4 * blockIdx.x + 3] = hwid;
-  }
-#endif
 #pragma unroll
   for (int q = 0; q < NA; ++q) {
     T *out = (q == 0 ? a.col_partials0 : a.col_partials1) + static_cast<size_t>(blockIdx.x) * a.n_pad;
