@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np
 os.environ.setdefault("POGS_AMD_TORCH_PRELOAD", "0")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pogs_amd
 from pogs_amd import synth
 A, b, _ = synth.csr_lasso(2000000, 500000, 50, seed=4, dtype=np.float32)

@@ -1,4 +1,6 @@
 #!/bin/bash
+# Development aid: kernel times of the C4 SpMVs (rocprofv3 --kernel-trace --stats over scripts/spmv_probe.py) for one or more
+# builds of the library: spmv_probe.sh <tag>[:ENV=value...] ...   (a tag names pogs_amd/variants/libpogs_amd_<tag>.so)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/probe
@@ -8,7 +10,7 @@ for tagenv in "$@"; do
   envs=$(echo $envs | tr ":" " ")
   cp $R/pogs_amd/variants/libpogs_amd_$tag.so $R/pogs_amd/libpogs_amd.so
   rm -rf /tmp/kt_$tag
-  env $envs timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt_$tag -o p -- python $R/scripts/tmp/spmv_probe.py > $R/gpurun_out/probe/$tag.log 2>&1
+  env $envs timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt_$tag -o p -- python $R/scripts/spmv_probe.py > $R/gpurun_out/probe/$tag.log 2>&1
   db=$(find /tmp/kt_$tag -name "*.db" | head -1)
   python $R/scripts/rocpd_summary.py $db $R/gpurun_out/probe/$tag.csv > /dev/null 2>&1
   python - <<PY
