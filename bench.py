@@ -41,7 +41,12 @@ between barrier + synchronize on both sides; when K steps take less than 0.1 s s
 windows are timed back to back and their mean is reported (`windows`, `window_s`).
 
 Inputs are resident in HBM when the timed region starts.  The JSON line carries `roofline`
-(the dominant kernel, timed with HIP events on the solver's stream over the timed region)
+(the dominant kernel, timed with HIP events on the solver's stream over the timed region;
+`roofline.traffic` of the headline workload is MEASURED BY THIS RUN at N = 1: after everything
+timed is done the script runs itself twice more for a few steps under `rocprofv3 --pmc
+FETCH_SIZE` / `--pmc WRITE_SIZE` -- about a minute, --no-live-traffic skips it -- and the
+committed counter summaries profiles/pmc_traffic_<config>.json stay in the line as
+`traffic_static`; the secondary workloads quote their committed summaries)
 and, at N = 1, `cpu_baseline`: the reference CPU path on the same (A, b, lambda) on this box's
 host cores, WHOLE workload (no row sample, nothing scaled).  Dense: the compiled reference in
 both BLAS builds -- oracle/_ref/libpogs_cpu_openblas.so (scipy's OpenBLAS, which threads its
@@ -95,6 +100,10 @@ def parse():
                     help="dense configurations: 'cgls' selects the matrix-free CGLS projector (the reference's "
                          "ProjectorCgls on a dense matrix, src/cpu/projector/projector_cgls.cpp) instead of the direct one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc passes of the headline "
+                         "workload, spawned after the timed part); the committed counter summary is quoted instead")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # the spawned pass itself
     ap.add_argument("--cpu-budget-s", type=float, default=600.0,
                     help="time-out of the reference's run of the whole workload (the CPU baseline)")
     ap.add_argument("--cpu-iters", type=int, default=60, help="ADMM iterations of the reference's whole-workload run")
@@ -366,6 +375,83 @@ def pmc_traffic(name, kernel_substr):
         return None, None, None
 
 
+def live_traffic(name, kernel_substr, budget_s=150.0):
+    """HBM bytes per launch of the dominant kernel MEASURED NOW: this script again on the same
+    workload (a few steps) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes,
+    kernel trace only), summarised exactly as scripts/pmc_summary.py does -- FETCH_SIZE / WRITE_SIZE are
+    KiB, the read side doubled (guides/MI355X_MICROARCH.md: gfx950 reports half of a wide coalesced
+    streaming read), launches of the device-resident CG loop that returned at once left out.
+    Returns (bytes per launch, description) or (None, reason)."""
+    import csv
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this run is itself being profiled"
+    tmp = tempfile.mkdtemp(prefix="pogs_pmc_", dir="/tmp")
+    t_start = time.time()
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "g", "--",
+                   sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "10", "--warmup", "2",
+                   "--traffic-child", "--no-cpu-baseline", "--no-secondary", "--no-live-traffic"]
+            left = budget_s - (time.time() - t_start)
+            if left < 20:
+                return None, "time budget of the counter passes used up"
+            env = dict(os.environ, TMPDIR="/tmp")
+            # its own process group, so that a pass that hangs can be ended together with whatever it started
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                  start_new_session=True)
+            try:
+                rc = pr.wait(timeout=left)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.wait()
+                return None, "the %s pass ran into its time budget" % counter
+            if rc != 0:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, rc)
+            per_launch = []
+            for root, _, files in os.walk(out):
+                for fn in files:
+                    if not fn.endswith("counter_collection.csv"):
+                        continue
+                    with open(os.path.join(root, fn)) as fh:
+                        for row in csv.DictReader(fh):
+                            if row["Counter_Name"] != counter:
+                                continue
+                            kn = re.sub(r"pogs_amd::|\(anonymous namespace\)::", "", row["Kernel_Name"])
+                            if kernel_substr in kn:
+                                per_launch.append(float(row["Counter_Value"]))
+            if not per_launch:
+                return None, "no launch of the kernel in the %s pass" % counter
+            vals[counter] = per_launch
+        f, w = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+        if len(f) == len(w) and max(f) > 0:
+            keep = [i for i in range(len(f)) if f[i] >= 0.02 * max(f)]
+            f, w = [f[i] for i in keep], [w[i] for i in keep]
+        fe, wr = sum(f) / len(f) * 1024.0, sum(w) / len(w) * 1024.0
+        return 2.0 * fe + wr, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (kernel trace only) of "
+                               "`bench.py --config %s --steps 10 --warmup 2` spawned after the timed part, %d launches of the "
+                               "kernel, read side x 2 (the gfx950 half count of wide streaming reads), %.0f s for both passes"
+                               % (name, len(f), time.time() - t_start))
+    except Exception as e:   # a profiler hiccup must not cost the bench line
+        return None, "counter pass: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def unsharded_parity(cfg, m, n, world, dev, local, res, shard_b_sums):
     """Rank 0, after the timed region of an N > 1 run: regenerates every rank's rows (torch_rows with the
     ranks' seeds, on this device), checks them against the sums of b the ranks reported, solves the whole
@@ -531,7 +617,7 @@ def run_config(env, name, with_cpu):
     # (the reference builds and destroys its solver inside PogsD/PogsS, src/interface_c/pogs_c.cpp:19-20);
     # the library's device pool (pogs_amd/csrc/common.h) is what keeps every cycle at the speed of the fastest
     cycles = None
-    if world == 1 and dist is None:
+    if world == 1 and dist is None and not args.traffic_child:
         from pogs_amd import _lib as L
 
         p0 = L.pool_stats(local)
@@ -638,7 +724,7 @@ def run_config(env, name, with_cpu):
                                             % (traffic_src, "collected on the kernel sources of this build" if traffic_fresh
                                                else "STALE: the kernel sources have changed since the counters were collected"
                                                if traffic_fresh is False else "no source hash in the file")) if traffic_src else None,
-                         "kernel": kernel, "bytes_per_launch": bytes_per_launch,
+                         "kernel": kernel, "counter_kernel_match": kernel_key, "bytes_per_launch": bytes_per_launch,
                          "avg_launch_ms": avg_ms, "launches": st["stream_launches"],
                          "launch_sampling": "HIP events around every %d-th launch of the kernel in the timed region" % PROFILE_EVERY,
                          "iteration": iteration},
@@ -714,6 +800,17 @@ def main():
                 sec[name] = {"value": None, "error": repr(e)[:300]}
         if line is not None:
             line["secondary"] = sec
+    # roofline.traffic of the headline workload from counters collected NOW (everything timed is done; the
+    # committed summary stays in the line as `traffic_static` for comparison)
+    if line is not None and env.world == 1 and not args.no_live_traffic and not args.traffic_child \
+            and not (args.m or args.n) and args.projector == "default":
+        rf = line["roofline"]
+        live, how = live_traffic(head, rf["counter_kernel_match"])
+        if live is not None:
+            rf["traffic_static"] = {"traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source")}
+            rf["traffic"], rf["traffic_source"] = live, how
+        else:
+            rf["traffic_live"] = "not measured: " + how
     out_line = json.dumps(line) if line is not None else None
     # The JSON line must be the LAST line of the job's stdout.  C libraries print through stdio
     # (RCCL's version banner: on a pipe it sits in the buffer until exit), so every rank empties

@@ -10,7 +10,7 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS" \
          "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE"; do
   n=$(echo $c | tr " " "_" | cut -c1-60)
-  env "$@" timeout 280 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$n -o g -- python $R/bench.py --config c4 --steps 20 --warmup 5 --no-cpu-baseline > $O/$n.log 2>&1
+  env "$@" timeout 280 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$n -o g -- python $R/bench.py --config c4 --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic > $O/$n.log 2>&1
 done
 python - <<PY
 import csv, glob, collections

@@ -12,11 +12,11 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cat $R/pogs_amd/libpogs_amd.so > /dev/null   # fresh box: page cache cold, the first process would pay the disk reads
 python -c 'import torch; torch.zeros(1, device="cuda")' > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python $R/bench.py --config $cfg --steps 200 --warmup 20 --no-cpu-baseline > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python $R/bench.py --config $cfg --steps 200 --warmup 20 --no-cpu-baseline --no-live-traffic > $O/kt.log 2>&1
 db=$(find $O/kt -name "*.db" | head -1)
 python $R/scripts/rocpd_summary.py $db $O/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o g -- python $R/bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o g -- python $R/bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic > $O/pmc_$c.log 2>&1
 done
 python $R/scripts/pmc_summary.py $(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json
 rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE

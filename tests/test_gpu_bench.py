@@ -40,6 +40,11 @@ def test_default_invocation_carries_the_contract_fields_and_the_secondary_worklo
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert 0.5 < rf["frac"] < 1.0 and abs(rf["bytes_per_launch"] - 4.0e9) < 1e6
+    # roofline.traffic comes from counters collected BY THIS RUN (two short rocprofv3 --pmc passes of the headline
+    # workload after the timed part); the committed summary rides along for comparison
+    assert rf["traffic_source"].startswith("measured in this run"), rf.get("traffic_live", rf["traffic_source"])
+    assert 0.97 * 4.0e9 < rf["traffic"] < 1.10 * 4.0e9, rf["traffic"]
+    assert "traffic_static" in rf
     assert abs(d["value"] - 1e3 * 1 / d["ms_per_step"]) <= 1e-6 * d["value"]
     assert d["solve_status"] == 0 and 95 <= d["solve_iterations"] <= 117          # the fixture problem: 106
     sec = d["secondary"]
@@ -74,7 +79,7 @@ def test_one_rank_rccl_path_runs_the_bench_command_at_the_plain_speed(plain, cfg
     device-resident CGLS loop with ONE grouped all-reduce per CG step on the stream (t = A^T q and the
     |q|^2 records; A^T r by recurrence) and no host poll inside the projection: measured on one box,
     alternating, -1.5 / -2.2 / -1.9 % against the plain run (scripts/c4_one_rank.sh)."""
-    d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--config", cfg],
+    d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-live-traffic", "--config", cfg],
                {"POGS_AMD_FORCE_DIST": "1"})
     ref = plain if cfg == "c2" else plain["secondary"][cfg]
     assert d["config"]["rccl_nranks"] == 1 and d["n_gpus"] == 1
