@@ -404,7 +404,7 @@ def live_traffic(name, kernel_substr, budget_s=150.0):
                    "--traffic-child", "--no-cpu-baseline", "--no-secondary", "--no-live-traffic"]
             left = budget_s - (time.time() - t_start)
             if left < 20:
-                return None, "time budget of the counter passes used up"
+                return None, "time: budget of the counter passes used up"
             env = dict(os.environ, TMPDIR="/tmp")
             # its own process group, so that a pass that hangs can be ended together with whatever it started
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
@@ -419,7 +419,7 @@ def live_traffic(name, kernel_substr, budget_s=150.0):
                 except OSError:
                     pass
                 pr.wait()
-                return None, "the %s pass ran into its time budget" % counter
+                return None, "time: the %s pass ran into its budget" % counter
             if rc != 0:
                 return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, rc)
             per_launch = []
@@ -775,7 +775,11 @@ def run_config(env, name, with_cpu):
     return line
 
 
+LIVE_TRAFFIC_LATEST_START_S = 300.0   # the counter passes are skipped when the run has already taken longer (a cold box)
+
+
 def main():
+    t_main = time.time()
     args = parse()
     maybe_spawn(args)
     import oracle_binding as ob
@@ -805,7 +809,11 @@ def main():
     if line is not None and env.world == 1 and not args.no_live_traffic and not args.traffic_child \
             and not (args.m or args.n) and args.projector == "default":
         rf = line["roofline"]
-        live, how = live_traffic(head, rf["counter_kernel_match"])
+        if time.time() - t_main > LIVE_TRAFFIC_LATEST_START_S:
+            live, how = None, "time: the run had already taken %.0f s (limit %.0f s for starting the counter passes)" % (
+                time.time() - t_main, LIVE_TRAFFIC_LATEST_START_S)
+        else:
+            live, how = live_traffic(head, rf["counter_kernel_match"])
         if live is not None:
             rf["traffic_static"] = {"traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source")}
             rf["traffic"], rf["traffic_source"] = live, how

@@ -42,9 +42,13 @@ def test_default_invocation_carries_the_contract_fields_and_the_secondary_worklo
     assert 0.5 < rf["frac"] < 1.0 and abs(rf["bytes_per_launch"] - 4.0e9) < 1e6
     # roofline.traffic comes from counters collected BY THIS RUN (two short rocprofv3 --pmc passes of the headline
     # workload after the timed part); the committed summary rides along for comparison
-    assert rf["traffic_source"].startswith("measured in this run"), rf.get("traffic_live", rf["traffic_source"])
+    # (on a box so cold that the run is already minutes old the passes are skipped and the line says so)
+    if "traffic_live" in rf:
+        assert rf["traffic_live"].startswith("not measured: time"), rf["traffic_live"]
+    else:
+        assert rf["traffic_source"].startswith("measured in this run"), rf["traffic_source"]
+        assert "traffic_static" in rf
     assert 0.97 * 4.0e9 < rf["traffic"] < 1.10 * 4.0e9, rf["traffic"]
-    assert "traffic_static" in rf
     assert abs(d["value"] - 1e3 * 1 / d["ms_per_step"]) <= 1e-6 * d["value"]
     assert d["solve_status"] == 0 and 95 <= d["solve_iterations"] <= 117          # the fixture problem: 106
     sec = d["secondary"]
