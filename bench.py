@@ -107,6 +107,8 @@ def parse():
     ap.add_argument("--cpu-budget-s", type=float, default=600.0,
                     help="time-out of the reference's run of the whole workload (the CPU baseline)")
     ap.add_argument("--cpu-iters", type=int, default=60, help="ADMM iterations of the reference's whole-workload run")
+    ap.add_argument("--cpu-best-only", action="store_true",
+                    help="time only the best BLAS build of the reference (what an N > 1 run does while the other ranks wait)")
     ap.add_argument("--cpu-full", action="store_true", help="run the reference to convergence instead (c2 on the GPU "
                                                             "box's host: max_iter, about twenty minutes)")
     return ap.parse_args()
@@ -257,9 +259,36 @@ def parity_from_fixture(cfg, fx, engine):
 CPU_PLAN = {"c2": [("openblas", 400), ("mkl", "cap")], "c3": [("openblas", None)]}
 
 
-def cpu_baseline(name, cfg, A_host, f, g, args, engine):
+def extrapolate_cpu(out, world, m, n):
+    """N > 1: `out` was measured on rank 0's OWN shard (m x n, a whole problem of one GPU's size).  The job's
+    problem has N m rows -- more elements than the reference can index at C5 (8e9: its vector and matrix views
+    carry int sizes, src/cpu/include/gsl/gsl_vector.h:135-138, gsl_blas.h:34-37) -- and every per-iteration term of
+    the reference (two gemv passes, the prox over m, the BLAS-1 algebra) is linear in m at fixed n, so its
+    iteration time is taken as N x the shard's ("extrapolate t_iter ~ m from C2 and say
+    so").  `value` becomes the whole problem's ADMM it/s; the measured rate stays as `value_on_one_shard`, which is
+    ALSO the CPU's figure in the line's own unit (shard iterations per second summed over the job: N shards at
+    1 / (N t_iter) each)."""
+    v = out.get("value")
+    if v is None or world <= 1:
+        return out
+    out["value_on_one_shard"] = v
+    out["value"] = v / world
+    out["unit"] = "it/s of the whole %d x %d problem" % (m * world, n)
+    out["value_in_metric_unit"] = v
+    out["extrapolated"] = ("t_iter ~ m (SURVEY.md section 8(d)): measured on rank 0's %d x %d shard, divided by N = %d; the "
+                           "reference cannot index the whole problem's %.1e elements at C5 (gsl_vector.h:135-138, "
+                           "gsl_blas.h:34-37)" % (m, n, world, float(m) * world * n))
+    for k in ("time_to_converge_s", "init_s", "loop_s"):
+        if k in out:
+            out[k + "_on_one_shard"] = out.pop(k)
+    out["sample"] = "rank 0's shard as a problem of its own (%s)" % out.get("sample", "")
+    return out
+
+
+def cpu_baseline(name, cfg, A_host, f, g, args, engine, world=1):
     """Times the reference CPU path on this box's host cores, on the SAME (A, f, g), WHOLE workload:
     no row sample, nothing scaled.  Returns (cpu_baseline dict, live parity dict or None).
+    (world > 1: rank 0's own shard, one build only, extrapolate_cpu() applied -- see there.)
 
     Dense (c2, c3): the compiled reference (`kind` "reference"; a clean subprocess -- it must not share
     a process with torch), `value` = iterations / (Total - Init) from its own summary line
@@ -296,9 +325,14 @@ def cpu_baseline(name, cfg, A_host, f, g, args, engine):
                    sample="whole workload %dx%d nnz %d fp32 to convergence, OpenMP oracle port (oracle/pogs_oracle.cpp, pinned to "
                           "the reference in tests/), %d threads: %d iterations, total %.1f s, init %.1f s"
                           % (m, n, A_host.nnz, ob.cpu_quota(), iters, t_init + t_loop, t_init))
+        if world > 1:
+            return extrapolate_cpu(out, world, m, n), None
         return out, _parity(engine, r["x"], r["optval"], iters, "oracle port, same A, b, lambda, default tolerances, whole workload, this run")
     builds, live = {}, None
-    for blas, cap in CPU_PLAN.get(name, [("openblas", "cap")]):
+    plan = CPU_PLAN.get(name, [("openblas", "cap")])
+    if world > 1 or args.cpu_best_only:
+        plan = plan[:1]   # the best build only: the other ranks are waiting
+    for blas, cap in plan:
         if not ob.ref_available(blas):
             builds[blas] = {"value": None, "sample": "oracle/_ref build for %s missing" % blas}
             continue
@@ -336,6 +370,8 @@ def cpu_baseline(name, cfg, A_host, f, g, args, engine):
     out.update({k: ok[best][k] for k in ("value", "init_s", "loop_s", "iterations", "converged", "sample")})
     if "time_to_converge_s" in ok[best]:
         out["time_to_converge_s"] = ok[best]["time_to_converge_s"]
+    if world > 1:
+        return extrapolate_cpu(out, world, m, n), None   # (the shard alone is not the sharded problem: no live parity)
     return out, live
 
 
@@ -375,7 +411,7 @@ def pmc_traffic(name, kernel_substr):
         return None, None, None
 
 
-def live_traffic(name, kernel_substr, budget_s=150.0):
+def live_traffic(name, kernel_substr, budget_s=150.0, device_index=None):
     """HBM bytes per launch of the dominant kernel MEASURED NOW: this script again on the same
     workload (a few steps) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes,
     kernel trace only), summarised exactly as scripts/pmc_summary.py does -- FETCH_SIZE / WRITE_SIZE are
@@ -405,7 +441,18 @@ def live_traffic(name, kernel_substr, budget_s=150.0):
             left = budget_s - (time.time() - t_start)
             if left < 20:
                 return None, "time: budget of the counter passes used up"
-            env = dict(os.environ, TMPDIR="/tmp")
+            # the pass is a ONE-GPU run of the workload (at N > 1: of one rank's shard size -- the kernel, its
+            # arguments and its traffic are the same on every rank): nothing of this job's launcher, rendezvous or
+            # forced-communicator environment may reach it
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME",
+                                "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "POGS_AMD_FORCE_DIST",
+                                "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+                                "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_ERROR_FILE", "OMP_NUM_THREADS")
+                   and not k.startswith("TORCHELASTIC_")}
+            env["TMPDIR"] = "/tmp"
+            if device_index is not None:
+                env["HIP_VISIBLE_DEVICES"] = str(device_index)   # rank 0's GPU (the others are idle, waiting)
             # its own process group, so that a pass that hangs can be ended together with whatever it started
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                   start_new_session=True)
@@ -505,10 +552,25 @@ class Env:
         if self.world > 1 or self.force_dist:
             import torch.distributed as dist
 
+            import datetime
+
             if self.force_dist and "MASTER_ADDR" not in os.environ:
-                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
-            dist.init_process_group("nccl")
+                with socket.socket() as sk:   # a free port: the counter passes' children and other tests may run beside us
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+            # rank 0 works alone for minutes after the timed region (the CPU baseline, the unsharded parity solve,
+            # the counter passes): no collective may time out meanwhile
+            dist.init_process_group("nccl", timeout=datetime.timedelta(minutes=60))
             self.dist = dist
+            # the other ranks wait for rank 0 on sockets (gloo), not spinning on a GPU collective: rank 0's CPU
+            # baseline needs the host cores
+            try:
+                self.wait_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=60))
+            except Exception:
+                self.wait_group = None
+
+    wait_group = None
 
     def barrier(self):
         import torch
@@ -517,6 +579,17 @@ class Env:
         if self.dist is not None:
             self.dist.barrier()
         torch.cuda.synchronize()
+
+    def long_barrier(self):
+        """Ranks meet after a stretch in which rank 0 worked alone (host-side wait where gloo is there)."""
+        import torch
+
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            if self.wait_group is not None:
+                self.dist.barrier(group=self.wait_group)
+            else:
+                self.dist.barrier()
 
 
 def run_config(env, name, with_cpu):
@@ -641,6 +714,62 @@ def run_config(env, name, with_cpu):
                   "pool": {"hipMalloc_calls": p1["mallocs"] - p0["mallocs"], "hipFree_calls": p1["frees"] - p0["frees"],
                            "blocks_reused": p1["reuses"] - p0["reuses"], "cached_bytes": p1["cached_bytes"]}}
 
+    # The same create + solve with the setup's two default-on shortcuts switched off (the fp32 Gram product on the
+    # native fp32 MFMA instead of the two-way fp16 split, all 50 Sinkhorn-Knopp passes): what the default saves, and
+    # what a caller who wants the reference's setup arithmetic to the last bit pays.
+    exact_setup = None
+    if not sparse and cfg["dtype"] == "f32" and world == 1 and dist is None and not args.traffic_child \
+            and args.projector == "default":
+        saved = {k: os.environ.get(k) for k in ("POGS_AMD_GRAM", "POGS_AMD_SK_FULL")}
+        os.environ.update(POGS_AMD_GRAM="fp32", POGS_AMD_SK_FULL="1")   # read at handle creation
+        try:
+            torch.cuda.synchronize()
+            t0 = time.time()
+            s_ = create()
+            t1 = time.time()
+            r_ = s_.solve(f, g)
+            t2 = time.time()
+            st_ = s_.stats()
+            s_.close()
+            exact_setup = {"time_to_converge_s": t2 - t0, "init_s": t1 - t0, "iterations": r_["iterations"] + 1,
+                           "status": r_["status"], "gram_ms": st_["gram_ms"], "equil_ms": st_["equil_ms"],
+                           "rel_x_vs_default_setup": float(np.linalg.norm(r_["x"].astype(np.float64) - res["x"].astype(np.float64))
+                                                           / max(np.linalg.norm(res["x"].astype(np.float64)), 1e-300)),
+                           "switches": "POGS_AMD_GRAM=fp32 POGS_AMD_SK_FULL=1"}
+        except Exception as e:
+            exact_setup = {"error": repr(e)[:300]}
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    # What a caller of the reference's one-shot entry point sees (src/interface_c/pogs_c.cpp:19-52: PogsS / PogsD with
+    # a HOST matrix; the totals it prints, src/cpu/pogs.cpp:485-490): the whole call with the upload of A inside it.
+    # The upload is reported on its own ("H2D separately") from a handle created on the
+    # same host buffer, whose t_h2d_s is the copy alone.  Never part of `value`.
+    one_shot = None
+    if not sparse and A_host is not None and world == 1 and dist is None and not args.traffic_child \
+            and args.projector == "default" and (m, n) == (cfg["m"], cfg["n"]):
+        try:
+            torch.cuda.synchronize()
+            t0 = time.time()
+            r_ = G._solve_graph_form(A_host, f, g, dtype=np_dtype)
+            t_call = time.time() - t0
+            t0 = time.time()
+            with pogs_amd.Solver(A_host, dtype=np_dtype, device=local) as s_:
+                t_create = time.time() - t0
+                st_ = s_.stats()
+            one_shot = {"one_shot_host_call_s": t_call, "h2d_s": st_["t_h2d_s"], "create_from_host_s": t_create,
+                        "iterations": r_["iterations"] + 1, "status": r_["status"],
+                        "h2d_gb_per_s": float(m) * n * esize / max(st_["t_h2d_s"], 1e-9) / 1e9,
+                        "what": "%s(ROW_MAJ, host A, ...) through the C ABI, wall clock around the call: upload of A (pageable "
+                                "host memory) + setup + loop + results back" % ("PogsD" if cfg["dtype"] == "f64" else "PogsS")}
+            assert r_["iterations"] == res["iterations"] and r_["status"] == res["status"]
+        except Exception as e:
+            one_shot = {"error": repr(e)[:300]}
+
     # N > 1: the shards are row ranges of ONE problem; rank 0 regenerates it whole and, when it fits,
     # solves it unsharded -- the sharded solution must land on that solve's
     unsharded = None
@@ -653,9 +782,20 @@ def run_config(env, name, with_cpu):
                 unsharded = unsharded_parity(cfg, m, n, world, dev, local, res, [float(v.item()) for v in sums])
             except Exception as e:   # never take the line down
                 unsharded = {"error": repr(e)[:300]}
-        env.barrier()
+        env.long_barrier()
 
     line = None
+    if rank == 0 and getattr(env, "peak_measured", None) is None and not args.traffic_child:
+        # the measured read ceiling of THIS device next to the data-sheet peak ("state
+        # both"): the library's read-bandwidth probe on 4 GB, nothing else running on the GPU
+        try:
+            from pogs_amd import _lib as L
+
+            torch.cuda.synchronize()
+            gbs, pat = L.read_bandwidth(local, 4 << 30, 10)
+            env.peak_measured = {"gb_per_s": gbs, "pattern": pat}
+        except Exception as e:
+            env.peak_measured = {"gb_per_s": None, "error": repr(e)[:200]}
     if rank == 0:
         its = world * args.steps / elapsed
         launches = max(st["stream_launches"], 1)
@@ -715,10 +855,21 @@ def run_config(env, name, with_cpu):
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
             "windows": windows, "window_s": times,
+            # (the scalars a reader of the driver's record needs sit in `config` and `roofline`, which it keeps whole:
+            # wall-clock-to-converge is half of BASELINE.json's metric)
             "config": {"workload": workload, "name": name, "rows_per_gpu": m, "cols": n, "projector": projector,
-                       "parallelism": "row-shard x%d" % world, "rccl_nranks": nranks_comm},
+                       "parallelism": "row-shard x%d" % world, "rccl_nranks": nranks_comm,
+                       "time_to_converge_s": init_s + solve_s, "init_s": init_s, "loop_s": st_solve["t_loop_s"],
+                       "solve_iterations": res["iterations"] + 1, "solve_status": res["status"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "peak_datasheet": HBM_PEAK_GBS,
+                         "peak_measured": (getattr(env, "peak_measured", None) or {}).get("gb_per_s"),
+                         "frac_of_peak_measured": (achieved / env.peak_measured["gb_per_s"]
+                                                   if (getattr(env, "peak_measured", None) or {}).get("gb_per_s") else None),
+                         "peak_measured_how": "PogsAmdReadBandwidth: best of two read-only kernels over 4 GB on this device, "
+                                              "10 launches each (pattern: %s)" % (getattr(env, "peak_measured", None) or {}).get("pattern"),
+                         "iteration_frac": iteration["frac"],
                          "traffic_source": ("static: %s (rocprofv3 --pmc passes of this command, committed; not "
                                             "measured in this run; %s)"
                                             % (traffic_src, "collected on the kernel sources of this build" if traffic_fresh
@@ -745,6 +896,16 @@ def run_config(env, name, with_cpu):
             line["gram_tflops"] = st_solve["gram_flops"] / max(st_solve["gram_ms"], 1e-9) / 1e9
         if cycles is not None:
             line["handle_cycles"] = cycles
+            line["config"]["handle_cycles_max_time_to_converge_s"] = cycles["max_time_to_converge_s"]
+            line["config"]["handle_cycles_max_init_s"] = cycles["max_init_s"]
+        if exact_setup is not None:
+            line["exact_setup"] = exact_setup
+            line["time_to_converge_exact_setup_s"] = exact_setup.get("time_to_converge_s")
+            line["config"]["time_to_converge_exact_setup_s"] = exact_setup.get("time_to_converge_s")
+        if one_shot is not None:
+            line["one_shot_host_call"] = one_shot
+            line["config"]["one_shot_host_call_s"] = one_shot.get("one_shot_host_call_s")
+            line["config"]["h2d_s"] = one_shot.get("h2d_s")
         if fixture is not None:
             try:
                 line["parity_vs_reference"] = parity_from_fixture(cfg, fixture, res)
@@ -752,6 +913,10 @@ def run_config(env, name, with_cpu):
                 line["parity_vs_reference"] = {"error": repr(e)[:300]}
         elif unsharded is not None:
             line["parity_vs_reference"] = unsharded
+    if rank == 0 and isinstance(line.get("parity_vs_reference"), dict) and "rel_x" in line["parity_vs_reference"]:
+        par = line["parity_vs_reference"]
+        line["config"]["parity_rel_x"] = par["rel_x"]
+        line["config"]["parity_iterations"] = "%d engine / %d reference" % (par["iterations_engine"], par["iterations_reference"])
     if rank == 0 and with_cpu and cfg["dtype"] == "f32":
         try:
             if sparse:
@@ -760,7 +925,7 @@ def run_config(env, name, with_cpu):
                 A_host = A.cpu().numpy()
             del A   # the GPU copy is not needed any more; the reference gets the host copy
             torch.cuda.empty_cache()
-            line["cpu_baseline"], live = cpu_baseline(name, cfg, A_host, f, g, args, res)
+            line["cpu_baseline"], live = cpu_baseline(name, cfg, A_host, f, g, args, res, world)
             if live is not None and "parity_vs_reference" in line:
                 line["parity_vs_reference"]["live_cpu_run"] = live
             elif live is not None:
@@ -775,7 +940,7 @@ def run_config(env, name, with_cpu):
     return line
 
 
-LIVE_TRAFFIC_LATEST_START_S = 300.0   # the counter passes are skipped when the run has already taken longer (a cold box)
+LIVE_TRAFFIC_LATEST_START_S = 420.0   # the counter passes are skipped when the run has already taken longer (a cold box)
 
 
 def main():
@@ -788,13 +953,14 @@ def main():
     os.environ.setdefault("OMP_NUM_THREADS", str(ob.cpu_quota()))
     env = Env(args)
     head = args.config or "c2"
-    line = run_config(env, head, with_cpu=env.world == 1 and not args.no_cpu_baseline)
+    # N > 1: rank 0 times the reference on its own shard after the timed region (cpu_baseline / extrapolate_cpu)
+    line = run_config(env, head, with_cpu=not args.no_cpu_baseline)
     # the driver's invocation (no --config, one GPU): c3, c4 (with their CPU legs) and c2 in fp64 under the same clock
     if args.config is None and env.world == 1 and not args.no_secondary and not (args.m or args.n) \
             and args.projector == "default":
         keep = ("metric", "value", "unit", "dtype", "ms_per_step", "steps", "windows", "window_s", "config", "roofline",
                 "time_to_converge_s", "init_s", "handle_cycles", "solve_iterations", "solve_status", "setup_ms", "gram_tflops",
-                "parity_vs_reference", "cpu_baseline")
+                "parity_vs_reference", "cpu_baseline", "exact_setup", "time_to_converge_exact_setup_s", "one_shot_host_call")
         sec = {}
         for name in ("c3", "c4", "c2f64"):
             try:
@@ -806,19 +972,57 @@ def main():
             line["secondary"] = sec
     # roofline.traffic of the headline workload from counters collected NOW (everything timed is done; the
     # committed summary stays in the line as `traffic_static` for comparison)
-    if line is not None and env.world == 1 and not args.no_live_traffic and not args.traffic_child \
+    # (N > 1: rank 0 alone, on its own GPU, with the shard's size -- the other ranks wait in long_barrier below)
+    if line is not None and not args.no_live_traffic and not args.traffic_child \
             and not (args.m or args.n) and args.projector == "default":
         rf = line["roofline"]
         if time.time() - t_main > LIVE_TRAFFIC_LATEST_START_S:
             live, how = None, "time: the run had already taken %.0f s (limit %.0f s for starting the counter passes)" % (
                 time.time() - t_main, LIVE_TRAFFIC_LATEST_START_S)
         else:
-            live, how = live_traffic(head, rf["counter_kernel_match"])
+            hv = os.environ.get("HIP_VISIBLE_DEVICES")
+            dev_index = None
+            if env.world > 1:   # the physical index of this rank's device
+                dev_index = hv.split(",")[env.local] if hv else env.local
+            live, how = live_traffic(head, rf["counter_kernel_match"], device_index=dev_index)
+            if live is not None and env.world > 1:
+                how += "; N = %d: the passes ran on rank 0's GPU at one rank's shard size" % env.world
         if live is not None:
             rf["traffic_static"] = {"traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source")}
             rf["traffic"], rf["traffic_source"] = live, how
         else:
             rf["traffic_live"] = "not measured: " + how
+    if line is not None:
+        # the line ENDS with the headline workload's own short summary (the driver keeps the tail of stdout: it must
+        # not end inside a secondary workload's fields) -- `secondary` and the long per-workload dictionaries first
+        tail_keys = ("time_to_converge_s", "init_s", "loop_s", "solve_iterations", "solve_status", "time_to_converge_exact_setup_s")
+        head_sum = {k: line[k] for k in tail_keys if k in line}
+        if "handle_cycles" in line:
+            head_sum["handle_cycles_max_time_to_converge_s"] = line["handle_cycles"]["max_time_to_converge_s"]
+            head_sum["handle_cycles_max_init_s"] = line["handle_cycles"]["max_init_s"]
+        if isinstance(line.get("one_shot_host_call"), dict):
+            head_sum["one_shot_host_call_s"] = line["one_shot_host_call"].get("one_shot_host_call_s")
+            head_sum["h2d_s"] = line["one_shot_host_call"].get("h2d_s")
+        par = line.get("parity_vs_reference")
+        if isinstance(par, dict) and "rel_x" in par:
+            head_sum["parity_rel_x"] = par["rel_x"]
+            head_sum["parity_iterations_engine"] = par["iterations_engine"]
+            head_sum["parity_iterations_reference"] = par["iterations_reference"]
+        head_sum.update(value=line["value"], unit=line["unit"], workload=line["config"]["name"],
+                        roofline_frac=line["roofline"]["frac"], iteration_frac=line["roofline"]["iteration"]["frac"])
+        ordered = {}
+        first = ("secondary", "handle_cycles", "parity_vs_reference", "first_handle_of_the_process", "time_to_converge_includes",
+                 "exact_setup", "one_shot_host_call", "window_s")
+        for k in first:
+            if k in line:
+                ordered[k] = line[k]
+        for k, v in line.items():
+            if k not in ordered and k != "cpu_baseline":
+                ordered[k] = v
+        if "cpu_baseline" in line:
+            ordered["cpu_baseline"] = line["cpu_baseline"]
+        ordered["headline"] = head_sum
+        line = ordered
     out_line = json.dumps(line) if line is not None else None
     # The JSON line must be the LAST line of the job's stdout.  C libraries print through stdio
     # (RCCL's version banner: on a pipe it sits in the buffer until exit), so every rank empties
@@ -831,7 +1035,7 @@ def main():
         pass
     sys.stdout.flush()
     if env.dist is not None:
-        env.dist.barrier()
+        env.long_barrier()
         env.dist.destroy_process_group()
     if out_line is not None:
         print(out_line, flush=True)

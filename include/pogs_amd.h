@@ -265,6 +265,11 @@ int PogsAmdProject(PogsAmdSolver *s, const void *x0, const void *y0, double tol,
  * trans = 'n' or 't' (reference: Matrix::Mul). */
 int PogsAmdMul(PogsAmdSolver *s, char trans, double alpha, const void *x, double beta,
                void *y);
+/* Diagnostic: GB/s at which `device` (-1: current) reads `bytes` of device memory with nothing else to
+ * do -- the better of two read-only kernels (all workgroups side by side, 16-byte non-temporal loads; the
+ * row-block shape of the dense pass), `reps` timed launches each.  bench.py prints it as
+ * roofline.peak_measured next to the data-sheet peak.  *pattern (may be NULL): 0 or 1, which one won. */
+int PogsAmdReadBandwidth(int device, size_t bytes, int reps, double *gb_per_s, int *pattern);
 /* The Norm2Est start vector (reference: gsl::rand, src/cpu/include/gsl/gsl_rand.h:8-16). */
 int PogsAmdRandUniform(int dtype, size_t n, void *out_host);
 

@@ -124,6 +124,7 @@ lib.PogsAmdGetEquil.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.P
 lib.PogsAmdProject.argtypes = [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p]
 lib.PogsAmdMul.argtypes = [c_void_p, c_char, c_double, c_void_p, c_double, c_void_p]
 lib.PogsAmdRandUniform.argtypes = [c_int, c_size_t, c_void_p]
+lib.PogsAmdReadBandwidth.argtypes = [c_int, c_size_t, c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_int)]
 
 
 class PogsAmdPoolInfo(ctypes.Structure):
@@ -158,7 +159,16 @@ ABI_SYMBOLS = [
     "PogsAmdIterate", "PogsAmdSetWarmStart", "PogsAmdGetStats", "PogsAmdResetStats", "PogsAmdDestroy", "PogsAmdLastError",
     "PogsAmdPoolStats", "PogsAmdPoolTrim",
     "PogsAmdProxEval", "PogsAmdFuncEval", "PogsAmdProjSubgradEval", "PogsAmdGetEquil", "PogsAmdProject", "PogsAmdMul", "PogsAmdRandUniform",
+    "PogsAmdReadBandwidth",
 ]
+
+
+def read_bandwidth(device=-1, nbytes=4 << 30, reps=10):
+    """(GB/s, pattern) of the device's read-bandwidth probe (include/pogs_amd.h: PogsAmdReadBandwidth)."""
+    gbs, pat = c_double(0.0), c_int(0)
+    if lib.PogsAmdReadBandwidth(device, nbytes, reps, ctypes.byref(gbs), ctypes.byref(pat)) != 0:
+        raise RuntimeError(last_error())
+    return gbs.value, ("side-by-side grid stride", "row blocks")[pat.value]
 
 
 def last_error():

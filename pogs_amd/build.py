@@ -62,10 +62,25 @@ def _plan_jobs():
     return jobs
 
 
+def _deps_newer_than(obj):
+    """True if any file the object was compiled from (its -MMD dependency list) is newer than it, or the
+    list is missing: a header change rebuilds the objects that include it, not all 37."""
+    dep = obj[:-2] + ".d"
+    if not os.path.exists(dep):
+        return True
+    t_obj = os.path.getmtime(obj)
+    text = open(dep).read().replace("\\\n", " ")
+    files = text.split(":", 1)[1].split() if ":" in text else []
+    for f in files:
+        if not os.path.exists(f) or os.path.getmtime(f) > t_obj:
+            return True
+    return False
+
+
 def _compile(job):
     src, objname, defs = job
     obj = os.path.join(OBJ, objname)
-    cmd = [_hipcc()] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc()] + FLAGS + defs + ["-MMD", "-MF", obj[:-2] + ".d", "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s (%s):\n%s\n%s" % (src, objname, r.stdout, r.stderr))
@@ -92,17 +107,13 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     todo = []
     objs = []
-    headers_newer = max((os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h")),
-                        default=0.0)
-    headers_newer = max(headers_newer, os.path.getmtime(os.path.join(_HERE, "..", "include", "pogs_amd.h")))
     jobs = [(src, src.replace(".hip", ".o"), []) for src in SOURCES]
     jobs += [(PLAN_SOURCE, objname, defs) for objname, defs in _plan_jobs()]
     for job in jobs:
         src, objname, _ = job
         obj = os.path.join(OBJ, objname)
         objs.append(obj)
-        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
-            os.path.getmtime(os.path.join(CSRC, src)), headers_newer)
+        stale = force or not os.path.exists(obj) or _deps_newer_than(obj)
         if stale:
             todo.append(job)
     if verbose:

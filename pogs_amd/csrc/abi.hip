@@ -449,6 +449,17 @@ int PogsAmdMul(PogsAmdSolver *s, char trans, double alpha, const void *x, double
   });
 }
 
+int PogsAmdReadBandwidth(int device, size_t bytes, int reps, double *gb_per_s, int *pattern) {
+  return guarded([&]() {
+    POGS_CHECK(gb_per_s && bytes >= (1u << 20), "null argument / fewer than 1 MiB");
+    DeviceGuard guard(device);
+    int pat = 0;
+    *gb_per_s = measure_read_bandwidth_gbs(bytes, reps, &pat);
+    if (pattern) *pattern = pat;
+    return 0;
+  });
+}
+
 int PogsAmdRandUniform(int dtype, size_t n, void *out_host) {
   return guarded([&]() {
     if (dtype == POGS_AMD_F32) rand_uniform_host(static_cast<float *>(out_host), n);

@@ -169,7 +169,13 @@ struct CgfStepA {
   // all-reduced product of this step, which travelled together with the |q|^2 records): u -= alpha t,
   // s = u - shift x, |s|^2 records.  One collective per CG step instead of two (|q|^2, then A^T r).
   T *u; const T *t; T *s;
-  double *rec_s;             // [blocks]
+  double *rec_s;             // [nb_n]
+  // Blocks that take part in the n-sided loops and write their records (|x|^2, |s|^2): cgf_blocks(n),
+  // whatever the launch's grid -- which follows max(n, m) with m this rank's LOCAL row count.  The
+  // replicated sums |x|^2 and |s|^2 (beta, the stopping test, the number of steps and with it the number
+  // of collectives a rank issues) must come out bit-identical on every rank of a row-sharded solve,
+  // also with unequal shards: their split into records depends on n alone.
+  int nb_n;
 };
 // U1: alpha = gamma / (|q|^2 + shift |p|^2) (cgls.h:262-271); x += alpha p, r -= alpha q (:274-277),
 // y_new = (first ? y_warm : y_new) + alpha q; partial |x|^2 (:298)
@@ -218,11 +224,13 @@ __global__ void __launch_bounds__(kCgfTpb) cgf_step_a_kernel(CgfStepA<T> a) {
   }
   const T alpha = static_cast<T>(alpha_d), neg_alpha = static_cast<T>(-alpha_d);
   const int stride = gridDim.x * kCgfTpb, t0 = blockIdx.x * kCgfTpb + threadIdx.x;
+  const bool n_side = static_cast<int>(blockIdx.x) < a.nb_n;
+  const int stride_n = a.nb_n * kCgfTpb, n_end = n_side ? a.n : 0;
   double acc[1] = {0.0};
   double acc_s[1] = {0.0};
   if (a.u) {
     const T sh = static_cast<T>(a.shift);
-    for (int i = t0; i < a.n; i += stride) {
+    for (int i = t0; i < n_end; i += stride_n) {
       const T v = a.x[i] + alpha * a.p[i];
       a.x[i] = v;
       acc[0] += static_cast<double>(v) * v;
@@ -233,7 +241,7 @@ __global__ void __launch_bounds__(kCgfTpb) cgf_step_a_kernel(CgfStepA<T> a) {
       acc_s[0] += static_cast<double>(sv) * sv;
     }
   } else {
-    for (int i = t0; i < a.n; i += stride) {
+    for (int i = t0; i < n_end; i += stride_n) {
       const T v = a.x[i] + alpha * a.p[i];
       a.x[i] = v;
       acc[0] += static_cast<double>(v) * v;
@@ -249,6 +257,7 @@ __global__ void __launch_bounds__(kCgfTpb) cgf_step_a_kernel(CgfStepA<T> a) {
   } else {
     for (int i = t0; i < a.m; i += stride) a.r[i] += neg_alpha * a.q[i];
   }
+  if (!n_side) return;   // (uniform per block) no record of this block
   dev::block_sum<1, kCgfTpb>(acc, s_red);
   if (threadIdx.x == 0) a.rec_x[blockIdx.x] = acc[0];
   if (a.u) {

@@ -104,8 +104,13 @@ class DevicePool {
     // on fresh memory being zero fails the same way on its first handle as on a recycled block
     static const bool poison = [] { const char *e = std::getenv("POGS_AMD_POOL_POISON"); return e && e[0] == '1'; }();
     if (poison) {
-      POGS_HIP_CHECK(hipMemset(ptr, 0xFF, bytes));
-      POGS_HIP_CHECK(hipDeviceSynchronize());
+      try {
+        POGS_HIP_CHECK(hipMemset(ptr, 0xFF, bytes));
+        POGS_HIP_CHECK(hipDeviceSynchronize());
+      } catch (...) {
+        release(ptr);   // the block is registered as live: hand it back instead of losing it
+        throw;
+      }
     }
     return ptr;
   }
@@ -113,6 +118,17 @@ class DevicePool {
     if (!p) return;
     std::unique_lock<std::mutex> lock(mu_);
     auto it = live_.find(p);
+    if (it != live_.end() && dev_[it->second.device & (kMaxPoolDevices - 1)].cap == static_cast<size_t>(-1)) {
+      // first release on this device: read the bound once, OUTSIDE the lock and with the BLOCK's device
+      // current (hipMemGetInfo answers for the current device, which need not be the block's)
+      const int bdev = it->second.device;
+      lock.unlock();
+      const size_t cap = query_capacity(bdev);
+      lock.lock();
+      PerDevice &pd0 = dev_[bdev & (kMaxPoolDevices - 1)];
+      if (pd0.cap == static_cast<size_t>(-1)) pd0.cap = cap;
+      it = live_.find(p);
+    }
     if (it == live_.end()) {   // not ours (should not happen): hand it to the runtime
       lock.unlock();
       (void)hipFree(p);
@@ -122,7 +138,7 @@ class DevicePool {
     live_.erase(it);
     PerDevice &pd = dev_[lv.device & (kMaxPoolDevices - 1)];
     pd.c.live_bytes -= lv.bytes;
-    const size_t cap = capacity(lv.device, lock);
+    const size_t cap = pd.cap;
     if (lv.bytes > cap) {
       lock.unlock();
       timed_free(lv.device, p, pd);
@@ -130,7 +146,9 @@ class DevicePool {
     }
     Idle id;
     id.p = p;
-    id.stamp = ++pd.release_seq;
+    // inside a QuiescedScope the caller has waited for everything that used the block: stamp 0 = no
+    // wait needed when it is handed out again
+    id.stamp = quiesced_depth() > 0 ? 0 : ++pd.release_seq;
     pd.idle.emplace(lv.bytes, id);
     pd.c.cached_bytes += lv.bytes;
     // over the bound: give the largest idle blocks back to the runtime
@@ -166,6 +184,18 @@ class DevicePool {
     for (auto &dp : out) timed_free(dp.first, dp.second, dev_[dp.first]);
     return bytes;
   }
+  static int &quiesced_depth() {
+    static thread_local int depth = 0;
+    return depth;
+  }
+  // RAII: the calling thread guarantees that nothing in flight uses the blocks it releases while the
+  // scope is open (it has synchronised the streams that touched them)
+  struct QuiescedScope {
+    QuiescedScope() { ++quiesced_depth(); }
+    ~QuiescedScope() { --quiesced_depth(); }
+    QuiescedScope(const QuiescedScope &) = delete;
+    QuiescedScope &operator=(const QuiescedScope &) = delete;
+  };
   PoolCounters counters(int device) {
     std::lock_guard<std::mutex> lock(mu_);
     return dev_[device & (kMaxPoolDevices - 1)].c;
@@ -194,24 +224,27 @@ class DevicePool {
   static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   }
-  // idle bytes the pool may hold on a device (called with mu_ held)
-  size_t capacity(int device, std::unique_lock<std::mutex> &) {
-    PerDevice &pd = dev_[device & (kMaxPoolDevices - 1)];
-    if (pd.cap == static_cast<size_t>(-1)) {
-      if (const char *e = std::getenv("POGS_AMD_POOL_MB")) {
-        pd.cap = static_cast<size_t>(std::max(0.0, std::atof(e)) * 1048576.0);
-      } else {
-        size_t free_b = 0, total_b = 0;
-        pd.cap = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? total_b / 4 : (static_cast<size_t>(16) << 30);
-      }
-    }
-    return pd.cap;
+  // idle bytes the pool may hold on `device` (no lock held; the device is made current for the query)
+  static size_t query_capacity(int device) {
+    if (const char *e = std::getenv("POGS_AMD_POOL_MB")) return static_cast<size_t>(std::max(0.0, std::atof(e)) * 1048576.0);
+    int cur = -1;
+    const bool sw = hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
+    size_t free_b = 0, total_b = 0;
+    const size_t cap = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? total_b / 4 : (static_cast<size_t>(16) << 30);
+    if (sw) (void)hipSetDevice(cur);
+    return cap;
   }
   void *finish_reuse(int dev, void *ptr, bool need_sync, unsigned long long upto) {
     if (need_sync) {
       // the block (and possibly others) was released with work in flight: one wait covers every
-      // block released before it began
-      POGS_HIP_CHECK(hipDeviceSynchronize());
+      // block released before it began.  (A handle's own blocks never take this path: ~Ctx waits for
+      // the handle's stream and releases inside a QuiescedScope, so they come back already "synced";
+      // what is left are temporaries of the set-up phases, released right after a stream wait too.)
+      hipError_t e = hipDeviceSynchronize();
+      if (e != hipSuccess) {
+        release(ptr);   // registered as live above: back to the cache, not lost
+        POGS_HIP_CHECK(e);
+      }
       std::lock_guard<std::mutex> lock(mu_);
       PerDevice &pd = dev_[dev & (kMaxPoolDevices - 1)];
       pd.synced_seq = std::max(pd.synced_seq, upto);

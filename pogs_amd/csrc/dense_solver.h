@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(256) scale_de_kernel(const T *src, T *dst, siz
 template <typename T, typename Tag = AllPlans>
 class DenseSolver final : public SolverBase {
  public:
+  ~DenseSolver() override { begin_destroy(ctx_); }
   DenseSolver(int ord, size_t m, size_t n, const void *A, int mem, const PogsAmdOptions *opt,
               const PogsAmdDist *dist) {
     const double t0 = wall_s();
@@ -153,6 +154,7 @@ class DenseSolver final : public SolverBase {
     ctx_.tmark_last = t0;
     ctx_.tmark("ctx init");
     upload(ord, A, mem);
+    if (mem != POGS_AMD_DEVICE) ctx_.sync();   // t_h2d_s is the whole copy from the host, not the time to enqueue it
     ctx_.stats.t_h2d_s = wall_s() - t0;
     ctx_.tmark("upload");
     alloc_state();
@@ -1392,7 +1394,9 @@ class DenseSolver final : public SolverBase {
     // dual residual (fused_cols.h)
     {
       PreColsArgs<T> pc;
-      pc.part0 = colpart_.p; pc.part1 = colpart2_.p; pc.nparts = nparts;
+      // a lean pass (the previous iteration's, when this one is speculated) forms the first set only: the
+      // second is stale pool memory then, and its sum -- published as S[kExactS2], never used -- reads as 0
+      pc.part0 = colpart_.p; pc.part1 = (lean && spec) ? nullptr : colpart2_.p; pc.nparts = nparts;
       pc.tot64 = pack_.p;
       pc.n = n_; pc.n_pad = n_pad_;
       pc.g = gview();

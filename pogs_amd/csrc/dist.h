@@ -29,6 +29,7 @@
 //   POGS_AMD_TEST_TRANSPORT=host  round 1's form: buffers staged through the host and summed there
 //       (hipStreamSynchronize on both sides of the exchange).
 #pragma once
+#include <exception>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -60,6 +61,26 @@ class DistComm {
   // row-sharded CG step (sparse.hip).  The test transport runs them one after the other.
   void group_begin() const;
   void group_end() const;
+  // RAII form: ncclGroupEnd is called on every way out of the scope.  When an exception unwinds
+  // through it (the first all-reduce failed, the communicator was aborted) the group is still closed
+  // -- an open thread-local RCCL group would swallow every later call of the thread -- and a second
+  // error from that closing call is dropped.
+  class Group {
+   public:
+    explicit Group(const DistComm &c) : c_(c), exc_(std::uncaught_exceptions()) { c_.group_begin(); }
+    ~Group() noexcept(false) {
+      if (std::uncaught_exceptions() > exc_) {
+        try { c_.group_end(); } catch (...) {}
+      } else {
+        c_.group_end();
+      }
+    }
+    Group(const Group &) = delete;
+    Group &operator=(const Group &) = delete;
+   private:
+    const DistComm &c_;
+    int exc_;
+  };
   // A vector and one / two scalar ranges as ONE all-reduce of a packed fp64 buffer.
   template <typename T>
   void allreduce2(T *buf, size_t count, double *scalars, size_t nscalars, hipStream_t stream);

@@ -619,6 +619,25 @@ struct SolverBase {
   // when an exception leaves it
   virtual void on_entry() {}
   virtual void on_error() {}
+
+ protected:
+  // First statement of a derived destructor: waits for the handle's stream and, if that succeeded,
+  // marks the calling thread "quiesced" until the LAST sub-object of the solver is gone (this base
+  // is destroyed after every derived member) -- the device blocks the members release then go back
+  // to the pool as safe to hand out at once, and no later handle pays a device-wide wait for them
+  // (DevicePool::finish_reuse; ADVICE r04: hipDeviceSynchronize stalled every stream of the device).
+  void begin_destroy(Ctx &ctx) {
+    if (quiesce_.armed || !ctx.stream || ctx.poisoned) return;
+    DeviceGuard guard(ctx.device);
+    if (hipStreamSynchronize(ctx.stream) == hipSuccess) quiesce_.arm();
+  }
+
+ private:
+  struct QuiesceOnDestroy {
+    bool armed = false;
+    void arm() { ++DevicePool::quiesced_depth(); armed = true; }
+    ~QuiesceOnDestroy() { if (armed) --DevicePool::quiesced_depth(); }
+  } quiesce_;
 };
 
 }  // namespace pogs_amd

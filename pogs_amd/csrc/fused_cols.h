@@ -42,7 +42,8 @@ __device__ __forceinline__ typename Vec16<T>::type colsum_group(const T *partial
 
 template <typename T>
 struct PreColsArgs {
-  const T *part0, *part1;   // SRC64 = false: [nparts][n_pad] partial column sums of the two sets
+  const T *part0, *part1;   // SRC64 = false: [nparts][n_pad] partial column sums of the two sets; part1 == nullptr:
+                            // the second set was not formed (fp64 lean passes): its totals and sum read as zero
   int nparts;
   const double *tot64;      // SRC64 = true: [2][n_pad] totals (summed over the ranks)
   int n, n_pad;
@@ -76,19 +77,30 @@ __global__ void __launch_bounds__(256) pre_cols_kernel(PreColsArgs<T> a) {
       // two independent chains per set keep more loads in flight (the partials sit in L2 / Infinity Cache)
       V t0 = dev::vzero<V>(), t1 = dev::vzero<V>();
       int b = g;
-      for (; b + kPreColsGroups < a.nparts; b += 2 * kPreColsGroups) {
-        const V u0 = *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col);
-        const V u1 = *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b) * a.n_pad + col);
-        const V w0 = *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b + kPreColsGroups) * a.n_pad + col);
-        const V w1 = *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b + kPreColsGroups) * a.n_pad + col);
-        dev::vfma(s0, static_cast<T>(1), u0);
-        dev::vfma(s1, static_cast<T>(1), u1);
-        dev::vfma(t0, static_cast<T>(1), w0);
-        dev::vfma(t1, static_cast<T>(1), w1);
-      }
-      if (b < a.nparts) {
-        dev::vfma(s0, static_cast<T>(1), *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col));
-        dev::vfma(s1, static_cast<T>(1), *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b) * a.n_pad + col));
+      if (a.part1) {   // (uniform)
+        for (; b + kPreColsGroups < a.nparts; b += 2 * kPreColsGroups) {
+          const V u0 = *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col);
+          const V u1 = *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b) * a.n_pad + col);
+          const V w0 = *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b + kPreColsGroups) * a.n_pad + col);
+          const V w1 = *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b + kPreColsGroups) * a.n_pad + col);
+          dev::vfma(s0, static_cast<T>(1), u0);
+          dev::vfma(s1, static_cast<T>(1), u1);
+          dev::vfma(t0, static_cast<T>(1), w0);
+          dev::vfma(t1, static_cast<T>(1), w1);
+        }
+        if (b < a.nparts) {
+          dev::vfma(s0, static_cast<T>(1), *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col));
+          dev::vfma(s1, static_cast<T>(1), *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b) * a.n_pad + col));
+        }
+      } else {   // the first set alone, in the same order
+        for (; b + kPreColsGroups < a.nparts; b += 2 * kPreColsGroups) {
+          const V u0 = *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col);
+          const V w0 = *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b + kPreColsGroups) * a.n_pad + col);
+          dev::vfma(s0, static_cast<T>(1), u0);
+          dev::vfma(t0, static_cast<T>(1), w0);
+        }
+        if (b < a.nparts)
+          dev::vfma(s0, static_cast<T>(1), *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col));
       }
       dev::vfma(s0, static_cast<T>(1), t0);
       dev::vfma(s1, static_cast<T>(1), t1);
@@ -127,7 +139,7 @@ __global__ void __launch_bounds__(256) pre_cols_kernel(PreColsArgs<T> a) {
       sacc[2] = static_cast<double>(h) * h;
       a.rhs[j] = t0;
       const T sd = t1 + h + a.zt_scale * xtj - prev;                                   // :366-373
-      sacc[3] = static_cast<double>(sd) * sd;
+      sacc[3] = (SRC64 || a.part1) ? static_cast<double>(sd) * sd : 0.0;
     } else {
       a.rhs[j] = static_cast<T>(0);
     }

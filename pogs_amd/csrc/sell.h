@@ -68,7 +68,14 @@ struct SellView {
   int nrows, ncols;
   int rr_rows;                  // rows per row range (<= SellCfg::RR)
   int nrr, ncb;                 // row ranges, column blocks
-  int ncg;                      // column groups (an even split of the column blocks)
+  int ncg;                      // column groups: pieces a row range's column blocks are cut into (one workgroup each)
+  // XCD-aware unit table (may be null: workgroup b then takes row range b / ncg, group b % ncg of an EVEN
+  // split): units[4 b ...] = {row range, first column block, one past the last, group slot} of workgroup b.
+  // The hardware deals workgroups to the 8 XCDs round robin (XCD = b mod 8) and the XCDs do not stream at
+  // the same rate (sparse.hip: plan_units): the table gives a faster XCD more column blocks per piece.
+  const int *units;
+  // debug (POGS_AMD_SELL_STAMPS): per workgroup {start, end (100 MHz wall clock), XCC id, non-zero units}
+  unsigned long long *stamps;
 };
 
 // One batch = kSellUB consecutive elements of every lane's stream, stored lane-major: the values of
@@ -115,8 +122,8 @@ __device__ __forceinline__ int sell_uniform_load(const int *p) {
 // The row sums of one (row range, column group) into s_y[0 .. nr): the streaming body shared by the
 // SpMV kernels below.  s_x: BW elements of LDS, s_y: RR elements; ends with a barrier (s_y complete).
 template <typename T, bool SQ>
-__device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__restrict__ x, T xs, int rr, int cg, int nr,
-                                              T *s_x, T *s_y) {
+__device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__restrict__ x, T xs, int rr, int cb0, int cb1,
+                                              int nr, T *s_x, T *s_y) {
   constexpr int BW = SellCfg<T>::BW;
   constexpr int UB = kSellUB, NB = kSellNB;
   const int t = threadIdx.x, lane = t & 63;
@@ -162,9 +169,6 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
       if (en[j]) s_y[B.r[j]] = old[j] + fl[j];
   };
 
-  // column blocks of this group: an even split of the ncb blocks
-  const int cb0 = static_cast<int>(static_cast<long long>(cg) * A.ncb / A.ncg);
-  const int cb1 = static_cast<int>(static_cast<long long>(cg + 1) * A.ncb / A.ncg);
   // x slice of the next non-empty tile, in registers (16-byte pieces)
   using V = typename Vec16<T>::type;
   constexpr int VEC = Vec16<T>::N;
@@ -318,15 +322,29 @@ __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, cons
   T *s_y = s_x + BW;                           // [RR]
   __shared__ double s_red[NS * kSellWaves];
   const int t = threadIdx.x;
+  unsigned long long t_start = 0;
+  if (A.stamps) t_start = wall_clock64();
   // consecutive workgroups (round-robin over the XCDs) take the column groups of one row range:
   // with 8 groups every XCD keeps re-reading the same eighth of x from its own L2
-  const int cg = static_cast<int>(blockIdx.x) % A.ncg;
-  const int rr = static_cast<int>(blockIdx.x) / A.ncg;
+  int cg, rr, cb0, cb1;
+  if (A.units) {
+    const int *u = A.units + 4 * static_cast<size_t>(blockIdx.x);
+    rr = sell_uniform_load(u);
+    cb0 = sell_uniform_load(u + 1);
+    cb1 = sell_uniform_load(u + 2);
+    cg = sell_uniform_load(u + 3);
+  } else {
+    cg = static_cast<int>(blockIdx.x) % A.ncg;
+    rr = static_cast<int>(blockIdx.x) / A.ncg;
+    // column blocks of this group: an even split of the ncb blocks
+    cb0 = static_cast<int>(static_cast<long long>(cg) * A.ncb / A.ncg);
+    cb1 = static_cast<int>(static_cast<long long>(cg + 1) * A.ncb / A.ncg);
+  }
   const int row0 = rr * A.rr_rows;
   const int nr = min(A.rr_rows, A.nrows - row0);
   T xs = 1;
   if (x_nrm2) xs = static_cast<T>(1.0 / sqrt(*x_nrm2));
-  sell_row_sums<T, SQ>(A, x, xs, rr, cg, nr, s_x, s_y);
+  sell_row_sums<T, SQ>(A, x, xs, rr, cb0, cb1, nr, s_x, s_y);
   double sacc[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
@@ -342,6 +360,14 @@ __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, cons
   } else {
     T *out = part + static_cast<size_t>(cg) * A.nrows + row0;
     for (int i = t; i < nr; i += kSellTpb) out[i] = s_y[i];
+  }
+  if (A.stamps && t == 0) {
+    unsigned long long *st = A.stamps + 4 * static_cast<size_t>(blockIdx.x);
+    st[0] = t_start;
+    st[1] = wall_clock64();
+    st[2] = __builtin_amdgcn_s_getreg(6164) & 15u;   // HW_REG_XCC_ID (id 20), bits [3:0]
+    st[3] = static_cast<unsigned long long>(sell_uniform_load(A.tile_unit + static_cast<size_t>(rr) * A.ncb + cb1) -
+                                            sell_uniform_load(A.tile_unit + static_cast<size_t>(rr) * A.ncb + cb0));
   }
 }
 

@@ -517,9 +517,14 @@ struct DevCsr {
   bool sell_ready = false;
   int rr_rows = 0, nrr = 0, ncb = 0, ncg = 1;
   size_t sell_elems = 0;
+  DevBuf<int> units;                      // XCD-aware unit table (plan_units); empty: the even split
+  DevBuf<unsigned long long> stamps;      // debug time stamps (POGS_AMD_SELL_STAMPS / the auto calibration)
+  bool stamps_on = false;
+  std::vector<int> h_tile_unit;           // host copy of tile_unit (plan_units)
   SellDims sdims() const { return SellDims{nrows, ncols, rr_rows, nrr, ncb, SellCfg<T>::BW}; }
   SellView<T> sview() const {
-    return SellView<T>{sval.p, sloc.p, srid.p, tile_unit.p, nrows, ncols, rr_rows, nrr, ncb, ncg};
+    return SellView<T>{sval.p, sloc.p, srid.p, tile_unit.p, nrows, ncols, rr_rows, nrr, ncb, ncg,
+                       units.p, stamps_on ? stamps.p : nullptr};
   }
 };
 
@@ -567,11 +572,14 @@ class SparseSolver final : public SolverBase {
     build_structure(ord, data, ptr, ind, mem);
     ctx_.stats.t_h2d_s = wall_s() - t0;
     alloc_state();
+    tune_units();
     equilibrate();
     norm_est();
     ctx_.sync();
     ctx_.stats.t_init_s = wall_s() - t0;
   }
+
+  ~SparseSolver() override { begin_destroy(ctx_); }
 
   int dtype() const override { return sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64; }
   int device() const override { return ctx_.device; }
@@ -907,6 +915,192 @@ class SparseSolver final : public SolverBase {
     M.sdst.release();
     M.scnt.release();
     M.ssoff.release();
+  }
+
+  // ---- XCD-aware units ----------------------------------------------------------------------
+  // The hardware deals the workgroups of a launch to the 8 XCDs round robin (workgroup b runs on XCD
+  // b mod 8) and an SpMV is ONE static round of ~248 workgroups, one per CU.  The XCDs do not stream
+  // at the same rate (per-workgroup time stamps, profiles/NOTES_r04.md: per-XCD medians between 122
+  // and 139 us in one launch, the same XCDs fast and slow in every launch), so with equal pieces the
+  // slowest XCD sets the kernel time ~7 % above the mean.  plan_units cuts every row range's column
+  // blocks into its ncg pieces in proportion to the rates of the XCDs that will run them and says
+  // which workgroup (i.e. which XCD) takes which piece.  The pieces of a row range are summed in group
+  // order as before; the table is a pure function of (tile sizes, rates), so a given rate vector gives
+  // the same bits every time.  rate[x]: relative streaming rate of XCD x (any positive scale).
+  void plan_units(DevCsr<T> &M, const double *rate) {
+    if (!M.sell_ready || M.ncg <= 1) return;
+    const int nrr = M.nrr, ncb = M.ncb, ncg = M.ncg, nwg = nrr * ncg;
+    if (M.h_tile_unit.empty()) {
+      M.h_tile_unit.resize(static_cast<size_t>(nrr) * ncb + 1);
+      POGS_HIP_CHECK(hipMemcpy(M.h_tile_unit.data(), M.tile_unit.p, M.h_tile_unit.size() * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    const std::vector<int> &tu = M.h_tile_unit;
+    double vsum = 0;
+    for (int x = 0; x < kNumXcd; ++x) vsum += rate[x];
+    std::vector<int> slots_left(kNumXcd, 0), next_slot(kNumXcd);
+    for (int b = 0; b < nwg; ++b) slots_left[b % kNumXcd]++;
+    for (int x = 0; x < kNumXcd; ++x) next_slot[x] = x;
+    const double w_total = static_cast<double>(tu[static_cast<size_t>(nrr) * ncb] - tu[0]);
+    std::vector<double> need(kNumXcd);   // work still to be given to XCD x
+    for (int x = 0; x < kNumXcd; ++x) need[x] = w_total * rate[x] / vsum;
+    std::vector<int> table(static_cast<size_t>(nwg) * 4);
+    std::vector<int> pick(ncg);
+    std::vector<double> want(ncg);
+    for (int rr = 0; rr < nrr; ++rr) {
+      const int *t0 = tu.data() + static_cast<size_t>(rr) * ncb;
+      const double w_rr = static_cast<double>(t0[ncb] - t0[0]);
+      // the ncg XCDs of this range: alternately the one with the most and the one with the least
+      // work left per free workgroup (a fast one is paired with a slow one), each XCD as often as it
+      // has workgroups left
+      std::vector<int> left = slots_left;
+      for (int j = 0; j < ncg; ++j) {
+        int best = -1;
+        double bv = 0;
+        for (int x = 0; x < kNumXcd; ++x) {
+          if (left[x] <= 0) continue;
+          const double per = need[x] / slots_left[x];
+          const bool better = best < 0 || ((j & 1) == 0 ? per > bv : per < bv);
+          if (better) { best = x; bv = per; }
+        }
+        POGS_CHECK(best >= 0, "plan_units: out of workgroups");
+        pick[j] = best;
+        left[best]--;
+      }
+      std::sort(pick.begin(), pick.end());   // pieces in XCD order: an XCD keeps reading the same part of x
+      double wsum = 0;
+      {
+        std::vector<int> used(kNumXcd, 0);
+        for (int j = 0; j < ncg; ++j) {
+          const int x = pick[j];
+          want[j] = need[x] / (slots_left[x] - used[x] > 0 ? slots_left[x] - used[x] : 1);
+          // (an XCD that appears twice in a range: its second piece is sized after the first is taken)
+          used[x]++;
+          wsum += want[j];
+        }
+      }
+      int cb = 0;
+      double acc_w = 0;
+      for (int j = 0; j < ncg; ++j) {
+        const int x = pick[j];
+        const int cb_first = cb;
+        if (j == ncg - 1) {
+          cb = ncb;
+        } else {
+          acc_w += want[j] / (wsum > 0 ? wsum : 1) * w_rr;
+          // the boundary whose cumulative work is nearest to the target
+          while (cb < ncb && std::abs(static_cast<double>(t0[cb + 1] - t0[0]) - acc_w) <= std::abs(static_cast<double>(t0[cb] - t0[0]) - acc_w)) ++cb;
+        }
+        const int b = next_slot[x];
+        next_slot[x] += kNumXcd;
+        POGS_CHECK(b < nwg, "plan_units: workgroup index");
+        table[static_cast<size_t>(b) * 4 + 0] = rr;
+        table[static_cast<size_t>(b) * 4 + 1] = cb_first;
+        table[static_cast<size_t>(b) * 4 + 2] = cb;
+        table[static_cast<size_t>(b) * 4 + 3] = j;
+        need[x] -= static_cast<double>(t0[cb] - t0[cb_first]);
+        slots_left[x]--;
+      }
+    }
+    ctx_.sync();
+    M.units.alloc(table.size());
+    POGS_HIP_CHECK(hipMemcpy(M.units.p, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (std::getenv("POGS_AMD_TRACE")) {
+      std::vector<double> load(kNumXcd, 0.0);
+      for (int b = 0; b < nwg; ++b) {
+        const int *u = table.data() + static_cast<size_t>(b) * 4;
+        load[b % kNumXcd] += tu[static_cast<size_t>(u[0]) * ncb + u[2]] - tu[static_cast<size_t>(u[0]) * ncb + u[1]];
+      }
+      std::fprintf(stderr, "[pogs_amd trace] plan_units %d x %d (%d groups): share of the work per XCD", M.nrows, M.ncols, ncg);
+      for (int x = 0; x < kNumXcd; ++x) std::fprintf(stderr, " %.4f", load[x] / w_total);
+      std::fprintf(stderr, "\n");
+    }
+  }
+
+  // Per-XCD streaming rates from time-stamped launches of M's SpMV (workgroup b: work units / duration,
+  // summed per XCC id); `reps` launches after one untimed.  Debug / calibration aid.
+  void measure_xcd_rates(DevCsr<T> &M, const T *xin, T *yout, int reps, double *rate, bool print) {
+    hipStream_t s = ctx_.stream;
+    const int nwg = M.nrr * M.ncg;
+    M.stamps.alloc(static_cast<size_t>(nwg) * 4);
+    std::vector<unsigned long long> h(static_cast<size_t>(nwg) * 4);
+    std::vector<double> work(kNumXcd, 0.0), time(kNumXcd, 0.0), tmax(kNumXcd, 0.0);
+    std::vector<int> cnt(kNumXcd, 0);
+    double kernel_us = 0;
+    for (int r = 0; r <= reps; ++r) {
+      M.stamps_on = true;
+      spmv<false>(M, xin, nullptr, SpAxpbyOp<T>{1, 0, nullptr, yout}, nullptr, 0);
+      M.stamps_on = false;
+      POGS_HIP_CHECK(hipMemcpyAsync(h.data(), M.stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      ctx_.sync();
+      if (r == 0) continue;
+      unsigned long long lo = ~0ull, hi = 0;
+      for (int b = 0; b < nwg; ++b) {
+        const unsigned long long t0 = h[4 * b], t1 = h[4 * b + 1];
+        const int x = static_cast<int>(h[4 * b + 2]) & (kNumXcd - 1);
+        const double us = static_cast<double>(t1 - t0) / 100.0;   // wall_clock64: 100 MHz
+        work[x] += static_cast<double>(h[4 * b + 3]);
+        time[x] += us;
+        tmax[x] = std::max(tmax[x], us);
+        cnt[x]++;
+        lo = std::min(lo, t0);
+        hi = std::max(hi, t1);
+      }
+      kernel_us += static_cast<double>(hi - lo) / 100.0;
+    }
+    for (int x = 0; x < kNumXcd; ++x) rate[x] = time[x] > 0 ? work[x] / time[x] : 1.0;
+    if (print) {
+      std::fprintf(stderr, "[pogs_amd stamps] %d x %d, %d workgroups, first start to last end %.1f us; per XCD mean us (max) [rate]:",
+                   M.nrows, M.ncols, nwg, kernel_us / reps);
+      double rs = 0;
+      for (int x = 0; x < kNumXcd; ++x) rs += rate[x];
+      for (int x = 0; x < kNumXcd; ++x)
+        std::fprintf(stderr, " %.1f (%.1f) [%.3f]", cnt[x] ? time[x] / cnt[x] : 0.0, tmax[x], rate[x] * kNumXcd / rs);
+      std::fprintf(stderr, "\n");
+    }
+  }
+
+  // POGS_AMD_XCD_WEIGHTS: "auto" -- measure the rates with time-stamped launches and plan with them (twice:
+  // the second measurement runs on the first plan); "r0,...,r7" -- plan with these relative rates; unset
+  // or "uniform": the even split.  POGS_AMD_SELL_STAMPS=1 prints the per-XCD times of the final plan.
+  void tune_units() {
+    const char *w = std::getenv("POGS_AMD_XCD_WEIGHTS");
+    const char *st = std::getenv("POGS_AMD_SELL_STAMPS");
+    const bool stamps = st && st[0] == '1';
+    const bool want_auto = w && std::strcmp(w, "auto") == 0;
+    double rate[kNumXcd];
+    bool have = false;
+    if (w && !want_auto && std::strcmp(w, "uniform") != 0) {
+      int k = 0;
+      const char *p = w;
+      while (k < kNumXcd && *p) {
+        char *end = nullptr;
+        const double v = std::strtod(p, &end);
+        if (end == p) break;
+        rate[k++] = v;
+        p = (*end == ',') ? end + 1 : end;
+      }
+      have = k == kNumXcd;
+      for (int x = 0; have && x < kNumXcd; ++x) have = rate[x] > 0.2 && rate[x] < 5.0;
+      POGS_CHECK(have, "POGS_AMD_XCD_WEIGHTS: eight positive comma-separated rates, \"auto\" or \"uniform\"");
+    }
+    if (!want_auto && !have && !stamps) return;
+    DevBuf<T> vin(static_cast<size_t>(std::max(m_, n_))), vout(static_cast<size_t>(std::max(m_, n_)));
+    launch_fill<T>(vin.p, static_cast<T>(1), vin.n, ctx_.stream);
+    for (DevCsr<T> *M : {&A_, &At_}) {
+      if (!M->sell_ready) continue;
+      double r[kNumXcd];
+      if (want_auto && M->ncg > 1) {
+        for (int pass = 0; pass < 2; ++pass) {
+          measure_xcd_rates(*M, vin.p, vout.p, 3, r, stamps);
+          // pass 1 measured under the first plan: the rates it shows are per XCD again (work / time)
+          plan_units(*M, r);
+        }
+      } else if (have) {
+        plan_units(*M, rate);
+      }
+      if (stamps) measure_xcd_rates(*M, vin.p, vout.p, 3, r, true);
+    }
+    ctx_.sync();
   }
 
   void alloc_state() {
@@ -1380,10 +1574,11 @@ class SparseSolver final : public SolverBase {
         // t = A^T q (this rank's rows), then t and the |q|^2 records over all ranks
         spmv_cg(At_, cg_q_.p, SpStoreOp<T>{tsum_.p}, rec_s2, 0, &e);
         ev.push_back(e);
-        ctx_.dist.group_begin();
-        ctx_.dist.allreduce(tsum_.p, n_, s);
-        ctx_.dist.allreduce(rec_a, rec_a_sum, static_cast<size_t>(nrec_a_sum), s);
-        ctx_.dist.group_end();
+        {
+          DistComm::Group grp(ctx_.dist);   // one RCCL launch; closed on every way out (also by an exception)
+          ctx_.dist.allreduce(tsum_.p, n_, s);
+          ctx_.dist.allreduce(rec_a, rec_a_sum, static_cast<size_t>(nrec_a_sum), s);
+        }
         nrec_q = nrec_a_sum;
       }
       // alpha ; x += alpha p ; r -= alpha q ; y_new += alpha q ; |x|^2        (:262-277, 298)
@@ -1399,8 +1594,9 @@ class SparseSolver final : public SolverBase {
       a.ycur = y_[cur_].p; a.ynew = ysync ? nullptr : y_[nw].p;
       a.rec_x = rec_x;
       a.u = multi_ ? cg_u_.p : nullptr; a.t = tsum_.p; a.s = cg_s_.p; a.rec_s = rec_s2;
+      a.nb_n = gp;
       hipLaunchKernelGGL(cgf_step_a_kernel<T>, dim3(gv), dim3(kCgfTpb), 0, s, a);
-      int nrec_s = gv;
+      int nrec_s = gp;
       if (!multi_) {
         // s = A^T r - shift x ; |s|^2 records                                (:281-286)
         nrec_s = spmv_cg(At_, cg_r_.p, SpAxpbyNormOp<T>{1, static_cast<T>(-shift), x, cg_s_.p}, rec_t, 0, &e);
@@ -1410,7 +1606,7 @@ class SparseSolver final : public SolverBase {
       CgfStepB<T> b;
       b.n = n_; b.S = S; b.k = enq;
       b.rec_s = rec_s2; b.nrec_s = nrec_s;
-      b.rec_x = rec_x; b.nrec_x = gv;
+      b.rec_x = rec_x; b.nrec_x = gp;
       b.tol = tol; b.maxit = 500;                                             // projector_cgls.cpp:17
       b.s = cg_s_.p; b.p = cg_p_.p; b.rec_p = rec_p;
       hipLaunchKernelGGL(cgf_step_b_kernel<T>, dim3(gp), dim3(kCgfTpb), 0, s, b);

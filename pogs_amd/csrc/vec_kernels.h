@@ -152,6 +152,11 @@ void launch_sum_jobs(const SumJob *jobs, int njobs, hipStream_t s);
 // mode 2 beta = S[kCgS2] / gamma, gamma = S[kCgS2] (:288-292), mode 3 gamma = S[kCgS2] (:245).
 void launch_sum_cg(const SumJob &job, double *S, double *cg, int mode, double shift, double eps, hipStream_t s);
 
+// Read-bandwidth probe of the current device (diagnostic; see vec_kernels.hip): GB/s of the better of two
+// read patterns over `bytes` of zero-filled memory, `reps` timed launches each; *pattern: 0 = side-by-side
+// grid stride, 1 = row blocks.
+double measure_read_bandwidth_gbs(size_t bytes, int reps, int *pattern);
+
 // Misc vector helpers.
 template <typename T> void launch_fill(T *p, T v, size_t n, hipStream_t s);
 template <typename T> void launch_sqrt_inplace(T *p, size_t n, hipStream_t s);

@@ -421,6 +421,84 @@ template <typename T>
 void launch_axpby(size_t n, T a, const T *x, T b, T *y, hipStream_t s) {
   if (n) hipLaunchKernelGGL(axpby_kernel<T>, grid1d(n), dim3(256), 0, s, n, a, x, b, y);
 }
+// ---------------------------------------------------------------------------------------------
+// Read-bandwidth probe (PogsAmdReadBandwidth, include/pogs_amd.h part 3): how fast THIS device reads a
+// large array with nothing else to do -- the measured ceiling bench.py prints next to the data-sheet peak
+// ("measured stream on the box and the datasheet value -- state both").  Two
+// patterns, the best of which is returned: all workgroups marching through the array side by side with
+// 16-byte non-temporal loads (the best of scripts/micro/read_bw.hip's table, profiles/r03_read_bw.txt),
+// and the row-block shape of the one-pass iteration kernel (a workgroup reads whole 40 KB rows, two a step).
+namespace {
+typedef float bw_v4 __attribute__((ext_vector_type(4)));
+template <int U>
+__global__ void __launch_bounds__(256) bw_stride_kernel(const bw_v4 *__restrict__ a, size_t nvec, float *out) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  bw_v4 acc = {0, 0, 0, 0};
+  for (; i + (U - 1) * stride < nvec; i += U * stride) {
+    bw_v4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(a + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += v[u];
+  }
+  for (; i < nvec; i += stride) acc += __builtin_nontemporal_load(a + i);
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;   // never true for the zero-filled array: keeps the loads
+}
+template <int NV, int R>
+__global__ void __launch_bounds__(256) bw_rows_kernel(const bw_v4 *__restrict__ a, int rows, int rowvec, float *out) {
+  bw_v4 acc = {0, 0, 0, 0};
+  for (int r0 = blockIdx.x * R; r0 < rows; r0 += gridDim.x * R) {
+    bw_v4 v[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int c = k * 256 + static_cast<int>(threadIdx.x);
+        v[r][k] = __builtin_nontemporal_load(a + static_cast<size_t>(min(r0 + r, rows - 1)) * rowvec + min(c, rowvec - 1));
+      }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) acc += v[r][k];
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
+}
+}  // namespace
+
+double measure_read_bandwidth_gbs(size_t bytes, int reps, int *pattern) {
+  const int rowvec = 2500, rows = static_cast<int>(std::max<size_t>(1, bytes / (16 * static_cast<size_t>(rowvec))));
+  const size_t nvec = static_cast<size_t>(rows) * rowvec;
+  DevBuf<bw_v4> a(nvec);
+  DevBuf<float> out(16);
+  hipStream_t s = nullptr;
+  a.zero(s);
+  hipEvent_t e0, e1;
+  POGS_HIP_CHECK(hipEventCreate(&e0));
+  POGS_HIP_CHECK(hipEventCreate(&e1));
+  double best = 0;
+  reps = std::max(1, reps);
+  for (int pat = 0; pat < 2; ++pat) {
+    auto launch = [&]() {
+      if (pat == 0) hipLaunchKernelGGL((bw_stride_kernel<4>), dim3(512), dim3(256), 0, s, a.p, nvec, out.p);
+      else hipLaunchKernelGGL((bw_rows_kernel<10, 2>), dim3(512), dim3(256), 0, s, a.p, rows, rowvec, out.p);
+    };
+    for (int i = 0; i < 2; ++i) launch();
+    POGS_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) launch();
+    POGS_HIP_CHECK(hipEventRecord(e1, s));
+    POGS_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    POGS_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double gbs = static_cast<double>(nvec) * 16.0 * reps / (static_cast<double>(ms) * 1e-3) / 1e9;
+    if (gbs > best) { best = gbs; if (pattern) *pattern = pat; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  POGS_HIP_CHECK(hipDeviceSynchronize());   // a / out go back to the pool with nothing in flight
+  return best;
+}
+
 #define POGS_INST(T)                                                                                     \
   template void launch_scale_objective<T>(FnView<T>, T *, T *, T *, T *, const T *, int, bool, hipStream_t); \
   template void launch_admm_pre<T>(const AdmmPreArgs<T> &, hipStream_t);                                 \

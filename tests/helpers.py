@@ -65,7 +65,8 @@ def _fsum(fv, v):
     return float(np.sum(c * out + d * v + 0.5 * e * v * v))
 
 
-def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, count_collectives=False, transport="1", **solve_kw):
+def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, count_collectives=False, transport="1", bounds=None,
+                    **solve_kw):
     """Solves with `world` ranks inside this process: one thread + one Solver per rank, rows split
     evenly, joined by the engine's in-process test communicator ("POGSLOCAL:" unique id, see
     pogs_amd/csrc/dist.h).  Verifies the engine's own row-sharded decomposition on ONE GPU.
@@ -80,7 +81,9 @@ def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, count_collectiv
     os.environ["POGS_AMD_TEST_TRANSPORT"] = transport
     m = A.shape[0]
     uid = (b"POGSLOCAL:" + os.urandom(8).hex().encode()).ljust(128, b"\0")
-    bounds = np.linspace(0, m, world + 1).astype(int)
+    # rows split evenly unless the caller names the shard boundaries (unequal shards)
+    bounds = np.linspace(0, m, world + 1).astype(int) if bounds is None else np.asarray(bounds, int)
+    assert len(bounds) == world + 1 and bounds[0] == 0 and bounds[-1] == m
     results, errors = [None] * world, []
 
     def work(r):
@@ -110,7 +113,7 @@ def run_row_sharded(pogs, A, f, g, world, dtype, solver_kw=None, count_collectiv
     return results, bounds
 
 
-def run_sharded_oracle(A, f, g, world, dtype, **solve_kw):
+def run_sharded_oracle(A, f, g, world, dtype, bounds=None, **solve_kw):
     """The ORACLE's row-sharded entry (oracle/pogs_oracle.cpp: OraclePogsShard* / OraclePogsSparseShard*)
     with `world` ranks as threads of this process and an in-test sum in rank order as the collective.
     Returns (per-rank result dicts, bounds) with the same row split as run_row_sharded."""
@@ -119,7 +122,7 @@ def run_sharded_oracle(A, f, g, world, dtype, **solve_kw):
     import oracle_binding as ob
 
     m = A.shape[0]
-    bounds = np.linspace(0, m, world + 1).astype(int)
+    bounds = np.linspace(0, m, world + 1).astype(int) if bounds is None else np.asarray(bounds, int)
     bar = threading.Barrier(world)
     slots = [None] * world
     results, errors = [None] * world, []

@@ -49,7 +49,31 @@ def test_default_invocation_carries_the_contract_fields_and_the_secondary_worklo
         assert rf["traffic_source"].startswith("measured in this run"), rf["traffic_source"]
         assert "traffic_static" in rf
     assert 0.97 * 4.0e9 < rf["traffic"] < 1.10 * 4.0e9, rf["traffic"]
+    # both peaks: the data-sheet 8 TB/s and this device's measured read ceiling
+    assert rf["peak_datasheet"] == 8000.0 and 5000.0 < rf["peak_measured"] < 8000.0, rf["peak_measured"]
+    assert abs(rf["frac_of_peak_measured"] - rf["achieved"] / rf["peak_measured"]) < 1e-12 and rf["frac_of_peak_measured"] < 1.02
+    assert abs(rf["iteration_frac"] - rf["iteration"]["frac"]) < 1e-12
     assert abs(d["value"] - 1e3 * 1 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    # wall-clock-to-converge (the other half of BASELINE.json's metric) where the driver's record keeps it: in
+    # `config`, and in the `headline` summary the line ENDS with
+    cf = d["config"]
+    assert cf["time_to_converge_s"] == d["time_to_converge_s"] and cf["init_s"] == d["init_s"]
+    assert cf["handle_cycles_max_time_to_converge_s"] == d["handle_cycles"]["max_time_to_converge_s"]
+    assert list(d)[-1] == "headline" and list(d)[0] == "secondary"
+    hl = d["headline"]
+    assert hl["workload"] == "c2" and hl["time_to_converge_s"] == d["time_to_converge_s"] and hl["value"] == d["value"]
+    assert hl["parity_rel_x"] == d["parity_vs_reference"]["rel_x"] == cf["parity_rel_x"]
+    # the setup with its two shortcuts switched off (native fp32 Gram, all 50 Sinkhorn-Knopp passes): same solve,
+    # a dearer setup, stated next to the default
+    ex = d["exact_setup"]
+    assert ex["status"] == 0 and abs(ex["iterations"] - d["solve_iterations"]) <= 2 and ex["rel_x_vs_default_setup"] < 5e-5, ex
+    assert d["time_to_converge_exact_setup_s"] == ex["time_to_converge_s"] == cf["time_to_converge_exact_setup_s"]
+    assert d["time_to_converge_s"] < ex["time_to_converge_s"] < 0.6, (d["time_to_converge_s"], ex["time_to_converge_s"])
+    # the reference user's one-shot call with a HOST matrix, and the upload on its own
+    os_ = d["one_shot_host_call"]
+    assert os_["status"] == 0 and os_["iterations"] == d["solve_iterations"], os_
+    assert 0.0 < os_["h2d_s"] < os_["one_shot_host_call_s"] < 3.0 and cf["h2d_s"] == os_["h2d_s"], os_
+    assert os_["one_shot_host_call_s"] >= d["time_to_converge_s"]
     assert d["solve_status"] == 0 and 95 <= d["solve_iterations"] <= 117          # the fixture problem: 106
     sec = d["secondary"]
     for name, idx in (("c3", 2), ("c4", 3), ("c2f64", 1)):
@@ -74,6 +98,27 @@ def test_default_invocation_carries_the_contract_fields_and_the_secondary_worklo
         assert hc["max_init_s"] <= init_cap and hc["max_time_to_converge_s"] <= ttc_cap, (name, hc)
         assert hc["max_init_s"] <= 1.3 * min(hc["init_s"]), (name, hc["init_s"])
         assert s["init_s"] <= init_cap and s["time_to_converge_s"] <= ttc_cap, (name, s["init_s"], s["time_to_converge_s"])
+
+
+def test_forced_communicator_line_is_contract_complete():
+    """The first multi-GPU line must not be the first time its extra legs run: the driver's
+    command through the one-rank RCCL path carries `cpu_baseline`, a `roofline.traffic` measured in the run (the
+    counter passes' children must not inherit the rendezvous / forced-communicator environment),
+    `parity_vs_reference` and `config.rccl_nranks == 1`."""
+    d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-secondary", "--cpu-best-only"],
+               {"POGS_AMD_FORCE_DIST": "1"}, timeout=900)
+    assert d["config"]["rccl_nranks"] == 1 and d["n_gpus"] == 1 and d["config"]["name"] == "c2"
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "reference" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb, cb
+    rf = d["roofline"]
+    if "traffic_live" in rf:
+        assert rf["traffic_live"].startswith("not measured: time"), rf["traffic_live"]
+    else:
+        assert rf["traffic_source"].startswith("measured in this run"), rf["traffic_source"]
+    assert 0.97 * 4.0e9 < rf["traffic"] < 1.10 * 4.0e9, rf["traffic"]
+    par = d["parity_vs_reference"]
+    assert par["rel_x"] < 1e-4 and abs(par["iterations_engine"] - par["iterations_reference"]) <= 3, par
+    assert d["headline"]["time_to_converge_s"] == d["time_to_converge_s"] == d["config"]["time_to_converge_s"]
 
 
 @pytest.mark.parametrize("cfg", ["c2", "c4"])

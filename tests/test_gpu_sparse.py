@@ -133,6 +133,48 @@ def test_sparse_lasso_fp32_scaled_c4():
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("order", ["csr", "csc"])
+def test_sparse_wide_matrix_follows_oracle(dtype, order):
+    """m < n through the sparse entry points: `PogsSparse*` takes any shape through CGLS
+    (src/interface_c/pogs_c.cpp:69-73, projector_cgls.cpp:52-88; the shift keeps A^T A + I definite whatever
+    the rank of A).  5000 x 20000, ~30 non-zeros per row: several column blocks for A, several row ranges for
+    A^T, every x-sized vector four times as long as the y-sized ones."""
+    pogs = _pogs()
+    from pogs_amd import _lib, synth
+
+    m, n = 5000, 20000
+    A, b, _ = synth.csr_lasso(m, n, 30, seed=21, dtype=dtype)
+    f, g = pogs.graph.lasso_functions(b, 0.1, n)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype)
+    if order == "csr":
+        got = pogs.graph._solve_graph_form(A, f, g, dtype=dtype)
+    else:   # the same matrix handed over as CSC through the raw ABI (COL_MAJ)
+        C = A.tocsc()
+        C.sort_indices()
+        fa, ga = f.arrays(dtype), g.arrays(dtype)
+        x, y, l = np.zeros(n, dtype), np.zeros(m, dtype), np.zeros(m, dtype)
+        real = ctypes.c_double if dtype == np.float64 else ctypes.c_float
+        optval, it = real(), ctypes.c_uint()
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        data, indptr, ind = (np.ascontiguousarray(C.data, dtype), np.ascontiguousarray(C.indptr, np.int32),
+                             np.ascontiguousarray(C.indices, np.int32))
+        fn = _lib.lib.PogsSparseD if dtype == np.float64 else _lib.lib.PogsSparseS
+        st = fn(_lib.COL_MAJ, m, n, C.nnz, ptr(data), ptr(indptr), ptr(ind),
+                *[ptr(fa[k]) for k in "abcdeh"], *[ptr(ga[k]) for k in "abcdeh"],
+                real(1.0), real(1e-4), real(1e-4), 2500, 0, 1, 1, ptr(x), ptr(y), ptr(l),
+                ctypes.cast(ctypes.byref(optval), ctypes.c_void_p), ctypes.cast(ctypes.byref(it), ctypes.c_void_p))
+        got = {"x": x, "y": y, "l": l, "optval": optval.value, "iterations": it.value, "status": st}
+    assert want["status"] == 0 and want["iterations"] > 50
+    _check(got, want, _tol(dtype, 1e-6, 2e-5), _tol(dtype, 2, max(5, int(0.05 * want["iterations"]))))
+    assert relerr(got["l"], want["l"]) < _tol(dtype, 1e-5, 2e-3)
+    # a solution of the problem, not just of the oracle: the objective in fp64 with numpy
+    from helpers import objective
+
+    assert objective(A.astype(np.float64), f, g, got["x"]) == pytest.approx(
+        objective(A.astype(np.float64), f, g, want["x"]), rel=_tol(dtype, 1e-7, 1e-5))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_cg_loop_variants_walk_the_same_trajectory(dtype, monkeypatch):
     """The device-resident CGLS loop (cg_fused.h) with y = A x from the CG recurrence every iteration
     (POGS_AMD_YSYNC=1000000), with the explicit product every 16th (default) and every iteration
@@ -486,6 +528,37 @@ def test_row_sharded_sparse_engine_matches_single_rank(dtype, world):
     for out in res[1:]:
         assert out["iterations"] == res[0]["iterations"]
         assert np.array_equal(out["x"], res[0]["x"])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_row_sharded_sparse_unequal_shards(dtype):
+    """Clearly unequal row shards (2000 / 3100 rows, and a 300 / 4800 split whose two ranks launch different
+    grids): the replicated sums of the device-resident CG loop (|x|^2, |s|^2 -> beta, the stopping test, the
+    number of steps and with it the number of collectives a rank issues) must be bit-identical on every rank
+    whatever its local row count (cg_fused.h: CgfStepA::nb_n; ADVICE r04) -- a rank that took one step more
+    than its peer would hang in a collective nobody else joins."""
+    pogs = _pogs()
+    from helpers import run_row_sharded, run_sharded_oracle
+    from pogs_amd import synth
+
+    m, n = 5100, 1200
+    A, b, _ = synth.csr_lasso(m, n, 15, seed=13, dtype=dtype)
+    f, g = pogs.graph.lasso_functions(b, 0.1, n)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=dtype)
+    for bounds in ([0, 2000, 5100], [0, 300, 5100]):
+        res, bd = run_row_sharded(pogs, A.tocsr(), f, g, 2, dtype, bounds=bounds)
+        want_sh, _ = run_sharded_oracle(A.tocsr(), f, g, 2, dtype, bounds=bounds)
+        assert list(bd) == bounds
+        assert res[0]["iterations"] == res[1]["iterations"] and np.array_equal(res[0]["x"], res[1]["x"])
+        it_slack = 1 if dtype == np.float64 else 5
+        for r, out in enumerate(res):
+            d_it = abs(int(out["iterations"]) - int(want["iterations"]))
+            tol = 1e-7 if dtype == np.float64 else (2e-5 if d_it == 0 else min(5e-4, 1e-4 * (1 + d_it)))
+            assert out["status"] == 0 and d_it <= it_slack
+            assert relerr(out["x"], want["x"]) < tol
+            assert relerr(out["y"], want["y"][bounds[r]:bounds[r + 1]]) < tol * 10
+            assert abs(int(out["iterations"]) - int(want_sh[r]["iterations"])) <= it_slack
+            assert relerr(out["x"], want_sh[r]["x"]) < (1e-7 if dtype == np.float64 else 5e-4)
 
 
 @pytest.mark.parametrize("mode", ["host", "cg_h"])

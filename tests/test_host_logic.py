@@ -222,3 +222,22 @@ def test_bench_bookkeeping_without_a_gpu(tmp_path, monkeypatch):
     L1 = synth.dense_logistic_rows(500, 40, seed=33, chunk=200)
     L2 = synth.dense_logistic_rows(500, 40, seed=33, chunk=200)
     assert np.array_equal(L1[0], L2[0]) and np.array_equal(L1[1], L2[1]) and set(np.unique(L1[1])) <= {-1.0, 1.0}
+
+
+def test_bench_extrapolates_the_cpu_leg_of_a_multi_gpu_line():
+    """bench.py at N > 1: rank 0 times the reference on its own shard and the line states the whole problem's
+    rate as an extrapolation t_iter ~ m; at N = 1 nothing is touched."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    base = {"value": 16.0, "unit": "it/s", "time_to_converge_s": 19.0, "init_s": 12.0, "loop_s": 7.0, "sample": "whole workload"}
+    one = bench.extrapolate_cpu(dict(base), 1, 100000, 10000)
+    assert one == base
+    r = bench.extrapolate_cpu(dict(base), 8, 100000, 10000)
+    assert r["value"] == 2.0 and r["value_on_one_shard"] == 16.0 and r["value_in_metric_unit"] == 16.0
+    assert "800000 x 10000" in r["unit"] and "t_iter ~ m" in r["extrapolated"] and "gsl_vector.h:135-138" in r["extrapolated"]
+    assert "time_to_converge_s" not in r and r["time_to_converge_s_on_one_shard"] == 19.0
+    assert r["sample"].startswith("rank 0's shard")
+    assert bench.extrapolate_cpu({"value": None}, 8, 1, 1) == {"value": None}
