@@ -857,6 +857,55 @@ def test_wide_10000x100000_solution_matches_compiled_reference():
         assert abs(r["optval"] - float(fx["optval_fp64"])) <= 1e-4 * float(fx["optval_fp64"])
 
 
+def test_wide_sparse_200000x1000000_solution_matches_compiled_reference():
+    """The sparse entry point on a WIDE matrix at full size: CSR 200000 x 1000000, ~1e7 non-zeros, lasso with
+    lambda = 0.2 max|A^T b| -- `PogsSparse*` takes any shape through CGLS (src/interface_c/pogs_c.cpp:69-73,
+    projector_cgls.cpp:52-88) -- against the compiled reference's fp32 (PogsSparseS) and fp64 (PogsSparseD)
+    solutions of the same problem (tests/golden/make_wide_sparse_reference.py -> wide_sparse_reference.npz; the
+    matrix is regenerated from its seed and checked against the fixture's checksums).  Until round 5 every
+    sparse parity solve was tall.  Same bars as for C4; both arithmetic types of the engine."""
+    import os
+
+    from pogs_amd import synth
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "wide_sparse_reference.npz")
+    if not os.path.exists(path):
+        pytest.skip("wide_sparse_reference.npz not generated")
+    pogs = _pogs()
+    fx = np.load(path)
+    m, n, k = (int(v) for v in fx["shape"])
+    A, b, _ = synth.csr_lasso(m, n, k, seed=int(fx["seed"]), dtype=np.float32, density=float(fx["density"]))
+    chk = np.array([float(A.nnz), float(A.data[::1009].astype(np.float64).sum()), float(A.indices[::1013].astype(np.float64).sum()),
+                    float(np.linalg.norm(b)), float(b[::101].sum())])
+    np.testing.assert_allclose(chk, fx["checksums"], rtol=1e-12, err_msg="the generator no longer reproduces the fixture's inputs")
+    lam = float(fx["lam"])
+    A64 = A.astype(np.float64)
+    for dtype, tag, xtol in ((np.float32, "", 1e-4), (np.float64, "_fp64", 1e-6)):
+        r = pogs.solve_lasso(A if dtype == np.float32 else A64, b, lam, dtype=dtype)
+        xr = np.zeros(n)
+        xr[fx["x_idx" + tag]] = fx["x_val" + tag]
+        x = r["x"].astype(np.float64)
+        it, itr = r["iterations"] + 1, int(fx["iterations" + tag]) + 1
+        rel_x = np.linalg.norm(x - xr) / np.linalg.norm(xr)
+        yr = fx["y" + tag].astype(np.float64)
+        print("wide sparse %s vs reference: iterations %d / %d, rel_x %.3e, optval %.6f / %.6f"
+              % (dtype.__name__, it, itr, rel_x, r["optval"], float(fx["optval" + tag])))
+        assert r["status"] == 0
+        assert abs(it - itr) <= (2 if dtype == np.float64 else max(3, itr // 10)), (it, itr)
+        assert rel_x <= xtol, rel_x
+        assert np.linalg.norm(r["y"].astype(np.float64) - yr) <= 2 * max(xtol, 1e-6) * np.linalg.norm(yr)
+        assert np.linalg.norm(r["l"]) == pytest.approx(float(fx["l_norm" + tag]), rel=10 * max(xtol, 1e-6))
+        obj = 0.5 * float(np.sum((A64 @ x - b) ** 2)) + lam * float(np.abs(x).sum())
+        assert abs(obj - float(fx["objective_at_x" + tag])) <= 1e-4 * float(fx["objective_at_x" + tag])
+        if it == itr:
+            # (the reference sums optval in its arithmetic type over m + n terms: 1e-4 in fp32)
+            assert abs(r["optval"] - float(fx["optval" + tag])) <= (2e-4 if dtype == np.float32 else 1e-8) * float(fx["optval" + tag])
+        # the support the reference finds
+        on_ref = set(int(i) for i in fx["x_idx" + tag][np.abs(fx["x_val" + tag]) > 1e-3 * np.abs(fx["x_val" + tag]).max()])
+        on = set(int(i) for i in np.flatnonzero(np.abs(x) > 1e-3 * np.abs(x).max()))
+        assert len(on ^ on_ref) <= max(2, len(on_ref) // 50), (len(on), len(on_ref))
+
+
 def test_c3_solution_matches_compiled_reference(ref_farm):
     """configs[2] at full size (200000 x 5000 logistic, logits with std 2) against the compiled
     reference on the same inputs (measured: ||dx|| / ||x|| = 2.3e-5, optval 7e-5, 188 vs 184 iterations).
