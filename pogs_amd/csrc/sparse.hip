@@ -517,14 +517,12 @@ struct DevCsr {
   bool sell_ready = false;
   int rr_rows = 0, nrr = 0, ncb = 0, ncg = 1;
   size_t sell_elems = 0;
-  DevBuf<int> units;                      // XCD-aware unit table (plan_units); empty: the even split
-  DevBuf<unsigned long long> stamps;      // debug time stamps (POGS_AMD_SELL_STAMPS / the auto calibration)
+  DevBuf<unsigned long long> stamps;      // debug time stamps (POGS_AMD_SELL_STAMPS)
   bool stamps_on = false;
-  std::vector<int> h_tile_unit;           // host copy of tile_unit (plan_units)
   SellDims sdims() const { return SellDims{nrows, ncols, rr_rows, nrr, ncb, SellCfg<T>::BW}; }
   SellView<T> sview() const {
     return SellView<T>{sval.p, sloc.p, srid.p, tile_unit.p, nrows, ncols, rr_rows, nrr, ncb, ncg,
-                       units.p, stamps_on ? stamps.p : nullptr};
+                       stamps_on ? stamps.p : nullptr};
   }
 };
 
@@ -917,105 +915,6 @@ class SparseSolver final : public SolverBase {
     M.ssoff.release();
   }
 
-  // ---- XCD-aware units ----------------------------------------------------------------------
-  // The hardware deals the workgroups of a launch to the 8 XCDs round robin (workgroup b runs on XCD
-  // b mod 8) and an SpMV is ONE static round of ~248 workgroups, one per CU.  The XCDs do not stream
-  // at the same rate (per-workgroup time stamps, profiles/NOTES_r04.md: per-XCD medians between 122
-  // and 139 us in one launch, the same XCDs fast and slow in every launch), so with equal pieces the
-  // slowest XCD sets the kernel time ~7 % above the mean.  plan_units cuts every row range's column
-  // blocks into its ncg pieces in proportion to the rates of the XCDs that will run them and says
-  // which workgroup (i.e. which XCD) takes which piece.  The pieces of a row range are summed in group
-  // order as before; the table is a pure function of (tile sizes, rates), so a given rate vector gives
-  // the same bits every time.  rate[x]: relative streaming rate of XCD x (any positive scale).
-  void plan_units(DevCsr<T> &M, const double *rate) {
-    if (!M.sell_ready || M.ncg <= 1) return;
-    const int nrr = M.nrr, ncb = M.ncb, ncg = M.ncg, nwg = nrr * ncg;
-    if (M.h_tile_unit.empty()) {
-      M.h_tile_unit.resize(static_cast<size_t>(nrr) * ncb + 1);
-      POGS_HIP_CHECK(hipMemcpy(M.h_tile_unit.data(), M.tile_unit.p, M.h_tile_unit.size() * sizeof(int), hipMemcpyDeviceToHost));
-    }
-    const std::vector<int> &tu = M.h_tile_unit;
-    double vsum = 0;
-    for (int x = 0; x < kNumXcd; ++x) vsum += rate[x];
-    std::vector<int> slots_left(kNumXcd, 0), next_slot(kNumXcd);
-    for (int b = 0; b < nwg; ++b) slots_left[b % kNumXcd]++;
-    for (int x = 0; x < kNumXcd; ++x) next_slot[x] = x;
-    const double w_total = static_cast<double>(tu[static_cast<size_t>(nrr) * ncb] - tu[0]);
-    std::vector<double> need(kNumXcd);   // work still to be given to XCD x
-    for (int x = 0; x < kNumXcd; ++x) need[x] = w_total * rate[x] / vsum;
-    std::vector<int> table(static_cast<size_t>(nwg) * 4);
-    std::vector<int> pick(ncg);
-    std::vector<double> want(ncg);
-    for (int rr = 0; rr < nrr; ++rr) {
-      const int *t0 = tu.data() + static_cast<size_t>(rr) * ncb;
-      const double w_rr = static_cast<double>(t0[ncb] - t0[0]);
-      // the ncg XCDs of this range: alternately the one with the most and the one with the least
-      // work left per free workgroup (a fast one is paired with a slow one), each XCD as often as it
-      // has workgroups left
-      std::vector<int> left = slots_left;
-      for (int j = 0; j < ncg; ++j) {
-        int best = -1;
-        double bv = 0;
-        for (int x = 0; x < kNumXcd; ++x) {
-          if (left[x] <= 0) continue;
-          const double per = need[x] / slots_left[x];
-          const bool better = best < 0 || ((j & 1) == 0 ? per > bv : per < bv);
-          if (better) { best = x; bv = per; }
-        }
-        POGS_CHECK(best >= 0, "plan_units: out of workgroups");
-        pick[j] = best;
-        left[best]--;
-      }
-      std::sort(pick.begin(), pick.end());   // pieces in XCD order: an XCD keeps reading the same part of x
-      double wsum = 0;
-      {
-        std::vector<int> used(kNumXcd, 0);
-        for (int j = 0; j < ncg; ++j) {
-          const int x = pick[j];
-          want[j] = need[x] / (slots_left[x] - used[x] > 0 ? slots_left[x] - used[x] : 1);
-          // (an XCD that appears twice in a range: its second piece is sized after the first is taken)
-          used[x]++;
-          wsum += want[j];
-        }
-      }
-      int cb = 0;
-      double acc_w = 0;
-      for (int j = 0; j < ncg; ++j) {
-        const int x = pick[j];
-        const int cb_first = cb;
-        if (j == ncg - 1) {
-          cb = ncb;
-        } else {
-          acc_w += want[j] / (wsum > 0 ? wsum : 1) * w_rr;
-          // the boundary whose cumulative work is nearest to the target
-          while (cb < ncb && std::abs(static_cast<double>(t0[cb + 1] - t0[0]) - acc_w) <= std::abs(static_cast<double>(t0[cb] - t0[0]) - acc_w)) ++cb;
-        }
-        const int b = next_slot[x];
-        next_slot[x] += kNumXcd;
-        POGS_CHECK(b < nwg, "plan_units: workgroup index");
-        table[static_cast<size_t>(b) * 4 + 0] = rr;
-        table[static_cast<size_t>(b) * 4 + 1] = cb_first;
-        table[static_cast<size_t>(b) * 4 + 2] = cb;
-        table[static_cast<size_t>(b) * 4 + 3] = j;
-        need[x] -= static_cast<double>(t0[cb] - t0[cb_first]);
-        slots_left[x]--;
-      }
-    }
-    ctx_.sync();
-    M.units.alloc(table.size());
-    POGS_HIP_CHECK(hipMemcpy(M.units.p, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
-    if (std::getenv("POGS_AMD_TRACE")) {
-      std::vector<double> load(kNumXcd, 0.0);
-      for (int b = 0; b < nwg; ++b) {
-        const int *u = table.data() + static_cast<size_t>(b) * 4;
-        load[b % kNumXcd] += tu[static_cast<size_t>(u[0]) * ncb + u[2]] - tu[static_cast<size_t>(u[0]) * ncb + u[1]];
-      }
-      std::fprintf(stderr, "[pogs_amd trace] plan_units %d x %d (%d groups): share of the work per XCD", M.nrows, M.ncols, ncg);
-      for (int x = 0; x < kNumXcd; ++x) std::fprintf(stderr, " %.4f", load[x] / w_total);
-      std::fprintf(stderr, "\n");
-    }
-  }
-
   // Per-XCD streaming rates from time-stamped launches of M's SpMV (workgroup b: work units / duration,
   // summed per XCC id); `reps` launches after one untimed.  Debug / calibration aid.
   void measure_xcd_rates(DevCsr<T> &M, const T *xin, T *yout, int reps, double *rate, bool print) {
@@ -1059,46 +958,20 @@ class SparseSolver final : public SolverBase {
     }
   }
 
-  // POGS_AMD_XCD_WEIGHTS: "auto" -- measure the rates with time-stamped launches and plan with them (twice:
-  // the second measurement runs on the first plan); "r0,...,r7" -- plan with these relative rates; unset
-  // or "uniform": the even split.  POGS_AMD_SELL_STAMPS=1 prints the per-XCD times of the final plan.
+  // POGS_AMD_SELL_STAMPS=1 (diagnostic): per-XCD times of both SpMVs on stderr once per handle.  What it showed in
+  // round 5 (profiles/NOTES_r05.md): the XCDs stream at the same rate (work / time within +-4 %, and the sign follows
+  // the column group, not the XCD); what differs is the WORK -- 109 column blocks over 8 groups is 13 or 14 blocks a
+  // piece, and the 14-block pieces set the kernel time ~3 % above the mean.  (An XCD-weighted unit table that cut the
+  // pieces by measured rates was built on that premise and removed again: there is no rate difference to weigh.)
   void tune_units() {
-    const char *w = std::getenv("POGS_AMD_XCD_WEIGHTS");
     const char *st = std::getenv("POGS_AMD_SELL_STAMPS");
-    const bool stamps = st && st[0] == '1';
-    const bool want_auto = w && std::strcmp(w, "auto") == 0;
-    double rate[kNumXcd];
-    bool have = false;
-    if (w && !want_auto && std::strcmp(w, "uniform") != 0) {
-      int k = 0;
-      const char *p = w;
-      while (k < kNumXcd && *p) {
-        char *end = nullptr;
-        const double v = std::strtod(p, &end);
-        if (end == p) break;
-        rate[k++] = v;
-        p = (*end == ',') ? end + 1 : end;
-      }
-      have = k == kNumXcd;
-      for (int x = 0; have && x < kNumXcd; ++x) have = rate[x] > 0.2 && rate[x] < 5.0;
-      POGS_CHECK(have, "POGS_AMD_XCD_WEIGHTS: eight positive comma-separated rates, \"auto\" or \"uniform\"");
-    }
-    if (!want_auto && !have && !stamps) return;
+    if (!(st && st[0] == '1')) return;
     DevBuf<T> vin(static_cast<size_t>(std::max(m_, n_))), vout(static_cast<size_t>(std::max(m_, n_)));
     launch_fill<T>(vin.p, static_cast<T>(1), vin.n, ctx_.stream);
     for (DevCsr<T> *M : {&A_, &At_}) {
       if (!M->sell_ready) continue;
       double r[kNumXcd];
-      if (want_auto && M->ncg > 1) {
-        for (int pass = 0; pass < 2; ++pass) {
-          measure_xcd_rates(*M, vin.p, vout.p, 3, r, stamps);
-          // pass 1 measured under the first plan: the rates it shows are per XCD again (work / time)
-          plan_units(*M, r);
-        }
-      } else if (have) {
-        plan_units(*M, rate);
-      }
-      if (stamps) measure_xcd_rates(*M, vin.p, vout.p, 3, r, true);
+      measure_xcd_rates(*M, vin.p, vout.p, 3, r, true);
     }
     ctx_.sync();
   }
@@ -1180,13 +1053,13 @@ class SparseSolver final : public SolverBase {
       if (M.ncg == 1) {
         static SmemGrants grants;
         ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, SQ, true, Op>), smem, grants);
-        hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, true, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
+        hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, true, Op>), dim3(g1), dim3(kSellBlock), smem, s, M.sview(), x,
                            x_nrm2, op, static_cast<T *>(nullptr), ctx_.spart.p, static_cast<const double *>(nullptr));
         grid = g1;
       } else {
         static SmemGrants grants;
         ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, SQ, false, Op>), smem, grants);
-        hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, false, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
+        hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, false, Op>), dim3(g1), dim3(kSellBlock), smem, s, M.sview(), x,
                            x_nrm2, op, M.part.p, ctx_.spart.p, static_cast<const double *>(nullptr));
         grid = std::max(1, std::min((M.nrows + 255) / 256, spmv_grid_));
         hipLaunchKernelGGL((reduce_parts_kernel<T, Op>), dim3(grid), dim3(256), 0, s, M.part.p, M.nrows, M.ncg, op,
@@ -1240,13 +1113,13 @@ class SparseSolver final : public SolverBase {
     if (M.ncg == 1) {
       static SmemGrants grants;
       ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, false, true, Op>), smem, grants);
-      hipLaunchKernelGGL((spmv_sell_kernel<T, false, true, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
+      hipLaunchKernelGGL((spmv_sell_kernel<T, false, true, Op>), dim3(g1), dim3(kSellBlock), smem, s, M.sview(), x,
                          static_cast<const double *>(nullptr), op, static_cast<T *>(nullptr), rec, guard);
       nrec = g1;
     } else {
       static SmemGrants grants;
       ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, false, false, Op>), smem, grants);
-      hipLaunchKernelGGL((spmv_sell_kernel<T, false, false, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
+      hipLaunchKernelGGL((spmv_sell_kernel<T, false, false, Op>), dim3(g1), dim3(kSellBlock), smem, s, M.sview(), x,
                          static_cast<const double *>(nullptr), op, M.part.p, rec, guard);
       nrec = cgf_blocks(M.nrows);
       hipLaunchKernelGGL((cgf_reduce_kernel<T, Op>), dim3(nrec), dim3(kCgfTpb), 0, s, M.part.p, M.nrows, M.ncg, op, rec, S,

@@ -73,9 +73,6 @@ struct StreamPlan {
   // columns each) -- column sums window-wise, row dots as partial dots that a small kernel adds
   // before the row functor runs; a fused row-dot + column-sum pass becomes those two in turn
   bool xl = false;
-  // > 0: the two-dot / two-accumulator pass of this shape runs in its LDS-staged form (stream_rows2_kernel<..., STG>)
-  // with this many workgroups (the staging buffer leaves room for two per CU)
-  int grid_stage = 0;
 };
 template <typename T> inline int stream_window_cols(const StreamPlan &p) { return p.tpb * p.nv * Vec16<T>::N; }
 template <typename T> inline int stream_windows(const StreamPlan &p, int n_pad) {
@@ -134,12 +131,6 @@ inline StreamPlan make_stream_plan(int n_pad, int num_cu) {
       // at nv = 5 the one-pass iteration kernel takes two rows per step (stream2_rows_c), needs 167
       // VGPRs and fits three workgroups per CU: a slow row functor (logistic prox) hides better
       p.grid_max = num_cu * ((nv == 5 || nv <= 2) ? 3 : 2);   // (nv <= 2: 8 rows per step, 158 VGPRs; 500000 x 2000: 0.694 -> 0.657 ms)
-      // nv = 5 (rows of 4097 .. 5120 fp32 entries; C3): the one-pass kernel keeps the NEXT row tile on its
-      // way into LDS while it works on this one (stream_rows2_kernel, STG) -- POGS_AMD_STAGE=0: the plain form
-      {
-        const char *se = std::getenv("POGS_AMD_STAGE");
-        if (nv == 5 && !(se && se[0] == '0')) p.grid_stage = num_cu * 2;
-      }
       p.ok = true;
       return p;
     }
@@ -184,13 +175,6 @@ __device__ __forceinline__ float4 vscale_add(const float4 &a, float s, const flo
 }
 __device__ __forceinline__ double2 vscale_add(const double2 &a, double s, const double2 &b) {
   return make_double2(a.x * s + b.x, a.y * s + b.y);
-}
-// Workgroup barrier for LDS traffic only: this wavefront's LDS operations have completed (lgkmcnt), everybody
-// has arrived; nothing is said about global memory operations in flight (__syncthreads() waits for those too).
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
 }
 template <typename V> __device__ __forceinline__ V vzero();
 template <> __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -623,21 +607,12 @@ struct StreamArgs2 {
 // 0.35 us per step.  At the C3 shape the R * NV extra vector registers take the kernel from three
 // to two workgroups per CU and the pass from 0.692 to 0.715 ms: resident workgroups hide the
 // functor better than a prefetch does.)
-//
-// STG (LDS-staged row tiles; round 5).  In the plain form a workgroup has loads in flight only while it
-// waits for its row tile: through the dots, the barrier, the row functor (for a logistic f a guarded Newton
-// iteration with an expf per step on R of the 256 lanes, prox_lib.h:131-170), the second barrier and the
-// column sums it requests nothing, and only other resident workgroups keep the memory pipe busy.  A second
-// tile in registers costs a resident workgroup (measured in round 3, above).  Here the NEXT tile travels
-// global -> LDS by DMA (global_load_lds_dwordx4: no registers, no instructions while it flies) from the
-// moment this tile has been read out of the staging buffer into registers: every wavefront copies exactly
-// the pieces it will read back itself (its own 64 x 16 B lines), so the staging needs no barrier -- its own
-// vmcnt(0) before the read-out, lgkmcnt(0) after it, then the next request.  The row functor's operands are
-// requested BEFORE the DMA is issued (vmcnt retires in order: a load issued after the DMA could only be
-// waited for together with the whole next tile).  The staging buffer is a static __shared__ array of its own:
-// the compiler keeps its DMA bookkeeping apart from the other LDS arrays (checked in the ISA: no vmcnt wait in
-// front of the s_part / s_u / s_x1 reads).  Same loads, same order of arithmetic: the same bits as the plain form.
-template <typename T, int TPB, int NV, int R, int ND, int NA, typename Op, bool STG = false>
+// (Measured in round 5 and not kept either: the NEXT tile travelling global -> LDS by DMA (global_load_lds_dwordx4,
+// every wavefront staging and reading back its own lines: no extra barrier, no registers) while this one is worked on.
+// The 40 KB staging buffer leaves room for two workgroups per CU instead of three, i.e. 80 KB in flight per CU instead
+// of up to 120: C3's pass 0.657 -> 0.725 ms.  The register file (512 KB per CU) holds more bytes in flight than the
+// LDS (160 KB) can; profiles/NOTES_r05.md.)
+template <typename T, int TPB, int NV, int R, int ND, int NA, typename Op>
 __global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op op) {
   using V = typename Vec16<T>::type;
   constexpr int VEC = Vec16<T>::N;
@@ -647,7 +622,6 @@ __global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op 
   __shared__ T s_part[2 * R * NDD * NW];
   __shared__ T s_u[2 * R * NA];
   __shared__ double s_red[NS * NW];
-  __shared__ V s_stage[STG ? NW * R * NV * 64 : 1];   // [wave][r][v][lane]
   // the second dot vector lives in LDS (dynamic, n_pad elements): it is re-read per
   // row with conflict-free 16-byte reads and frees 4*NV VGPRs for a second resident wave
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -675,64 +649,9 @@ __global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op 
 
   const int nblk = (a.m + R - 1) / R;
   int slot = 0;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  // STG: request row tile `blk` into this wavefront's part of the staging buffer.  Every lane names a valid
-  // address (rows and columns past the end are clamped; what they hold is masked at the read-out), so the
-  // copy is branch-free.
-  // `real` false (past the last tile of this workgroup): the same R * NV requests, all for the first KB of the
-  // matrix (L2 hits, never read out) -- the number of copies behind the row functor's operand loads is then
-  // the same on every path and the compiler waits for those operands with a counted vmcnt(R * NV), not vmcnt(0).
-  auto stage_issue = [&](int blk, bool real) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int row = real ? min(blk * R + r, a.m - 1) : 0;
-      const T *rp = a.A + static_cast<size_t>(row) * a.lda;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int col = real ? min((v * TPB + t) * VEC, a.n_pad - VEC) : min(lane * VEC, a.n_pad - VEC);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rp + col),
-                                         (__attribute__((address_space(3))) void *)(&s_stage[((wave_u * R + r) * NV + v) * 64]),
-                                         16, 0, 2 /* nt: read once */);
-      }
-    }
-  };
-  // STG: the row functor's operands travel one step ahead too, requested just before the copy of their tile, so
-  // that the one vmcnt(0) at the top of a step covers both and nothing younger than the next copy is ever
-  // waited for inside the step.  (The waits are the s_waitcnt BUILTIN, which the compiler's own wait-count
-  // bookkeeping sees: after it, it knows these loads have returned and adds no wait of its own at their use.)
-  typename Op::Pre pre_next;
-  if (STG && static_cast<int>(blockIdx.x) < nblk) {
-    if (ND > 0 && t < R && static_cast<int>(blockIdx.x) * R + t < a.m) pre_next = op.prefetch(blockIdx.x * R + t);
-    stage_issue(blockIdx.x, true);
-  }
   for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x, slot ^= 1) {
     const int row0 = blk * R;
     V av[R][NV];
-    typename Op::Pre pre;
-    if (STG) {
-      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this tile and this step's functor operands have landed
-      asm volatile("" ::: "memory");
-      pre = pre_next;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int row = row0 + r;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          const int col = (v * TPB + t) * VEC;
-          const V val = s_stage[((wave_u * R + r) * NV + v) * 64 + lane];
-          av[r][v] = (col < a.n_pad && row < a.m) ? val : dev::vzero<V>();
-        }
-      }
-      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): read out before the next copy may overwrite it
-      asm volatile("" ::: "memory");
-      {
-        const int nb = blk + static_cast<int>(gridDim.x);
-        if (ND > 0 && t < R && nb < nblk && nb * R + t < a.m) pre_next = op.prefetch(nb * R + t);
-        asm volatile("" ::: "memory");
-        stage_issue(nb, nb < nblk);
-        asm volatile("" ::: "memory");
-      }
-    } else {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int row = row0 + r;
@@ -747,8 +666,8 @@ __global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op 
     }
     // the row functor's own operands (coefficients, y-vectors) are requested now, so
     // their latency overlaps the row tile's instead of following the reduction
+    typename Op::Pre pre;
     if (ND > 0 && t < R && row0 + t < a.m) pre = op.prefetch(row0 + t);
-    }
     if (ND > 0) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -768,9 +687,7 @@ __global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op 
           if (ND > 1) s_part[((slot * R + r) * NDD + 1) * NW + wave] = s1;
         }
       }
-      // (STG: __syncthreads() carries a workgroup fence that waits for EVERY outstanding memory operation --
-      // including the copy of the next tile just requested; the LDS traffic here needs lgkmcnt alone)
-      if (STG) dev::lds_barrier(); else __syncthreads();
+      __syncthreads();
       if (t < R) {
         const int row = row0 + t;
         T uu[NA];
@@ -790,7 +707,7 @@ __global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op 
 #pragma unroll
         for (int q = 0; q < NA; ++q) s_u[(slot * R + t) * NA + q] = uu[q];
       }
-      if (STG) dev::lds_barrier(); else __syncthreads();
+      __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -850,8 +767,7 @@ template <int ND, int NA = 2>
 inline int stream2_grid(const StreamPlan &p, int m) {
   const int R = stream2_rows<ND, NA>(p);
   const int nblk = (m + R - 1) / R;
-  int gmax = ND > 0 ? p.grid_max : p.grid_dot;   // (the column-sum-only form keeps the two-per-CU grid)
-  if (ND == 2 && NA == 2 && p.grid_stage > 0) gmax = p.grid_stage;   // the LDS-staged form: two workgroups per CU
+  const int gmax = ND > 0 ? p.grid_max : p.grid_dot;   // (the column-sum-only form keeps the two-per-CU grid)
   return nblk < gmax ? (nblk > 0 ? nblk : 1) : gmax;
 }
 
@@ -864,15 +780,6 @@ void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, 
   if (p.tpb == TPB_ && p.nv == NV_) {                                                           \
     constexpr int R_ = stream2_rows_c(ND, NV_, NA);                                             \
     const size_t lds = (ND > 1) ? static_cast<size_t>(a.n_pad) * sizeof(T) : 0;                 \
-    if constexpr (ND == 2 && NA == 2 && TPB_ == 256 && NV_ == 5) {                              \
-      if (p.grid_stage > 0) {                                                                   \
-        static SmemGrants grants_s;                                                             \
-        ensure_dynamic_smem(reinterpret_cast<const void *>(&stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op, true>), lds, grants_s); \
-        hipLaunchKernelGGL((stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op, true>), dim3(grid), \
-                           dim3(TPB_), lds, s, a, op);                                          \
-        return;                                                                                 \
-      }                                                                                         \
-    }                                                                                           \
     static SmemGrants grants;   /* per device; concurrent solvers share it */                   \
     ensure_dynamic_smem(reinterpret_cast<const void *>(&stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>), lds, grants); \
     hipLaunchKernelGGL((stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>), dim3(grid),         \
