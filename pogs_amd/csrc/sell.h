@@ -65,7 +65,11 @@ constexpr int kSellUB = 4;              // elements per lane and batch (a tile's
 constexpr int kSellNB = 8;              // batches in flight per wavefront (3 x 16- / 8-byte loads each)
 constexpr int kSellLmax = 32;           // sort classes: row lengths 1..32 each, longer rows together
 template <typename T> struct SellCfg;
-template <> struct SellCfg<float> { static constexpr int BW = 18432, RR = 16384; };   // 72 KB + 64 KB of LDS (measured at C4 against 24576 x 12288, 20480 x 16384, 22528 x 16384, 14336 x 16384: 165 / 155 / 163 / 155 us, this one 152; 16384 x 16384 -- every x slice on a 64 KB boundary -- 237)
+#ifndef POGS_SELL_BW_F32   // (compile-time overrides: tile-shape experiments through pogs_amd/variants/, scripts/spmv_probe.sh)
+#define POGS_SELL_BW_F32 18432
+#define POGS_SELL_RR_F32 16384
+#endif
+template <> struct SellCfg<float> { static constexpr int BW = POGS_SELL_BW_F32, RR = POGS_SELL_RR_F32; };   // 72 KB + 64 KB of LDS (measured at C4 against 24576 x 12288, 20480 x 16384, 22528 x 16384, 14336 x 16384: 165 / 155 / 163 / 155 us, this one 152; 16384 x 16384 -- every x slice on a 64 KB boundary -- 237)
 template <> struct SellCfg<double> { static constexpr int BW = 12288, RR = 6144; };   // 96 KB + 48 KB
 constexpr unsigned short kSellNoRow = 0xFFFF;
 constexpr int kSellOffBits = 23;        // plan: stream offset of a row inside its tile (9 bits of stream above it)

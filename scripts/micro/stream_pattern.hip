@@ -53,6 +53,57 @@ __global__ void __launch_bounds__(TPB) walk(const u4 *__restrict__ val, const u2
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+// The same separate streams, plus what a tile boundary adds in the SpMV: every TILE steps each thread requests 9 x 16 B of
+// an L2-resident vector (the x slice: 72 KB per workgroup and tile, 246 MB per SpMV on top of the 846 MB of matrix -- but
+// from L2, not HBM).  STORE: the slice also goes through LDS with the two barriers of the swap.
+template <int STORE>
+__global__ void __launch_bounds__(TPB) walk_x(const u4 *__restrict__ val, const u2 *__restrict__ loc, const u2 *__restrict__ rid,
+                                              const u4 *__restrict__ xvec, int xvecs, int G, int S, int TILE, unsigned *out) {
+  __shared__ u4 s_x[TPB * 9];
+  const int t = threadIdx.x, g = blockIdx.x;
+  auto at = [&](int j) -> size_t { return (static_cast<size_t>(g) * S + (j < S ? j : S - 1)) * TPB + t; };
+  u4 v[NB];
+  u2 c[NB], r[NB];
+  u4 xr[9];
+  unsigned acc = 0;
+  auto fetch = [&](int j, int q) {
+    const size_t i = at(j);
+    v[q] = __builtin_nontemporal_load(val + i);
+    c[q] = __builtin_nontemporal_load(loc + i);
+    r[q] = __builtin_nontemporal_load(rid + i);
+  };
+  auto xload = [&](int tile) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) xr[k] = xvec[(static_cast<size_t>(tile) * 9 * TPB + k * TPB + t) % xvecs];
+  };
+  xload(0);
+#pragma unroll
+  for (int q = 0; q < NB; ++q) fetch(q, q);
+  int next_tile = 0, tile = 0;
+  for (int j = 0; j < S; j += NB) {
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      if (j + q == next_tile) {   // (uniform)
+        if (STORE) {
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < 9; ++k) s_x[k * TPB + t] = xr[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) acc += xr[k].x;
+        }
+        xload(++tile);
+        if (STORE) __syncthreads();
+        next_tile += TILE;
+      }
+      acc += v[q].x ^ v[q].y ^ v[q].z ^ v[q].w ^ c[q].x ^ c[q].y ^ r[q].x ^ r[q].y;
+      if (STORE) acc += s_x[(v[q].x & 0xFFF) % (TPB * 9)].x;
+      fetch(j + NB + q, q);
+    }
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 template <typename F>
 static double time_us(F &&launch, int reps = 20) {
   hipEvent_t a, b;
@@ -81,7 +132,27 @@ int main() {
   hipMemset(val, 1, steps_max * TPB * 32);
   hipMemset(loc, 1, steps_max * TPB * 8);
   hipMemset(rid, 1, steps_max * TPB * 8);
-  for (int G : {248, 256, 496, 512}) {
+  {
+    void *xv;
+    const int xvecs = 131072;   // 2 MB: the C4 x vector, L2-resident
+    hipMalloc(&xv, static_cast<size_t>(xvecs) * 16);
+    hipMemset(xv, 1, static_cast<size_t>(xvecs) * 16);
+    const int G = 248;
+    const double gb3 = static_cast<double>(G) * S * TPB * 32 / 1e9;
+    for (int tile : {15, 30, 1000000}) {
+      double us = time_us([&] {
+        hipLaunchKernelGGL((walk_x<0>), dim3(G), dim3(TPB), 0, 0, static_cast<const u4 *>(val), static_cast<const u2 *>(loc),
+                           static_cast<const u2 *>(rid), static_cast<const u4 *>(xv), xvecs, G, S, tile, out);
+      });
+      std::printf("G %3d  separate + x slice every %7d steps, no LDS   %7.1f us  %6.0f GB/s (matrix bytes)\n", G, tile, us, gb3 / us * 1e6);
+      us = time_us([&] {
+        hipLaunchKernelGGL((walk_x<1>), dim3(G), dim3(TPB), 0, 0, static_cast<const u4 *>(val), static_cast<const u2 *>(loc),
+                           static_cast<const u2 *>(rid), static_cast<const u4 *>(xv), xvecs, G, S, tile, out);
+      });
+      std::printf("G %3d  separate + x slice every %7d steps, LDS swap %7.1f us  %6.0f GB/s (matrix bytes)\n", G, tile, us, gb3 / us * 1e6);
+    }
+  }
+  for (int G : {248, 256}) {
     const int Sg = G <= 256 ? S : S / 2;
     const double gb3 = static_cast<double>(G) * Sg * TPB * 32 / 1e9, gb2 = static_cast<double>(G) * Sg * TPB * 24 / 1e9;
 #define RUN(MODE, TAGS, name)                                                                                         \
