@@ -509,7 +509,12 @@ def unsharded_parity(cfg, m, n, world, dev, local, res, shard_b_sums):
     import pogs_amd
     from pogs_amd import graph as G
 
+    from pogs_amd import _lib as L
+
     np_dtype = np.float64 if cfg["dtype"] == "f64" else np.float32
+    # the library's pool may be sitting on tens of GB of idle blocks (the sharded handle was just closed): give them
+    # back before torch asks the runtime for the whole matrix
+    L.pool_trim(local)
     A_all = torch.empty((m * world, n), dtype=torch.float64 if cfg["dtype"] == "f64" else torch.float32, device=dev)
     b_parts = []
     for r in range(world):
@@ -937,6 +942,12 @@ def run_config(env, name, with_cpu):
     if sparse:
         csr_dev = None
     torch.cuda.empty_cache()
+    try:   # the next workload's matrices come from torch: the pool's idle blocks of this one go back to the runtime
+        from pogs_amd import _lib as L
+
+        L.pool_trim(local)
+    except Exception:
+        pass
     return line
 
 

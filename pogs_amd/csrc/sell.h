@@ -33,21 +33,28 @@
 //     at C4; putting the three arrays into one stream gave nothing more).
 //
 // Pipeline: a wavefront walks its batches of all tiles of the workgroup as one sequence with 8
-// batches (24 loads) in flight, also across tile boundaries -- a fetch needs no LDS.
-//
-// Producer wavefronts (round 5).  Until round 4 the eight streaming wavefronts also carried the x slices: each
-// requested its part of the NEXT tile's slice one tile ahead and stored it at the boundary.  vmcnt retires in
-// order, and the compiler has to assume that a boundary may follow a boundary after one batch: in the ISA the
-// store waited with vmcnt(11) .. vmcnt(3), i.e. until all but ONE batch of the 8-deep ring had landed -- every
-// tile boundary (14 per workgroup at C4) drained the load pipeline of all eight wavefronts and paid a memory
-// latency to refill it.  The bare load stream of this kernel runs at 6.84 TB/s (scripts/micro/stream_pattern.hip:
-// 124 us for C4's bytes), the kernel took 142.  Now four extra wavefronts per workgroup own the slices: they
-// request slice k + 1 into their registers, meet the streaming wavefronts at the boundary barrier, store it,
-// second barrier.  Their vmcnt is their own; the streaming wavefronts have nothing but batch loads in flight
-// and their counted vmcnt(21..23) never waits for more than the oldest batch -- also across a boundary.  What bounds the kernel is this load stream alone
+// batches (24 loads) in flight, also across tile boundaries -- a fetch needs no LDS -- and the x
+// slice of the next tile waits in registers, requested one tile ahead, so a tile boundary costs two
+// barriers and the LDS stores, no memory latency.  What bounds the kernel is this load stream alone
 // (round 4, profiles/NOTES_r04.md: with the gathers and row-sum updates compiled out it takes 142.8
 // instead of 145.2 us; ring depths 4 / 6 / 8 are equal, 12 slower; the LDS reads of the next batch
 // requested ahead of this batch's stores: no change).
+//
+// Round 5 (profiles/NOTES_r05.md) looked at everything around this stream once more, with per-workgroup time stamps
+// (POGS_AMD_SELL_STAMPS) and a micro-benchmark of the bare load stream (scripts/micro/stream_pattern.hip):
+//   * the bare stream of this kernel's bytes -- 248 workgroups, three arrays, 8 batches in flight -- takes 124-129 us
+//     (6.6-6.8 TB/s), 132 us with the x slices and their LDS swaps; the MEAN workgroup of the real kernel takes
+//     127-131 us: a workgroup streams as fast as the bare pattern does.  The kernel time (136-146 us) is its slowest one;
+//   * the XCDs stream at the same rate (work / time within +-4 %): what differs between workgroups is the number of
+//     column blocks (13 or 14).  Equal blocks (narrower, 112 instead of 109) made every workgroup as slow as the
+//     slow ones: 1372 against 1377 it/s;
+//   * where the streams lie in memory does not matter (all workgroups marching through one window: 124.2 against
+//     123.6 us);
+//   * the wait for the x slice in registers drains the 8-deep load ring at every tile boundary (vmcnt(11..3) in the
+//     ISA).  Four extra producer wavefronts that own the slices (own vmcnt; the streaming wavefronts never wait for
+//     more than their oldest batch, checked in the ISA) changed nothing: 1346 against 1340-1351 it/s -- the ring
+//     refills faster than a tile takes;
+// so what is left is bytes (8.4 per non-zero here).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -56,16 +63,14 @@
 
 namespace pogs_amd {
 
-constexpr int kSellTpb = 512;           // CONSUMER threads of a workgroup (one workgroup per CU: LDS): 8 wavefronts walk the lane streams
+constexpr int kSellTpb = 512;           // one workgroup per CU (LDS), 8 wavefronts with up to 256 VGPRs each
 constexpr int kSellWaves = kSellTpb / 64;
-constexpr int kSellProd = 256;          // PRODUCER threads: 4 more wavefronts that do nothing but carry the x slices global -> registers -> LDS
-constexpr int kSellBlock = kSellTpb + kSellProd;   // threads per workgroup (12 wavefronts, 3 per SIMD: up to 168 VGPRs each)
 constexpr int kSellStreams = kSellTpb;  // lane streams per tile
 constexpr int kSellUB = 4;              // elements per lane and batch (a tile's stream length is a multiple of it)
 constexpr int kSellNB = 8;              // batches in flight per wavefront (3 x 16- / 8-byte loads each)
 constexpr int kSellLmax = 32;           // sort classes: row lengths 1..32 each, longer rows together
 template <typename T> struct SellCfg;
-#ifndef POGS_SELL_BW_F32   // (compile-time overrides: tile-shape experiments through pogs_amd/variants/, scripts/spmv_probe.sh)
+#ifndef POGS_SELL_BW_F32   // (compile-time overrides: tile-shape experiments through scripts/build_variant.py, scripts/spmv_probe.sh)
 #define POGS_SELL_BW_F32 18432
 #define POGS_SELL_RR_F32 16384
 #endif
@@ -84,7 +89,7 @@ struct SellView {
   int rr_rows;                  // rows per row range (<= SellCfg::RR)
   int nrr, ncb;                 // row ranges, column blocks
   int ncg;                      // column groups (an even split of the column blocks)
-  // debug (POGS_AMD_SELL_STAMPS): per workgroup {start, end (100 MHz wall clock), XCC id, non-zero units}
+  // debug (POGS_AMD_SELL_STAMPS): per workgroup {start, end (100 MHz wall clock), XCC id, 64-element units walked}
   unsigned long long *stamps;
 };
 
@@ -132,13 +137,13 @@ __device__ __forceinline__ int sell_uniform_load(const int *p) {
 // The row sums of one (row range, column group) into s_y[0 .. nr): the streaming body shared by the
 // SpMV kernels below.  s_x: BW elements of LDS, s_y: RR elements; ends with a barrier (s_y complete).
 template <typename T, bool SQ>
-__device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__restrict__ x, T xs, int rr, int cb0, int cb1,
-                                              int nr, T *s_x, T *s_y) {
+__device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__restrict__ x, T xs, int rr, int cg, int nr,
+                                              T *s_x, T *s_y) {
   constexpr int BW = SellCfg<T>::BW;
   constexpr int UB = kSellUB, NB = kSellNB;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  for (int i = t; i < nr; i += kSellBlock) s_y[i] = 0;   // (all twelve wavefronts; first touched after the first boundary's barriers)
+  for (int i = t; i < nr; i += kSellTpb) s_y[i] = 0;
 
   const T *__restrict__ a_val = A.val;
   const unsigned short *__restrict__ a_loc = A.loc;
@@ -179,92 +184,84 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
       if (en[j]) s_y[B.r[j]] = old[j] + fl[j];
   };
 
-  // ---- producer wavefronts: the x slices --------------------------------------------------------
-  // (threads kSellTpb .. kSellBlock-1; they execute exactly the barriers the streaming wavefronts execute: two per
-  // non-empty tile of the group, one at the end)
-  if (t >= kSellTpb) {
-    const int tp = t - kSellTpb;
-    using V = typename Vec16<T>::type;
-    constexpr int VEC = Vec16<T>::N;
-    constexpr int XV = BW / (kSellProd * VEC);
-    static_assert(BW % (kSellProd * VEC) == 0, "the x slice is a whole number of 16-byte vectors per producer thread");
-    V xreg[XV];
-    int x_cb = cb0 - 1, x_w = 0;   // block whose slice is in xreg, its width
-    auto x_prefetch = [&]() {   // advance x_cb to the next non-empty tile and request its slice
-      do { ++x_cb; } while (x_cb < cb1 && tu(x_cb) == tu(x_cb + 1));
-      if (x_cb >= cb1) return;
-      const int c0 = x_cb * BW, w = min(BW, A.ncols - c0);
-      if (w >= VEC) {
-        // unconditional loads: a vector that straddles or lies past the end re-reads the last whole
-        // vector of the slice (no branch per vector); what it really holds is sorted out in x_store
-        const int c_last = w - VEC;
-#pragma unroll
-        for (int i = 0; i < XV; ++i) {
-          const int c = (i * kSellProd + tp) * VEC;
-          xreg[i] = *reinterpret_cast<const V *>(x + c0 + min(c, c_last));
-        }
-      } else {
-        // a last column block narrower than one vector: producer thread 0 owns it
-#pragma unroll
-        for (int i = 0; i < XV; ++i) xreg[i] = dev_vzero<V>();
-        if (tp == 0) {
-          T out[VEC];
-#pragma unroll
-          for (int q = 0; q < VEC; ++q) out[q] = q < w ? x[c0 + q] : static_cast<T>(0);
-          __builtin_memcpy(&xreg[0], out, sizeof(V));
-        }
-      }
-      x_w = w;
-    };
-    auto x_store = [&]() {
-      // Every word of s_x has ONE writer: the vector that straddles the end of the slice takes its
-      // leading elements from the tail of the last whole vector (which is what it loaded: elements
-      // c .. w-1 sit at offset c - c_last in it) and zeros behind them; vectors past the end are zero.
-      if (x_w == BW) {   // (uniform) a full-width slice: every vector is what it loaded
-#pragma unroll
-        for (int i = 0; i < XV; ++i) {
-          T tmp[VEC];
-          __builtin_memcpy(tmp, &xreg[i], sizeof(V));
-#pragma unroll
-          for (int q = 0; q < VEC; ++q) tmp[q] *= xs;
-          V v;
-          __builtin_memcpy(&v, tmp, sizeof(V));
-          *reinterpret_cast<V *>(s_x + (i * kSellProd + tp) * VEC) = v;
-        }
-        return;
-      }
-      const int c_last = x_w - VEC;
+  // column blocks of this group: an even split of the ncb blocks
+  const int cb0 = static_cast<int>(static_cast<long long>(cg) * A.ncb / A.ncg);
+  const int cb1 = static_cast<int>(static_cast<long long>(cg + 1) * A.ncb / A.ncg);
+  // x slice of the next non-empty tile, in registers (16-byte pieces)
+  using V = typename Vec16<T>::type;
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int XV = BW / (kSellTpb * VEC);
+  V xreg[XV];
+  int x_cb = cb0 - 1, x_w = 0;   // block whose slice is in xreg, its width
+  auto x_prefetch = [&]() {   // advance x_cb to the next non-empty tile and request its slice
+    do { ++x_cb; } while (x_cb < cb1 && tu(x_cb) == tu(x_cb + 1));
+    if (x_cb >= cb1) return;
+    const int c0 = x_cb * BW, w = min(BW, A.ncols - c0);
+    if (w >= VEC) {
+      // unconditional loads: a vector that straddles or lies past the end re-reads the last whole
+      // vector of the slice (no branch per vector, a compile-time number of loads in flight); what
+      // it really holds is sorted out in x_store, one tile later, when the data has long arrived
+      // (touching the loaded value here would make the compiler wait for it -- and with it for the
+      // whole batch ring -- at every tile boundary)
+      const int c_last = w - VEC;
 #pragma unroll
       for (int i = 0; i < XV; ++i) {
-        const int c = (i * kSellProd + tp) * VEC;
-        T in[VEC], out[VEC];
-        __builtin_memcpy(in, &xreg[i], sizeof(V));
-        const int sh = (x_w >= VEC && c > c_last) ? c - c_last : 0;   // 0: the vector is what it loaded
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) {
-          T e = in[q];
-#pragma unroll
-          for (int u = 1; u < VEC; ++u)
-            if (sh == u) e = (q + u < VEC) ? in[q + u] : static_cast<T>(0);
-          if (sh >= VEC) e = 0;
-          out[q] = e * xs;
-        }
-        V v;
-        __builtin_memcpy(&v, out, sizeof(V));
-        *reinterpret_cast<V *>(s_x + c) = v;
+        const int c = (i * kSellTpb + t) * VEC;
+        xreg[i] = *reinterpret_cast<const V *>(x + c0 + min(c, c_last));
       }
-    };
-    x_prefetch();
-    while (x_cb < cb1) {
-      __syncthreads();   // the streaming wavefronts are done with the previous tile's slice
-      x_store();
-      x_prefetch();      // the next one travels while this tile is streamed
-      __syncthreads();
+    } else {
+      // a last column block narrower than one vector: thread 0 owns it
+#pragma unroll
+      for (int i = 0; i < XV; ++i) xreg[i] = dev_vzero<V>();
+      if (t == 0) {
+        T out[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) out[q] = q < w ? x[c0 + q] : static_cast<T>(0);
+        __builtin_memcpy(&xreg[0], out, sizeof(V));
+      }
     }
-    __syncthreads();     // (the streaming wavefronts' closing barrier)
-    return;
-  }
-
+    x_w = w;
+  };
+  auto x_store = [&]() {
+    // Every word of s_x has ONE writer: the vector that straddles the end of the slice takes its
+    // leading elements from the tail of the last whole vector (which is what it loaded: elements
+    // c .. w-1 sit at offset c - c_last in it) and zeros behind them; vectors past the end are zero.
+    // (The ragged tail used to be stored by threads 0 .. VEC-2 on top of the owner's zero vector, a
+    // write-write race between wavefronts.)
+    if (x_w == BW) {   // (uniform) a full-width slice: every vector is what it loaded
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        T tmp[VEC];
+        __builtin_memcpy(tmp, &xreg[i], sizeof(V));
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) tmp[q] *= xs;
+        V v;
+        __builtin_memcpy(&v, tmp, sizeof(V));
+        *reinterpret_cast<V *>(s_x + (i * kSellTpb + t) * VEC) = v;
+      }
+      return;
+    }
+    const int c_last = x_w - VEC;
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int c = (i * kSellTpb + t) * VEC;
+      T in[VEC], out[VEC];
+      __builtin_memcpy(in, &xreg[i], sizeof(V));
+      const int sh = (x_w >= VEC && c > c_last) ? c - c_last : 0;   // 0: the vector is what it loaded
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        T e = in[q];
+#pragma unroll
+        for (int u = 1; u < VEC; ++u)
+          if (sh == u) e = (q + u < VEC) ? in[q + u] : static_cast<T>(0);
+        if (sh >= VEC) e = 0;
+        out[q] = e * xs;
+      }
+      V v;
+      __builtin_memcpy(&v, out, sizeof(V));
+      *reinterpret_cast<V *>(s_x + c) = v;
+    }
+  };
   // The wavefront's batches of ALL tiles of the workgroup form one sequence (every wavefront has
   // the same number per tile, so all of them cross a tile boundary at the same step).  The ring is
   // filled with the first NB batches; every step consumes the oldest batch and refills its slot
@@ -297,6 +294,7 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
   };
   SellBatch<T> B[NB];
   bool first[NB];
+  x_prefetch();
   if (tb > 0) {
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
@@ -309,9 +307,11 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
       for (int q = 0; q < NB; ++q) {
         if (i + q < tb) {   // uniform
           if (first[q]) {
-            // first batch of a tile (the same step for every wavefront): the producers swap the x slice
+            // first batch of a tile (the same step for every wavefront): swap the x slice
             __syncthreads();   // the previous tile's gathers and row-sum updates are done
-            __syncthreads();   // the new slice is in LDS
+            x_store();
+            x_prefetch();
+            __syncthreads();
           }
           consume(B[q]);
         }
@@ -329,7 +329,7 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
 // non-zero turns this launch into a no-op (the device-resident CG loop, cg_fused.h: the host
 // enqueues a loop's worth of launches without reading anything back).
 template <typename T, bool SQ, bool DIRECT, typename Op>
-__global__ void __launch_bounds__(kSellBlock) spmv_sell_kernel(SellView<T> A, const T *__restrict__ x,
+__global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, const T *__restrict__ x,
                                                              const double *x_nrm2, Op op, T *__restrict__ part,
                                                              double *scalar_partials, const double *guard) {
   if (guard && *guard != 0.0) return;
@@ -346,15 +346,11 @@ __global__ void __launch_bounds__(kSellBlock) spmv_sell_kernel(SellView<T> A, co
   // with 8 groups every XCD keeps re-reading the same eighth of x from its own L2
   const int cg = static_cast<int>(blockIdx.x) % A.ncg;
   const int rr = static_cast<int>(blockIdx.x) / A.ncg;
-  // column blocks of this group: an even split of the ncb blocks
-  const int cb0 = static_cast<int>(static_cast<long long>(cg) * A.ncb / A.ncg);
-  const int cb1 = static_cast<int>(static_cast<long long>(cg + 1) * A.ncb / A.ncg);
   const int row0 = rr * A.rr_rows;
   const int nr = min(A.rr_rows, A.nrows - row0);
   T xs = 1;
   if (x_nrm2) xs = static_cast<T>(1.0 / sqrt(*x_nrm2));
-  sell_row_sums<T, SQ>(A, x, xs, rr, cb0, cb1, nr, s_x, s_y);
-  if (t >= kSellTpb) return;   // the producer wavefronts are done (the barriers below count the remaining ones)
+  sell_row_sums<T, SQ>(A, x, xs, rr, cg, nr, s_x, s_y);
   double sacc[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
@@ -372,6 +368,8 @@ __global__ void __launch_bounds__(kSellBlock) spmv_sell_kernel(SellView<T> A, co
     for (int i = t; i < nr; i += kSellTpb) out[i] = s_y[i];
   }
   if (A.stamps && t == 0) {
+    const int cb0 = static_cast<int>(static_cast<long long>(cg) * A.ncb / A.ncg);
+    const int cb1 = static_cast<int>(static_cast<long long>(cg + 1) * A.ncb / A.ncg);
     unsigned long long *st = A.stamps + 4 * static_cast<size_t>(blockIdx.x);
     st[0] = t_start;
     st[1] = wall_clock64();

@@ -570,7 +570,7 @@ class SparseSolver final : public SolverBase {
     build_structure(ord, data, ptr, ind, mem);
     ctx_.stats.t_h2d_s = wall_s() - t0;
     alloc_state();
-    tune_units();
+    print_stamps();
     equilibrate();
     norm_est();
     ctx_.sync();
@@ -962,12 +962,8 @@ class SparseSolver final : public SolverBase {
     }
   }
 
-  // POGS_AMD_SELL_STAMPS=1 (diagnostic): per-XCD times of both SpMVs on stderr once per handle.  What it showed in
-  // round 5 (profiles/NOTES_r05.md): the XCDs stream at the same rate (work / time within +-4 %, and the sign follows
-  // the column group, not the XCD); what differs is the WORK -- 109 column blocks over 8 groups is 13 or 14 blocks a
-  // piece, and the 14-block pieces set the kernel time ~3 % above the mean.  (An XCD-weighted unit table that cut the
-  // pieces by measured rates was built on that premise and removed again: there is no rate difference to weigh.)
-  void tune_units() {
+  // POGS_AMD_SELL_STAMPS=1 (diagnostic): per-XCD times of both SpMVs on stderr once per handle (sell.h: what they showed).
+  void print_stamps() {
     const char *st = std::getenv("POGS_AMD_SELL_STAMPS");
     if (!(st && st[0] == '1')) return;
     DevBuf<T> vin(static_cast<size_t>(std::max(m_, n_))), vout(static_cast<size_t>(std::max(m_, n_)));
@@ -1057,13 +1053,13 @@ class SparseSolver final : public SolverBase {
       if (M.ncg == 1) {
         static SmemGrants grants;
         ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, SQ, true, Op>), smem, grants);
-        hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, true, Op>), dim3(g1), dim3(kSellBlock), smem, s, M.sview(), x,
+        hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, true, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
                            x_nrm2, op, static_cast<T *>(nullptr), ctx_.spart.p, static_cast<const double *>(nullptr));
         grid = g1;
       } else {
         static SmemGrants grants;
         ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, SQ, false, Op>), smem, grants);
-        hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, false, Op>), dim3(g1), dim3(kSellBlock), smem, s, M.sview(), x,
+        hipLaunchKernelGGL((spmv_sell_kernel<T, SQ, false, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
                            x_nrm2, op, M.part.p, ctx_.spart.p, static_cast<const double *>(nullptr));
         grid = std::max(1, std::min((M.nrows + 255) / 256, spmv_grid_));
         hipLaunchKernelGGL((reduce_parts_kernel<T, Op>), dim3(grid), dim3(256), 0, s, M.part.p, M.nrows, M.ncg, op,
@@ -1117,13 +1113,13 @@ class SparseSolver final : public SolverBase {
     if (M.ncg == 1) {
       static SmemGrants grants;
       ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, false, true, Op>), smem, grants);
-      hipLaunchKernelGGL((spmv_sell_kernel<T, false, true, Op>), dim3(g1), dim3(kSellBlock), smem, s, M.sview(), x,
+      hipLaunchKernelGGL((spmv_sell_kernel<T, false, true, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
                          static_cast<const double *>(nullptr), op, static_cast<T *>(nullptr), rec, guard);
       nrec = g1;
     } else {
       static SmemGrants grants;
       ensure_dynamic_smem(reinterpret_cast<const void *>(&spmv_sell_kernel<T, false, false, Op>), smem, grants);
-      hipLaunchKernelGGL((spmv_sell_kernel<T, false, false, Op>), dim3(g1), dim3(kSellBlock), smem, s, M.sview(), x,
+      hipLaunchKernelGGL((spmv_sell_kernel<T, false, false, Op>), dim3(g1), dim3(kSellTpb), smem, s, M.sview(), x,
                          static_cast<const double *>(nullptr), op, M.part.p, rec, guard);
       nrec = cgf_blocks(M.nrows);
       hipLaunchKernelGGL((cgf_reduce_kernel<T, Op>), dim3(nrec), dim3(kCgfTpb), 0, s, M.part.p, M.nrows, M.ncg, op, rec, S,
@@ -1255,6 +1251,10 @@ class SparseSolver final : public SolverBase {
     for (int j = 0; j < n_ && pre_cheap_; ++j) pre_cheap_ = is_cheap_prox(g.h[j]);
     launch_scale_objective<T>(f_.view(), fs_.a.p, fs_.c.p, fs_.d.p, fs_.e.p, d_.p, m_, true, s);
     launch_scale_objective<T>(g_.view(), gs_.a.p, gs_.c.p, gs_.d.p, gs_.e.p, e_.p, n_, false, s);
+    // coefficient arrays that hold one value throughout (a lasso: h, c, d, e of both halves) are not streamed by the
+    // prox step: 16 of its 44 bytes per element
+    uni_f_ = probe_uniform<T>(fview(), m_, s);
+    uni_g_ = probe_uniform<T>(gview(), n_, s);
     ctl_ = AdmmControl<T>();
     ctl_.abs_tol = static_cast<T>(p.abs_tol);
     ctl_.rel_tol = static_cast<T>(p.rel_tol);
@@ -1549,6 +1549,7 @@ class SparseSolver final : public SolverBase {
     pa.x12 = x12_.p; pa.y12 = y12_.p;
     pa.xtemp = xtemp_.p; pa.ytemp = ytemp_.p;
     pa.rho = ctl_.rho; pa.alpha = ctl_.alpha(); pa.cheap = pre_cheap_;
+    pa.uf = uni_f_; pa.ug = uni_g_;
     pa.partials = ctx_.spart.p + sp_pre_off_;
     pa.blocks_x = pre_blocks(n_);
     const double *S;
@@ -1688,6 +1689,7 @@ class SparseSolver final : public SolverBase {
   int ysync_ = 16;               // y = A x explicitly every ysync_-th iteration (0: always), else by recurrence
   unsigned long long proj_count_ = 0;
   bool pre_cheap_ = false;       // every f_i, g_j has a few-operation prox (admm_pre_kernel inlines it)
+  FnUniform<T> uni_f_, uni_g_;   // coefficient arrays of f / g that hold one value throughout (load_problem)
   FnBuf<T> f_, g_, fs_, gs_;
   AdmmControl<T> ctl_;
   bool loaded_ = false;   // load_problem has run: f, g and the control block are valid

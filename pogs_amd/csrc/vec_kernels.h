@@ -38,6 +38,19 @@ struct FnBuf {  // owning device SoA of function objects
   FnView<T> view() const { return FnView<T>{h.p, a.p, b.p, c.p, d.p, e.p}; }
 };
 
+// Which coefficient arrays of a (scaled) function vector hold one value throughout (bit 0: h, 1: c, 2: d, 3: e), and
+// that value.  A lasso's f is (kSquare, a_i, b_i, 1, 0, 0) and its g (kAbs, a_j, 0, lambda, 0, 0): four of the six
+// streams the prox step reads per element carry no information -- 16 of its 44 bytes per element at C4.
+template <typename T>
+struct FnUniform {
+  int mask = 0;
+  int h = 0;
+  T c = 0, d = 0, e = 0;
+};
+// Probes the n function objects of `fn` (device arrays, scaled); waits for the stream.
+template <typename T>
+FnUniform<T> probe_uniform(FnView<T> fn, int n, hipStream_t s);
+
 template <typename T>
 struct AdmmPreArgs {
   int n_x, n_y;
@@ -57,6 +70,7 @@ struct AdmmPreArgs {
   // every f_i and g_j is one of the few-operation base functions (is_cheap_prox): the prox is inlined
   // instead of a call into the full library (Lambert W, cubic roots, Newton steps behind one switch)
   bool cheap = false;
+  FnUniform<T> ug, uf;   // uniform coefficient arrays of g and f: not loaded (mask 0: everything is)
 };
 
 // clamp c,e >= 0 (FunctionObj::CheckConsts, prox_lib.h:62-69) and scale by the

@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(kVecTpb) admm_pre_kernel(AdmmPreArgs<T> a) {
   const int blk = is_x ? blockIdx.x : blockIdx.x - a.blocks_x;
   const int n = is_x ? a.n_x : a.n_y;
   const FnView<T> fn = is_x ? a.g : a.f;
+  const FnUniform<T> uni = is_x ? a.ug : a.uf;
   const T *cur = is_x ? a.x_cur : a.y_cur;
   const T *zt = is_x ? a.xt : a.yt;
   T *z12 = is_x ? a.x12 : a.y12;
@@ -51,7 +52,12 @@ __global__ void __launch_bounds__(kVecTpb) admm_pre_kernel(AdmmPreArgs<T> a) {
     const int i = (blk * kPreU + u) * kVecTpb + threadIdx.x;
     if (i < n) {
       prev[u] = cur[i]; ztv[u] = zt[i];
-      fh[u] = fn.h[i]; fa[u] = fn.a[i]; fb[u] = fn.b[i]; fc[u] = fn.c[i]; fd[u] = fn.d[i]; fe[u] = fn.e[i];
+      fa[u] = fn.a[i]; fb[u] = fn.b[i];
+      // (uniform per workgroup) an array that holds one value throughout is not read
+      fh[u] = (uni.mask & 1) ? uni.h : fn.h[i];
+      fc[u] = (uni.mask & 2) ? uni.c : fn.c[i];
+      fd[u] = (uni.mask & 4) ? uni.d : fn.d[i];
+      fe[u] = (uni.mask & 8) ? uni.e : fn.e[i];
     }
   }
 #pragma unroll
@@ -247,6 +253,43 @@ void launch_scale_objective(FnView<T> fn, T *a, T *c, T *d, T *e, const T *scale
   if (n <= 0) return;
   hipLaunchKernelGGL(scale_objective_kernel<T>, dim3(vec_blocks(n)), dim3(kVecTpb), 0, s, fn, a, c, d, e,
                      scale, n, divide);
+}
+
+namespace {
+template <typename T>
+struct UniformProbeOut {
+  int differs;   // bit k set: array k (h, c, d, e) holds more than one value
+  int h0;
+  T c0, d0, e0;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) uniform_probe_kernel(FnView<T> fn, int n, UniformProbeOut<T> *out) {
+  const int h0 = fn.h[0];
+  const T c0 = fn.c[0], d0 = fn.d[0], e0 = fn.e[0];
+  int bad = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    bad |= (fn.h[i] != h0) ? 1 : 0;
+    bad |= (fn.c[i] != c0) ? 2 : 0;   // (a NaN differs from itself: such an array is simply read as before)
+    bad |= (fn.d[i] != d0) ? 4 : 0;
+    bad |= (fn.e[i] != e0) ? 8 : 0;
+  }
+  if (bad) atomicOr(&out->differs, bad);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { out->h0 = h0; out->c0 = c0; out->d0 = d0; out->e0 = e0; }
+}
+}  // namespace
+template <typename T>
+FnUniform<T> probe_uniform(FnView<T> fn, int n, hipStream_t s) {
+  FnUniform<T> u;
+  if (n <= 0) return u;
+  DevBuf<UniformProbeOut<T>> out(1);
+  out.zero(s);
+  hipLaunchKernelGGL(uniform_probe_kernel<T>, dim3(std::max(1, std::min((n + 255) / 256, 2048))), dim3(256), 0, s, fn, n, out.p);
+  UniformProbeOut<T> h;
+  POGS_HIP_CHECK(hipMemcpyAsync(&h, out.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  POGS_HIP_CHECK(hipStreamSynchronize(s));
+  u.mask = ~h.differs & 15;
+  u.h = h.h0; u.c = h.c0; u.d = h.d0; u.e = h.e0;
+  return u;
 }
 
 template <typename T>
@@ -502,6 +545,7 @@ double measure_read_bandwidth_gbs(size_t bytes, int reps, int *pattern) {
 #define POGS_INST(T)                                                                                     \
   template void launch_scale_objective<T>(FnView<T>, T *, T *, T *, T *, const T *, int, bool, hipStream_t); \
   template void launch_admm_pre<T>(const AdmmPreArgs<T> &, hipStream_t);                                 \
+  template FnUniform<T> probe_uniform<T>(FnView<T>, int, hipStream_t);                                   \
   template void launch_admm_tail<T>(int, const T *, const T *, const T *, T *, double *, hipStream_t);   \
   template void launch_func_eval<T>(int, FnView<T>, const T *, double *, hipStream_t);                   \
   template void launch_prox_eval<T>(int, FnView<T>, T, const T *, T *, hipStream_t);                     \

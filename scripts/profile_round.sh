@@ -4,7 +4,7 @@
 #   kernel_stats.csv          rocprofv3 --kernel-trace --stats summary of the same command
 #   pmc_traffic.json          FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes, corrected)
 # usage: profile_round.sh <tag> [c2|c3|c4|c2f64]       (then copy the three files into profiles/)
-tag=${1:-r04}
+tag=${1:-r05}
 cfg=${2:-c2}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_${tag}_${cfg}
@@ -15,6 +15,7 @@ python -c 'import torch; torch.zeros(1, device="cuda")' > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- python $R/bench.py --config $cfg --steps 200 --warmup 20 --no-cpu-baseline --no-live-traffic > $O/kt.log 2>&1
 db=$(find $O/kt -name "*.db" | head -1)
 python $R/scripts/rocpd_summary.py $db $O/kernel_stats.csv
+python $R/scripts/iter_gaps.py $db $O/iter_gaps.json > $O/iter_gaps.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o g -- python $R/bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic > $O/pmc_$c.log 2>&1
 done

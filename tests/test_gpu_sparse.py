@@ -174,6 +174,51 @@ def test_sparse_wide_matrix_follows_oracle(dtype, order):
         objective(A.astype(np.float64), f, g, want["x"]), rel=_tol(dtype, 1e-7, 1e-5))
 
 
+@pytest.mark.parametrize("case", ["uniform", "c_varies", "all_vary", "h_varies"])
+def test_sparse_prox_step_with_uniform_and_per_element_coefficients(case):
+    """The sparse prox step does not stream coefficient arrays that hold one value throughout (vec_kernels.h:
+    FnUniform, probed on the device per solve: h, c, d, e of a lasso) -- every mix of uniform and per-element
+    arrays must give the oracle's solve (prox_lib.h:207-230: the coefficients enter per element)."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    m, n = 3000, 800
+    A, b, _ = synth.csr_lasso(m, n, 20, seed=31, dtype=np.float64)
+    f, g = pogs.graph.lasso_functions(b, 0.1, n)
+    rng = np.random.default_rng(5)
+    if case in ("c_varies", "all_vary"):
+        f.c = rng.uniform(0.5, 2.0, m)
+        g.c = 0.1 * rng.uniform(0.5, 2.0, n)
+    if case == "all_vary":
+        f.d = 0.01 * rng.standard_normal(m)
+        f.e = rng.uniform(0.0, 0.2, m)
+        g.d = 0.01 * rng.standard_normal(n)
+        g.e = rng.uniform(0.0, 0.2, n)
+    if case == "h_varies":
+        g.h = np.where(rng.random(n) < 0.5, int(pogs.graph.Function.kAbs), int(pogs.graph.Function.kHuber)).astype(np.int32)
+        f.h = np.where(rng.random(m) < 0.7, int(pogs.graph.Function.kSquare), int(pogs.graph.Function.kHuber)).astype(np.int32)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float64)
+    got = pogs.graph._solve_graph_form(A, f, g, dtype=np.float64)
+    _check(got, want, 1e-6, 2)
+
+
+def test_stamps_diagnostic_prints_per_xcd_times_and_changes_nothing(monkeypatch, capfd):
+    """POGS_AMD_SELL_STAMPS=1: per-workgroup time stamps of both SpMVs, summed per XCC id, on stderr once per handle
+    (sell.h / profiles/NOTES_r05.md: the evidence that the XCDs stream at the same rate); the solve is the same."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.csr_lasso(20000, 5000, 50, seed=3, dtype=np.float32)
+    base = pogs.solve_lasso(A, b, 0.1, dtype=np.float32)
+    capfd.readouterr()
+    monkeypatch.setenv("POGS_AMD_SELL_STAMPS", "1")
+    got = pogs.solve_lasso(A, b, 0.1, dtype=np.float32)
+    err = capfd.readouterr().err
+    lines = [ln for ln in err.splitlines() if ln.startswith("[pogs_amd stamps]")]
+    assert len(lines) == 2 and "20000 x 5000" in lines[0] and "5000 x 20000" in lines[1], err[-800:]
+    assert got["iterations"] == base["iterations"] and np.array_equal(got["x"], base["x"])
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_cg_loop_variants_walk_the_same_trajectory(dtype, monkeypatch):
     """The device-resident CGLS loop (cg_fused.h) with y = A x from the CG recurrence every iteration
