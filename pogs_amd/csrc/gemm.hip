@@ -894,6 +894,12 @@ void launch_gemm(bool a_kmaj, bool b_kmaj, bool lower_only, const GemmArgs<T> &g
   else launch_gemm_ab<T, true, false>(lower_only, g, s);
 }
 
+// (Measured in round 5 and not kept: a LOOK-AHEAD form -- the trailing update of group k on a second stream, in three
+// pieces with an event after the next group's block columns, while the main stream factorises group k + 1; the chain
+// diagonal block -> panel product is 7 of the phase's 12.3 ms at n = 10000 and needs only those columns.  Same bits
+// (the pieces are the tiles of the one launch, cut at tile boundaries), but slower on every shape: 13.4 against 12.3 ms
+// (C2), 25.6 against 23.5 (C2 in fp64), 5.8 against 4.6 (C3) -- two cross-stream event waits per group cost more than
+// the one-workgroup factorisation gains beside a GEMM that fills the device; profiles/NOTES_r05.md.)
 template <typename T>
 void cholesky_lower(T *G, size_t ldg, int n, T *W, size_t ldw, hipStream_t s) {
   constexpr int NB = CholBlock<T>::NB;

@@ -23,5 +23,6 @@ python $R/scripts/pmc_summary.py $(find $O/pmc_FETCH_SIZE -name "*counter_collec
 rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 # the plain run comes last so that its line quotes the counters collected above (same sources, same box)
 cp $O/pmc_traffic.json $R/profiles/pmc_traffic_${cfg}.json
-python $R/bench.py --config $cfg --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.err
-cat $O/bench.json
+# (third argument "--no-cpu": skip the CPU leg of the plain run -- minutes at c2 / c3 / c4)
+python $R/bench.py --config $cfg --steps 200 --warmup 20 $([ "$3" = "--no-cpu" ] && echo --no-cpu-baseline) > $O/bench.json 2> $O/bench.err
+tail -c 600 $O/bench.json
