@@ -187,6 +187,26 @@ int PogsAmdSolve(PogsAmdSolver *s,
                  void *x, void *y, void *l, void *mu, double *optval,
                  unsigned int *final_iter);
 
+/* The same solve with BROADCAST coefficients: a field of f or g whose pointer is NULL holds one value (a0 .. e0, h0) for
+ * every element and is filled on the device -- the caller neither builds nor converts nor uploads an array for it.  A
+ * lasso's f is (h = SQUARE, a = 1, b = b_i, c = 1, d = 0, e = 0) and its g (h = ABS, a = 1, b = 0, c = lambda, d = e = 0):
+ * one per-element array out of twelve (python/pogs/graph.py:428,431 builds m + n objects for them; at 2.5e6 elements
+ * the twelve arrays are 60 MB of host work per solve).  Everything else as PogsAmdSolve / PogsAmdBeginRun. */
+typedef struct PogsAmdFn {
+  const void *a, *b, *c, *d, *e;   /* HOST arrays of the solver's dtype, or NULL */
+  const int *h;                    /* HOST array of enum FUNCTION values, or NULL */
+  double a0, b0, c0, d0, e0;       /* the value of a field whose pointer is NULL  */
+  int h0;
+} PogsAmdFn;
+int PogsAmdSolveFn(PogsAmdSolver *s, const PogsAmdFn *f, const PogsAmdFn *g,
+                   double rho, double abs_tol, double rel_tol, unsigned int max_iter,
+                   unsigned int verbose, int adaptive_rho, int gap_stop,
+                   void *x, void *y, void *l, void *mu, double *optval,
+                   unsigned int *final_iter);
+int PogsAmdBeginRunFn(PogsAmdSolver *s, const PogsAmdFn *f, const PogsAmdFn *g,
+                      double rho, double abs_tol, double rel_tol, unsigned int max_iter,
+                      int adaptive_rho, int gap_stop);
+
 /* Benchmark stepping.  PogsAmdBeginRun loads f/g and the solve parameters and
  * resets the ADMM state to the cold start; PogsAmdIterate then advances exactly
  * `iters` ADMM iterations of real solves (restarting from the cold start each

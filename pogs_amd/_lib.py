@@ -109,6 +109,17 @@ lib.PogsAmdCreateSparse.argtypes = [ctypes.POINTER(c_void_p), c_int, c_int, c_si
 lib.PogsAmdSolve.argtypes = [c_void_p] + [c_void_p] * 12 + [c_double, c_double, c_double, c_uint, c_uint, c_int, c_int,
                                                             c_void_p, c_void_p, c_void_p, c_void_p,
                                                             ctypes.POINTER(c_double), ctypes.POINTER(c_uint)]
+class PogsAmdFn(ctypes.Structure):
+    """include/pogs_amd.h: a function vector whose NULL fields are broadcast scalars."""
+    _fields_ = [("a", c_void_p), ("b", c_void_p), ("c", c_void_p), ("d", c_void_p), ("e", c_void_p), ("h", c_void_p),
+                ("a0", c_double), ("b0", c_double), ("c0", c_double), ("d0", c_double), ("e0", c_double), ("h0", c_int)]
+
+
+lib.PogsAmdSolveFn.argtypes = [c_void_p, ctypes.POINTER(PogsAmdFn), ctypes.POINTER(PogsAmdFn), c_double, c_double, c_double,
+                               c_uint, c_uint, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                               ctypes.POINTER(c_double), ctypes.POINTER(c_uint)]
+lib.PogsAmdBeginRunFn.argtypes = [c_void_p, ctypes.POINTER(PogsAmdFn), ctypes.POINTER(PogsAmdFn), c_double, c_double, c_double,
+                                  c_uint, c_int, c_int]
 lib.PogsAmdBeginRun.argtypes = [c_void_p] + [c_void_p] * 12 + [c_double, c_double, c_double, c_uint, c_int, c_int]
 lib.PogsAmdIterate.argtypes = [c_void_p, c_uint, ctypes.POINTER(c_double), ctypes.POINTER(c_uint)]
 lib.PogsAmdSetWarmStart.argtypes = [c_void_p, c_void_p, c_void_p]
@@ -155,7 +166,7 @@ def pool_trim(device=-1):
 # Every symbol include/pogs_amd.h declares (checked by tests/test_abi.py).
 ABI_SYMBOLS = [
     "PogsD", "PogsS", "PogsSparseD", "PogsSparseS",
-    "PogsAmdDistUniqueId", "PogsAmdCreateDense", "PogsAmdCreateSparse", "PogsAmdSolve", "PogsAmdBeginRun",
+    "PogsAmdDistUniqueId", "PogsAmdCreateDense", "PogsAmdCreateSparse", "PogsAmdSolve", "PogsAmdSolveFn", "PogsAmdBeginRun", "PogsAmdBeginRunFn",
     "PogsAmdIterate", "PogsAmdSetWarmStart", "PogsAmdGetStats", "PogsAmdResetStats", "PogsAmdDestroy", "PogsAmdLastError",
     "PogsAmdPoolStats", "PogsAmdPoolTrim",
     "PogsAmdProxEval", "PogsAmdFuncEval", "PogsAmdProjSubgradEval", "PogsAmdGetEquil", "PogsAmdProject", "PogsAmdMul", "PogsAmdRandUniform",

@@ -309,6 +309,40 @@ int PogsAmdSolve(PogsAmdSolver *s, const void *f_a, const void *f_b, const void 
   }, s);
 }
 
+namespace {
+FnHost fn_host(const PogsAmdFn *p) {
+  POGS_CHECK(p != nullptr, "null function description");
+  FnHost f{p->a, p->b, p->c, p->d, p->e, p->h};
+  f.s0[0] = p->a0; f.s0[1] = p->b0; f.s0[2] = p->c0; f.s0[3] = p->d0; f.s0[4] = p->e0;
+  f.h0 = p->h0;
+  POGS_CHECK(p->h || (p->h0 >= 0 && p->h0 <= 15), "function code out of range");
+  return f;
+}
+}  // namespace
+
+int PogsAmdSolveFn(PogsAmdSolver *s, const PogsAmdFn *f, const PogsAmdFn *g, double rho, double abs_tol, double rel_tol,
+                   unsigned int max_iter, unsigned int verbose, int adaptive_rho, int gap_stop, void *x, void *y, void *l,
+                   void *mu, double *optval, unsigned int *final_iter) {
+  return guarded([&]() {
+    POGS_CHECK(s && s->impl, "null solver");
+    DeviceGuard guard(s->impl->device());
+    const FnHost fh = fn_host(f), gh = fn_host(g);
+    return s->impl->solve(fh, gh, make_params(rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop), x, y, l, mu,
+                          optval, final_iter);
+  }, s);
+}
+
+int PogsAmdBeginRunFn(PogsAmdSolver *s, const PogsAmdFn *f, const PogsAmdFn *g, double rho, double abs_tol, double rel_tol,
+                      unsigned int max_iter, int adaptive_rho, int gap_stop) {
+  return guarded([&]() {
+    POGS_CHECK(s && s->impl, "null solver");
+    DeviceGuard guard(s->impl->device());
+    const FnHost fh = fn_host(f), gh = fn_host(g);
+    s->impl->begin_run(fh, gh, make_params(rho, abs_tol, rel_tol, max_iter, 0, adaptive_rho, gap_stop));
+    return 0;
+  }, s);
+}
+
 int PogsAmdBeginRun(PogsAmdSolver *s, const void *f_a, const void *f_b, const void *f_c, const void *f_d,
                     const void *f_e, const int *f_h, const void *g_a, const void *g_b, const void *g_c,
                     const void *g_d, const void *g_e, const int *g_h, double rho, double abs_tol, double rel_tol,

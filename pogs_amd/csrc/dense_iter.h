@@ -7,32 +7,20 @@
 template <typename T, typename Tag>
 void DenseSolver<T, Tag>::load_problem(const FnHost &f, const FnHost &g, const SolveParams &p) {
   hipStream_t s = ctx_.stream;
-  auto up = [&](FnBuf<T> &dst, const FnHost &src, int cnt) {
-    POGS_HIP_CHECK(hipMemcpyAsync(dst.h.p, src.h, cnt * sizeof(int), hipMemcpyHostToDevice, s));
-    POGS_HIP_CHECK(hipMemcpyAsync(dst.a.p, src.a, cnt * sizeof(T), hipMemcpyHostToDevice, s));
-    POGS_HIP_CHECK(hipMemcpyAsync(dst.b.p, src.b, cnt * sizeof(T), hipMemcpyHostToDevice, s));
-    POGS_HIP_CHECK(hipMemcpyAsync(dst.c.p, src.c, cnt * sizeof(T), hipMemcpyHostToDevice, s));
-    POGS_HIP_CHECK(hipMemcpyAsync(dst.d.p, src.d, cnt * sizeof(T), hipMemcpyHostToDevice, s));
-    POGS_HIP_CHECK(hipMemcpyAsync(dst.e.p, src.e, cnt * sizeof(T), hipMemcpyHostToDevice, s));
-  };
-  up(f_, f, m_);
-  up(g_, g, n_);
+  upload_fn<T>(f_, f, m_, s);
+  upload_fn<T>(g_, g, n_, s);
   warn_negative_coeffs<T>(f, m_);   // prox_lib.h:62-69 (the clamp is in scale_objective_kernel)
   warn_negative_coeffs<T>(g, n_);
   // the one-pass kernel evaluates prox_f inline: only for the cheap base functions
   bool all_cheap = true, all_logistic = true;
   if (tmode_) {   // transposed storage: it is prox_g that runs inside the pass
     all_logistic = false;
-    for (int j = 0; j < n_; ++j) all_cheap = all_cheap && is_cheap_prox(g.h[j]);
+    all_cheap = all_h(g, n_, [](int h) { return is_cheap_prox(h); });
   } else {
-    for (int i = 0; i < m_; ++i) {
-      all_cheap = all_cheap && is_cheap_prox(f.h[i]);
-      all_logistic = all_logistic && f.h[i] == kLogistic;
-    }
+    all_cheap = all_h(f, m_, [](int h) { return is_cheap_prox(h); });
+    all_logistic = all_h(f, m_, [](int h) { return h == kLogistic; });
   }
-  pre_cheap_ = true;
-  for (int i = 0; i < m_ && pre_cheap_; ++i) pre_cheap_ = is_cheap_prox(f.h[i]);
-  for (int j = 0; j < n_ && pre_cheap_; ++j) pre_cheap_ = is_cheap_prox(g.h[j]);
+  pre_cheap_ = all_h(f, m_, [](int h) { return is_cheap_prox(h); }) && all_h(g, n_, [](int h) { return is_cheap_prox(h); });
   fused_now_ = fused_ok_ && (all_cheap || all_logistic);
   fused_logistic_ = fused_now_ && all_logistic && !all_cheap;
   // scaled copies: h and b shared with the originals (pogs.cpp:608-617)

@@ -576,7 +576,36 @@ struct SolveParams {
 struct FnHost {  // host SoA, element type = solver dtype
   const void *a, *b, *c, *d, *e;
   const int *h;
+  // PogsAmdSolveFn / PogsAmdBeginRunFn: a field whose pointer is null holds ONE value for every element (a0 .. e0
+  // in this order, h0) -- it is filled on the device instead of being built, converted and uploaded by the caller
+  double s0[5] = {1.0, 0.0, 1.0, 0.0, 0.0};
+  int h0 = 15;   // kZero
+  int hval(size_t i) const { return h ? h[i] : h0; }
 };
+
+// Host-side scans of the function codes: one look when the codes are broadcast.
+template <typename Pred>
+inline bool all_h(const FnHost &f, size_t count, Pred pred) {
+  if (!f.h) return count == 0 || pred(f.h0);
+  for (size_t i = 0; i < count; ++i)
+    if (!pred(f.h[i])) return false;
+  return true;
+}
+
+// The six coefficient arrays of `src` into the device SoA `dst` (cnt elements each): copied from the host, or filled
+// on the device where the host gave one value for all.
+template <typename T>
+inline void upload_fn(FnBuf<T> &dst, const FnHost &src, int cnt, hipStream_t s) {
+  if (cnt <= 0) return;
+  if (src.h) POGS_HIP_CHECK(hipMemcpyAsync(dst.h.p, src.h, cnt * sizeof(int), hipMemcpyHostToDevice, s));
+  else launch_fill_int(dst.h.p, src.h0, static_cast<size_t>(cnt), s);
+  const void *ptr[5] = {src.a, src.b, src.c, src.d, src.e};
+  T *out[5] = {dst.a.p, dst.b.p, dst.c.p, dst.d.p, dst.e.p};
+  for (int k = 0; k < 5; ++k) {
+    if (ptr[k]) POGS_HIP_CHECK(hipMemcpyAsync(out[k], ptr[k], cnt * sizeof(T), hipMemcpyHostToDevice, s));
+    else launch_fill<T>(out[k], static_cast<T>(src.s0[k]), static_cast<size_t>(cnt), s);
+  }
+}
 
 // FunctionObj::CheckConsts (src/include/prox_lib.h:62-69): a negative c or e is not convex; the
 // reference prints a warning per offending object and uses 0.  The clamp itself happens on the
@@ -587,10 +616,15 @@ inline unsigned warn_negative_coeffs(const FnHost &f, size_t count) {
   constexpr unsigned kMaxWarn = 8;
   const T *c = static_cast<const T *>(f.c), *e = static_cast<const T *>(f.e);
   unsigned nc = 0, ne = 0;
-  for (size_t i = 0; i < count; ++i) {
+  // (a broadcast coefficient is one value: one look, the count of objects it stands for)
+  if (!c && count && f.s0[2] < 0.0) nc = static_cast<unsigned>(std::min<size_t>(count, 0xFFFFFFFFu));
+  if (!e && count && f.s0[4] < 0.0) ne = static_cast<unsigned>(std::min<size_t>(count, 0xFFFFFFFFu));
+  for (unsigned w = 0; w < std::min(nc, kMaxWarn); ++w) std::printf("WARNING c < 0. Function not convex. Using c = 0");
+  for (unsigned w = 0; w < std::min(ne, kMaxWarn); ++w) std::printf("WARNING e < 0. Function not convex. Using e = 0");
+  for (size_t i = 0; i < count && (c || e); ++i) {
     // (the reference's messages carry no newline: Printf at prox_lib.h:64,66)
-    if (c[i] < static_cast<T>(0) && nc++ < kMaxWarn) std::printf("WARNING c < 0. Function not convex. Using c = 0");
-    if (e[i] < static_cast<T>(0) && ne++ < kMaxWarn) std::printf("WARNING e < 0. Function not convex. Using e = 0");
+    if (c && c[i] < static_cast<T>(0) && nc++ < kMaxWarn) std::printf("WARNING c < 0. Function not convex. Using c = 0");
+    if (e && e[i] < static_cast<T>(0) && ne++ < kMaxWarn) std::printf("WARNING e < 0. Function not convex. Using e = 0");
   }
   if (nc > kMaxWarn) std::printf("\nWARNING c < 0 in %u more function objects", nc - kMaxWarn);
   if (ne > kMaxWarn) std::printf("\nWARNING e < 0 in %u more function objects", ne - kMaxWarn);

@@ -1234,21 +1234,11 @@ class SparseSolver final : public SolverBase {
   // ---- per solve -----------------------------------------------------------
   void load_problem(const FnHost &f, const FnHost &g, const SolveParams &p) {
     hipStream_t s = ctx_.stream;
-    auto up = [&](FnBuf<T> &dst, const FnHost &src, int cnt) {
-      POGS_HIP_CHECK(hipMemcpyAsync(dst.h.p, src.h, cnt * sizeof(int), hipMemcpyHostToDevice, s));
-      POGS_HIP_CHECK(hipMemcpyAsync(dst.a.p, src.a, cnt * sizeof(T), hipMemcpyHostToDevice, s));
-      POGS_HIP_CHECK(hipMemcpyAsync(dst.b.p, src.b, cnt * sizeof(T), hipMemcpyHostToDevice, s));
-      POGS_HIP_CHECK(hipMemcpyAsync(dst.c.p, src.c, cnt * sizeof(T), hipMemcpyHostToDevice, s));
-      POGS_HIP_CHECK(hipMemcpyAsync(dst.d.p, src.d, cnt * sizeof(T), hipMemcpyHostToDevice, s));
-      POGS_HIP_CHECK(hipMemcpyAsync(dst.e.p, src.e, cnt * sizeof(T), hipMemcpyHostToDevice, s));
-    };
-    up(f_, f, m_);
-    up(g_, g, n_);
+    upload_fn<T>(f_, f, m_, s);
+    upload_fn<T>(g_, g, n_, s);
     warn_negative_coeffs<T>(f, m_);   // prox_lib.h:62-69 (the clamp is in scale_objective_kernel)
     warn_negative_coeffs<T>(g, n_);
-    pre_cheap_ = true;
-    for (int i = 0; i < m_ && pre_cheap_; ++i) pre_cheap_ = is_cheap_prox(f.h[i]);
-    for (int j = 0; j < n_ && pre_cheap_; ++j) pre_cheap_ = is_cheap_prox(g.h[j]);
+    pre_cheap_ = all_h(f, m_, [](int h) { return is_cheap_prox(h); }) && all_h(g, n_, [](int h) { return is_cheap_prox(h); });
     launch_scale_objective<T>(f_.view(), fs_.a.p, fs_.c.p, fs_.d.p, fs_.e.p, d_.p, m_, true, s);
     launch_scale_objective<T>(g_.view(), gs_.a.p, gs_.c.p, gs_.d.p, gs_.e.p, e_.p, n_, false, s);
     // coefficient arrays that hold one value throughout (a lasso: h, c, d, e of both halves) are not streamed by the

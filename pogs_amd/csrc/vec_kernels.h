@@ -173,6 +173,7 @@ double measure_read_bandwidth_gbs(size_t bytes, int reps, int *pattern);
 
 // Misc vector helpers.
 template <typename T> void launch_fill(T *p, T v, size_t n, hipStream_t s);
+void launch_fill_int(int *p, int v, size_t n, hipStream_t s);
 template <typename T> void launch_sqrt_inplace(T *p, size_t n, hipStream_t s);
 template <typename T> void launch_scal(T *p, T alpha, size_t n, hipStream_t s);
 // out[i] = alpha * in[i] * (divide ? 1 / sc[i] : sc[i])   (warm start: x0 / e, lambda0 / d)

@@ -448,6 +448,9 @@ template <typename T>
 void launch_fill(T *p, T v, size_t n, hipStream_t s) {
   if (n) hipLaunchKernelGGL(fill_kernel<T>, grid1d(n), dim3(256), 0, s, p, v, n);
 }
+void launch_fill_int(int *p, int v, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(fill_kernel<int>, grid1d(n), dim3(256), 0, s, p, v, n);
+}
 template <typename T>
 void launch_sqrt_inplace(T *p, size_t n, hipStream_t s) {
   if (n) hipLaunchKernelGGL(sqrt_kernel<T>, grid1d(n), dim3(256), 0, s, p, n);

@@ -418,10 +418,23 @@ class Solver:
         _LIVE_SOLVERS.add(self)
 
     def _coef(self, f, g):
+        """(f, g) as two PogsAmdFn structures: per-element fields as typed host arrays, fields that are still scalars
+        as broadcast values (filled on the device; include/pogs_amd.h: PogsAmdSolveFn).  Returns (structs, keep-alive)."""
         assert len(f) == self.m and len(g) == self.n
-        fa, ga = _as_vector(f).arrays(self.dtype), _as_vector(g).arrays(self.dtype)
-        args = [_ptr(fa[k]) for k in "abcdeh"] + [_ptr(ga[k]) for k in "abcdeh"]
-        return args, (fa, ga)
+        keep, structs = [], []
+        for fv in (_as_vector(f), _as_vector(g)):
+            st = _lib.PogsAmdFn()
+            for k in FunctionVector._FIELDS:
+                v = fv._v[k]
+                if isinstance(v, np.ndarray):
+                    arr = np.ascontiguousarray(v, dtype=np.int32 if k == "h" else self.dtype)
+                    keep.append(arr)
+                    setattr(st, k, arr.ctypes.data)
+                else:
+                    setattr(st, k, None)
+                    setattr(st, k + "0", int(v) if k == "h" else float(v))
+            structs.append(st)
+        return structs, keep
 
     def warm_start(self, x0, l0):
         """Start the next solve from (x0, lambda0) instead of zero (reference: SetInitX /
@@ -443,9 +456,9 @@ class Solver:
         mu = np.zeros(self.n, self.dtype)
         optval = ctypes.c_double()
         final_iter = ctypes.c_uint()
-        status = lib.PogsAmdSolve(self._h, *args, rho, abs_tol, rel_tol, int(max_iter), int(verbose),
-                                  int(adaptive_rho), int(gap_stop), _ptr(x), _ptr(y), _ptr(l), _ptr(mu),
-                                  ctypes.byref(optval), ctypes.byref(final_iter))
+        status = lib.PogsAmdSolveFn(self._h, ctypes.byref(args[0]), ctypes.byref(args[1]), rho, abs_tol, rel_tol,
+                                    int(max_iter), int(verbose), int(adaptive_rho), int(gap_stop), _ptr(x), _ptr(y),
+                                    _ptr(l), _ptr(mu), ctypes.byref(optval), ctypes.byref(final_iter))
         del keep
         if status == POGS_ERROR:
             raise RuntimeError("pogs_amd: solve failed: " + _lib.last_error())
@@ -454,8 +467,8 @@ class Solver:
 
     def begin_run(self, f, g, abs_tol=1e-4, rel_tol=1e-4, max_iter=2500, rho=1.0, adaptive_rho=True, gap_stop=True):
         args, keep = self._coef(f, g)
-        st = lib.PogsAmdBeginRun(self._h, *args, rho, abs_tol, rel_tol, int(max_iter), int(adaptive_rho),
-                                 int(gap_stop))
+        st = lib.PogsAmdBeginRunFn(self._h, ctypes.byref(args[0]), ctypes.byref(args[1]), rho, abs_tol, rel_tol,
+                                   int(max_iter), int(adaptive_rho), int(gap_stop))
         del keep
         if st != 0:
             raise RuntimeError("pogs_amd: begin_run failed: " + _lib.last_error())

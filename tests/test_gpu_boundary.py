@@ -311,3 +311,49 @@ def test_the_reference_loader_restated_picks_up_the_alias_and_solves_c1(tmp_path
     gold = np.load(os.path.join(ROOT, "tests", "golden", "reference_outputs.npz"))
     assert out["iterations"] == int(gold["c1_f64_iterations"]) and out["status"] == int(gold["c1_f64_status"])
     assert relerr(np.array(out["x"]), gold["c1_f64_x"]) < 1e-9
+
+
+@pytest.mark.parametrize("kind", ["dense", "sparse"])
+def test_broadcast_coefficients_give_the_array_paths_bits(kind):
+    """`Solver.solve` hands fields that are still scalars to `PogsAmdSolveFn` as broadcast values (filled on the device;
+    include/pogs_amd.h) instead of building, converting and uploading an array each: the solve must come out bit for bit
+    as with all twelve arrays spelled out (`PogsAmdSolve`), for a lasso (one per-element field) and for a vector whose
+    every field is per-element; a negative broadcast `c` is clamped with the reference's warning like an array's."""
+    import ctypes
+
+    import pogs_amd
+    from pogs_amd import _lib, synth
+    from pogs_amd import graph as G
+
+    if kind == "dense":
+        A, b, _ = synth.dense_lasso(3000, 400, seed=61, dtype=np.float32)
+    else:
+        A, b, _ = synth.csr_lasso(6000, 1500, 20, seed=61, dtype=np.float32)
+    m, n = A.shape
+    f, g = G.lasso_functions(b, 0.1, n)
+    assert not isinstance(f._v["c"], np.ndarray) and isinstance(f._v["b"], np.ndarray)     # scalars stayed scalars
+    with pogs_amd.Solver(A, dtype=np.float32) as s:
+        got = s.solve(f, g)                                                              # PogsAmdSolveFn, 1 array of 12
+        fa, ga = f.arrays(np.float32), g.arrays(np.float32)
+        x, y, l, mu = np.zeros(n, np.float32), np.zeros(m, np.float32), np.zeros(m, np.float32), np.zeros(n, np.float32)
+        optval, it = ctypes.c_double(), ctypes.c_uint()
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        st = _lib.lib.PogsAmdSolve(s._h, *[ptr(fa[k]) for k in "abcdeh"], *[ptr(ga[k]) for k in "abcdeh"], 1.0, 1e-4, 1e-4,
+                                   2500, 0, 1, 1, ptr(x), ptr(y), ptr(l), ptr(mu), ctypes.byref(optval), ctypes.byref(it))
+        assert st == got["status"] == 0 and it.value == got["iterations"]
+        assert np.array_equal(x, got["x"]) and np.array_equal(y, got["y"]) and np.array_equal(l, got["l"])
+        assert optval.value == got["optval"]
+        # every field per element (the scalars read as arrays once): the same bits again
+        f2, g2 = G.lasso_functions(b, 0.1, n)
+        for fv in (f2, g2):
+            for k in "habcde":
+                getattr(fv, k)
+            assert all(isinstance(fv._v[k], np.ndarray) for k in "habcde")
+        again = s.solve(f2, g2)
+        assert again["iterations"] == got["iterations"] and np.array_equal(again["x"], got["x"])
+        # a negative broadcast c: clamped to 0 (prox_lib.h:62-69), i.e. g = 0 -> plain least squares, like the array form
+        g3 = G.FunctionVector(n, G.Function.kAbs, 1.0, 0.0, -0.5)
+        g4 = G.FunctionVector(n, G.Function.kAbs, 1.0, 0.0, -0.5)
+        g4.c
+        r3, r4 = s.solve(f, g3), s.solve(f, g4)
+        assert r3["status"] == r4["status"] and np.array_equal(r3["x"], r4["x"])
