@@ -375,6 +375,30 @@ def cpu_baseline(name, cfg, A_host, f, g, args, engine, world=1):
     return out, live
 
 
+def pick_windows(K, L, per_step_s, min_s=0.25, max_windows=40):
+    """Number of back-to-back windows of K steps for a workload whose solve takes L iterations: W K as close to a
+    whole number k of solves as W <= max_windows allows, the smallest k that makes the timed stretch at least `min_s`
+    seconds.  Returns (W, fraction of a solve by which W K misses k L)."""
+    if K >= 3 * L:
+        return 1, abs(K - round(K / L) * L) / float(K)
+    best = None
+    for k in range(1, 33):
+        w = max(1, int(round(k * L / float(K))))
+        if w > max_windows:
+            break
+        err = abs(w * K - k * L) / float(L)
+        long_enough = w * K * per_step_s >= min_s
+        # (a stretch that stays too short whatever k: the longest one that is still close to whole solves)
+        cand = (0, round(err, 3), w) if long_enough else (1, 0 if err <= 0.06 else 1, -w)
+        if best is None or cand < best[0]:
+            best = (cand, w, err)
+        if long_enough and err <= 0.06:
+            break
+    if best is None:
+        return max(1, min(max_windows, int(round(L / float(K))))), 1.0
+    return best[1], best[2]
+
+
 def csrc_sha16():
     """sha256 (first 16 hex digits) over the kernel sources, as scripts/pmc_summary.py records it."""
     import hashlib
@@ -667,9 +691,18 @@ def run_config(env, name, with_cpu):
 
     solver.begin_run(f, g)
     solver.iterate(args.warmup)
-    # exactly K steps between barriers; several windows when K steps are too short to time well
+    # exactly K steps between barriers, in as many back-to-back windows as make the timed stretch a whole number of
+    # SOLVES (pick_windows): the iterations of a solve do not cost the same (a CGLS projection takes 4 steps early in
+    # a C4 solve, 1 in its middle, 2-3 plus the exact-residual products at its end: 1.5 / 0.53 / 1.06 ms per iteration),
+    # and the metric is a solve's iterations over its loop time -- a window that covers the cheap
+    # middle of a solve would flatter it.  The iterations run periodically (a converged solve restarts from the cold
+    # start), so any stretch of k whole periods is unbiased whatever its phase.
     per_step_guess = max(st_solve["t_loop_s"] / max(st_solve["iterations"], 1), 1e-6)
-    windows = 1 if args.steps * per_step_guess >= 0.1 else min(25, max(3, int(0.25 / (args.steps * per_step_guess)) | 1))
+    windows, cover = pick_windows(args.steps, int(res["iterations"]) + 1, per_step_guess)
+    if dist is not None:   # every rank must run the same number of windows (barriers): rank 0's choice
+        wt = torch.tensor([windows], dtype=torch.int64, device=dev)
+        dist.broadcast(wt, 0)
+        windows = int(wt.item())
     times = []
     solver.reset_stats()
     for _ in range(windows):
@@ -860,6 +893,9 @@ def run_config(env, name, with_cpu):
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
             "windows": windows, "window_s": times,
+            "windows_cover": "%d x %d = %d iterations = %.2f solves of %d" % (windows, args.steps, windows * args.steps,
+                                                                              windows * args.steps / float(res["iterations"] + 1),
+                                                                              res["iterations"] + 1),
             # (the scalars a reader of the driver's record needs sit in `config` and `roofline`, which it keeps whole:
             # wall-clock-to-converge is half of BASELINE.json's metric)
             "config": {"workload": workload, "name": name, "rows_per_gpu": m, "cols": n, "projector": projector,

@@ -241,3 +241,23 @@ def test_bench_extrapolates_the_cpu_leg_of_a_multi_gpu_line():
     assert "time_to_converge_s" not in r and r["time_to_converge_s_on_one_shard"] == 19.0
     assert r["sample"].startswith("rank 0's shard")
     assert bench.extrapolate_cpu({"value": None}, 8, 1, 1) == {"value": None}
+
+
+def test_bench_windows_cover_whole_solves():
+    """bench.py times exactly K steps per window; the windows together cover a whole number of solves, because the
+    iterations of a solve do not cost the same (C4: 1.5 ms early, 0.53 ms in the middle, 1.06 ms at the end) and the
+    metric is a solve's iterations over its loop time."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for K, L, per_step in ((20, 359, 0.87e-3), (20, 106, 0.68e-3), (20, 189, 0.72e-3), (200, 359, 0.87e-3), (200, 106, 0.68e-3)):
+        w, err = bench.pick_windows(K, L, per_step)
+        solves = w * K / float(L)
+        assert 1 <= w <= 40 and abs(solves - round(solves)) <= 0.06 and err <= 0.06, (K, L, w, solves)
+        assert w * K * per_step >= 0.25
+    assert bench.pick_windows(20, 359, 0.87e-3)[0] == 18                 # one C4 solve
+    assert bench.pick_windows(1000, 106, 0.68e-3)[0] == 1               # K spans many solves already
+    w, _ = bench.pick_windows(20, 2500, 1e-3)                          # a solve longer than 40 windows: as many as allowed
+    assert w == 40
