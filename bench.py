@@ -1005,7 +1005,7 @@ def main():
     # the driver's invocation (no --config, one GPU): c3, c4 (with their CPU legs) and c2 in fp64 under the same clock
     if args.config is None and env.world == 1 and not args.no_secondary and not (args.m or args.n) \
             and args.projector == "default":
-        keep = ("metric", "value", "unit", "dtype", "ms_per_step", "steps", "windows", "window_s", "config", "roofline",
+        keep = ("metric", "value", "unit", "dtype", "ms_per_step", "steps", "windows", "window_s", "windows_cover", "config", "roofline",
                 "time_to_converge_s", "init_s", "handle_cycles", "solve_iterations", "solve_status", "setup_ms", "gram_tflops",
                 "parity_vs_reference", "cpu_baseline", "exact_setup", "time_to_converge_exact_setup_s", "one_shot_host_call")
         sec = {}
