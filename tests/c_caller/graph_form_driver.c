@@ -4,7 +4,10 @@
  * compares what it prints with the python binding and the oracle on the same inputs; the CPU suite
  * only compiles and links it (C99, -Wall -Wextra -Werror -pedantic).
  *
- *   graph_form_driver <dense64|dense32|colmajor64|csr64> m n lambda <file>
+ *   graph_form_driver <dense64|dense32|colmajor64|csr64|handle64> m n lambda <file>
+ *
+ * handle64: the additive part of the header from C -- PogsAmdCreateDense, then PogsAmdSolveFn with every field of f and g
+ * but f.b given as a broadcast value (a PogsAmdFn whose NULL pointers stand for a0 .. e0, h0), PogsAmdDestroy.
  *
  * <file>: raw doubles, A (m x n, row-major; for csr64 its zeros are the sparsity pattern) followed
  * by b (m).  Output: one "key value..." line per result. */
@@ -31,7 +34,7 @@ int main(int argc, char **argv) {
   FILE *in;
   if (argc != 6) return 2;
   kind = !strcmp(argv[1], "dense64") ? 0 : !strcmp(argv[1], "dense32") ? 1 : !strcmp(argv[1], "colmajor64") ? 2
-         : !strcmp(argv[1], "csr64") ? 3 : -1;
+         : !strcmp(argv[1], "csr64") ? 3 : !strcmp(argv[1], "handle64") ? 4 : -1;
   if (kind < 0) return 2;
   m = (size_t)strtoul(argv[2], NULL, 10);
   n = (size_t)strtoul(argv[3], NULL, 10);
@@ -61,6 +64,21 @@ int main(int argc, char **argv) {
     status = PogsD(COL_MAJ, m, n, At, fa, fb, fc, fd, fe, fh, ga, gb, gc, gd, ge, gh, 1.0, 1e-4, 1e-4, 2500u, 0u, 1, 1,
                    x, y, l, &optval, &final_iter);
     free(At);
+  } else if (kind == 4) {
+    PogsAmdSolver *h = NULL;
+    PogsAmdFn f, g;
+    double *mu = calloc(n, sizeof *mu);
+    if (!mu) return 3;
+    memset(&f, 0, sizeof f);
+    memset(&g, 0, sizeof g);
+    f.b = fb;                                    /* the one per-element field of a lasso */
+    f.a0 = 1; f.c0 = 1; f.d0 = 0; f.e0 = 0; f.h0 = SQUARE;
+    g.a0 = 1; g.b0 = 0; g.c0 = lambda; g.d0 = 0; g.e0 = 0; g.h0 = ABS;
+    status = PogsAmdCreateDense(&h, POGS_AMD_F64, ROW_MAJ, m, n, A, POGS_AMD_HOST, NULL, NULL);
+    if (status == 0)
+      status = PogsAmdSolveFn(h, &f, &g, 1.0, 1e-4, 1e-4, 2500u, 0u, 1, 1, x, y, l, mu, &optval, &final_iter);
+    PogsAmdDestroy(h);
+    free(mu);
   } else if (kind == 1) {
     /* every array narrowed to float, results widened for printing */
     float *A32 = malloc(m * n * sizeof *A32), *c32 = malloc((5 * (m + n)) * sizeof *c32);

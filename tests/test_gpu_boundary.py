@@ -189,10 +189,11 @@ def test_handle_keeps_its_device_and_leaves_the_callers_device_alone():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["dense64", "dense32", "colmajor64", "csr64"])
+@pytest.mark.parametrize("kind", ["dense64", "dense32", "colmajor64", "csr64", "handle64"])
 def test_plain_c_caller_gets_the_python_bindings_answer(tmp_path, kind):
     """tests/c_caller/graph_form_driver.c (gcc, C99, linked with -lpogs_amd only) calls PogsD /
-    PogsS / PogsSparseD like examples/c/lasso.c:102-106 on inputs written by this test; what it
+    PogsS / PogsSparseD like examples/c/lasso.c:102-106 on inputs written by this test (handle64: the additive
+    handle entry points with broadcast coefficients, PogsAmdCreateDense + PogsAmdSolveFn); what it
     prints must be what the python binding returns for the same arrays (same library, same
     entry points: bit-identical) and within the usual tolerance of the oracle."""
     import subprocess
