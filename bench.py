@@ -37,8 +37,11 @@ pays per call, src/interface_c/pogs_c.cpp:19-20) and reports every cycle and the
 
 value = N * K / T: iterations of one per-GPU shard per second, summed over ranks (at N = 1 the
 ADMM it/s of the configuration).  T is the max over ranks of the time of exactly K steps
-between barrier + synchronize on both sides; when K steps take less than 0.1 s several such
-windows are timed back to back and their mean is reported (`windows`, `window_s`).
+between barrier + synchronize on both sides; as many such windows are timed back to back as make
+the timed stretch a WHOLE NUMBER OF SOLVES (`windows`, `window_s`, `windows_cover`; pick_windows) and
+their mean is reported: the iterations of a solve do not all cost the same (a sparse solve's CGLS
+projections take 4 steps early, 1 in the middle, 2-3 at the end), and the metric is a solve's
+iterations over its loop time.
 
 Inputs are resident in HBM when the timed region starts.  The JSON line carries `roofline`
 (the dominant kernel, timed with HIP events on the solver's stream over the timed region;
@@ -47,8 +50,15 @@ timed is done the script runs itself twice more for a few steps under `rocprofv3
 FETCH_SIZE` / `--pmc WRITE_SIZE` -- about a minute, --no-live-traffic skips it -- and the
 committed counter summaries profiles/pmc_traffic_<config>.json stay in the line as
 `traffic_static`; the secondary workloads quote their committed summaries)
-and, at N = 1, `cpu_baseline`: the reference CPU path on the same (A, b, lambda) on this box's
-host cores, WHOLE workload (no row sample, nothing scaled).  Dense: the compiled reference in
+and `cpu_baseline`: the reference CPU path on the same (A, b, lambda) on this box's
+host cores, WHOLE workload (no row sample, nothing scaled) -- at N > 1 rank 0 times it on its OWN
+shard after the timed region (the other ranks wait on sockets) and the line gives the whole problem's
+rate as `value / N`, marked `extrapolated` (every per-iteration term of the reference is linear in m; the
+whole C5 problem is beyond its int-sized views), and `roofline.traffic` is measured on rank 0's GPU.
+The line also carries both roofline peaks (`peak_datasheet`, `peak_measured`: the library's read probe),
+`exact_setup` (the same create + solve with the setup's two shortcuts off), `one_shot_host_call` (the
+reference's entry point with a HOST matrix, and the upload on its own) and ends with `headline`: the
+headline workload's own wall-clock figures (the driver keeps the tail of stdout).  Dense: the compiled reference in
 both BLAS builds -- oracle/_ref/libpogs_cpu_openblas.so (scipy's OpenBLAS, which threads its
 gemv: the "best configuration") and oracle/_ref/libpogs_cpu.so (MKL, the build the oracle is
 pinned to; on the GPU box's AMD host its sgemv runs on one thread,
