@@ -78,17 +78,22 @@ template <> struct SellCfg<float> { static constexpr int BW = POGS_SELL_BW_F32, 
 template <> struct SellCfg<double> { static constexpr int BW = 12288, RR = 6144; };   // 96 KB + 48 KB
 constexpr unsigned short kSellNoRow = 0xFFFF;
 constexpr int kSellOffBits = 23;        // plan: stream offset of a row inside its tile (9 bits of stream above it)
+constexpr int kSellOff2Bits = 22;       // (two id slots) the offset; bit 22: the row's end is the SECOND one of its batch
 
 template <typename T>
 struct SellView {
   const T *val;
   const unsigned short *loc;    // column - first column of the tile's block
-  const unsigned short *rid;    // kSellNoRow, or (row - first row of the range) on the last element of a row
+  const unsigned short *rid;    // tags: kSellNoRow, or (row - first row of the range) on the last element of a row;
+                                // two (below): per batch of a lane the rows of its first and second row end
   const int *tile_unit;         // [nrr * ncb + 1]: first 64-element unit of each tile; a tile holds 8 K units
   int nrows, ncols;
   int rr_rows;                  // rows per row range (<= SellCfg::RR)
   int nrr, ncb;                 // row ranges, column blocks
   int ncg;                      // column groups (an even split of the column blocks)
+  int two;                      // 1: "two id slots" format -- bit 15 of loc marks the last element of a row and rid holds
+                                // 2 ids per 4-element batch (no batch of a stream has more than 2 row ends: the planner
+                                // orders a stream's rows that way); 7 bytes per stored fp32 element instead of 8
   // debug (POGS_AMD_SELL_STAMPS): per workgroup {start, end (100 MHz wall clock), XCC id, 64-element units walked}
   unsigned long long *stamps;
 };
@@ -97,24 +102,26 @@ struct SellView {
 // a lane are one 16-byte (fp32) vector, its local columns and row tags one 8-byte vector each, so a
 // wavefront fetches a batch with three fully coalesced wide loads; batch b of wavefront w of a tile
 // sits at element (first unit of the tile) * 64 + (b * 8 + w) * 256.
-template <typename T>
+template <typename T, bool TWO>
 struct SellBatch {
   T v[kSellUB];
-  unsigned short c[kSellUB], r[kSellUB];
+  unsigned short c[kSellUB], r[TWO ? 2 : kSellUB];
 };
+constexpr unsigned short kSellEndBit = 0x8000;   // (two id slots) set in loc on the last element of a row
 template <typename V> __device__ __forceinline__ V dev_vzero() {
   V v;
   __builtin_memset(&v, 0, sizeof(V));
   return v;
 }
 template <int BYTES> struct SellRaw;
+template <> struct SellRaw<4> { typedef unsigned int type; };
 template <> struct SellRaw<8> { typedef unsigned int type __attribute__((ext_vector_type(2))); };
 template <> struct SellRaw<16> { typedef unsigned int type __attribute__((ext_vector_type(4))); };
 template <typename E, int N>
 __device__ __forceinline__ void sell_load(const E *p, E (&out)[N]) {   // N * sizeof(E) bytes, non-temporal, in <= 16-byte pieces
   constexpr int BYTES = N * static_cast<int>(sizeof(E));
-  constexpr int PIECE = BYTES >= 16 ? 16 : 8;
-  static_assert(BYTES % PIECE == 0, "batch vectors are 8 or 16 byte multiples");
+  constexpr int PIECE = BYTES >= 16 ? 16 : (BYTES >= 8 ? 8 : 4);
+  static_assert(BYTES % PIECE == 0, "batch vectors are 4, 8 or 16 byte multiples");
   typedef typename SellRaw<PIECE>::type R;
   R raw[BYTES / PIECE];
 #pragma unroll
@@ -136,7 +143,7 @@ __device__ __forceinline__ int sell_uniform_load(const int *p) {
 
 // The row sums of one (row range, column group) into s_y[0 .. nr): the streaming body shared by the
 // SpMV kernels below.  s_x: BW elements of LDS, s_y: RR elements; ends with a barrier (s_y complete).
-template <typename T, bool SQ>
+template <typename T, bool SQ, bool TWO>
 __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__restrict__ x, T xs, int rr, int cg, int nr,
                                               T *s_x, T *s_y) {
   constexpr int BW = SellCfg<T>::BW;
@@ -151,16 +158,17 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
   const int *__restrict__ a_tu = A.tile_unit + static_cast<size_t>(rr) * A.ncb;   // this row range's tiles
   auto tu = [&](int cb) { return sell_uniform_load(a_tu + cb); };
 
-  auto fetch = [&](size_t e0, SellBatch<T> &B) {   // e0: first element of this lane's batch
+  auto fetch = [&](size_t e0, SellBatch<T, TWO> &B) {   // e0: first element of this lane's batch
     sell_load<T, UB>(a_val + e0, B.v);
     sell_load<unsigned short, UB>(a_loc + e0, B.c);
-    sell_load<unsigned short, UB>(a_rid + e0, B.r);
+    if constexpr (TWO) sell_load<unsigned short, 2>(a_rid + e0 / 2, B.r);
+    else sell_load<unsigned short, UB>(a_rid + e0, B.r);
   };
   T acc = 0;   // running sum of the lane's current row (rows never straddle tiles)
-  auto consume = [&](const SellBatch<T> &B) {
+  auto consume = [&](const SellBatch<T, TWO> &B) {
     T xg[UB];
 #pragma unroll
-    for (int j = 0; j < UB; ++j) xg[j] = s_x[B.c[j]];
+    for (int j = 0; j < UB; ++j) xg[j] = s_x[TWO ? (B.c[j] & (kSellEndBit - 1)) : B.c[j]];
     // running sums in registers first; the row ends of the batch are then flushed with INDEPENDENT
     // LDS accesses (all reads, then all writes).  A row belongs to one lane and ends once, so the
     // (up to UB) sums a lane flushes here are distinct and nobody else touches them -- written as
@@ -168,20 +176,29 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
     // becomes UB dependent LDS round trips.
     T fl[UB], old[UB];
     bool en[UB];
+    unsigned short row[UB];
+    bool seen = false;   // (two id slots) a row has ended earlier in this batch: the next end is the second slot's
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
       const T v = B.v[j];
       acc += (SQ ? v * v : v) * xg[j];
-      en[j] = B.r[j] != kSellNoRow;
+      if constexpr (TWO) {
+        en[j] = (B.c[j] & kSellEndBit) != 0;
+        row[j] = seen ? B.r[1] : B.r[0];
+        seen = seen || en[j];
+      } else {
+        en[j] = B.r[j] != kSellNoRow;
+        row[j] = B.r[j];
+      }
       fl[j] = acc;
       acc = en[j] ? static_cast<T>(0) : acc;
     }
 #pragma unroll
     for (int j = 0; j < UB; ++j)
-      if (en[j]) old[j] = s_y[B.r[j]];
+      if (en[j]) old[j] = s_y[row[j]];
 #pragma unroll
     for (int j = 0; j < UB; ++j)
-      if (en[j]) s_y[B.r[j]] = old[j] + fl[j];
+      if (en[j]) s_y[row[j]] = old[j] + fl[j];
   };
 
   // column blocks of this group: an even split of the ncb blocks
@@ -292,7 +309,7 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
     first = f_b == 0 && f_cb < cb1;
     ++f_b;
   };
-  SellBatch<T> B[NB];
+  SellBatch<T, TWO> B[NB];
   bool first[NB];
   x_prefetch();
   if (tb > 0) {
@@ -350,7 +367,9 @@ __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, cons
   const int nr = min(A.rr_rows, A.nrows - row0);
   T xs = 1;
   if (x_nrm2) xs = static_cast<T>(1.0 / sqrt(*x_nrm2));
-  sell_row_sums<T, SQ>(A, x, xs, rr, cg, nr, s_x, s_y);
+  // (one uniform branch per launch: the two storage formats differ in what a batch fetches and how it names its rows)
+  if (A.two) sell_row_sums<T, SQ, true>(A, x, xs, rr, cg, nr, s_x, s_y);
+  else sell_row_sums<T, SQ, false>(A, x, xs, rr, cg, nr, s_x, s_y);
   double sacc[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
@@ -405,13 +424,24 @@ __global__ void sell_count_kernel(const int *ind, const int *ptr, SellDims D, un
 // soff[tile * rr_rows + row] = stream << 23 | offset of the row in its stream, tile_nu[tile] =
 // 64-element units of the tile = 8 * K, K = longest stream rounded up to the batch size.
 // *err |= 4 if an offset does not fit its 23 bits (the caller then keeps the plain CSR kernel).
+//
+// The same deal laid out for the "two id slots" format (soff2, tile_nu2; SellView::two): a stream takes
+// its rows from both ends of its list -- a short row from the back while the current batch of 4 has
+// room for it and has seen fewer than two row ends, a long one from the front otherwise (it runs
+// on into a later batch, whose first end it is), and zeros up to the batch boundary when two rows
+// have ended and nothing left is long enough to leave the batch -- so that no batch holds more than
+// two ends.  soff2 = stream << 23 | (second end of its batch) << 22 | offset.  A row's elements stay
+// together and in order, so both layouts add up every row sum in the same order: same bits.
+// With ~2.2 non-zeros per (row, tile) (C4) the streams need no extra padding for this; with mostly
+// single-element rows they need a lot (the caller compares the two totals and takes the smaller
+// matrix).  *err |= 8: an offset of this layout does not fit 22 bits (the caller keeps the tags).
 constexpr int kSellClasses = kSellLmax + 2;   // 0 unused, 1..32, 33 = longer
 __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cnt, SellDims D, int *tile_nu,
-                                                        unsigned *soff, int *err) {
+                                                        unsigned *soff, int *tile_nu2, unsigned *soff2, int *err) {
   extern __shared__ unsigned short s_sorted[];           // [rr_rows]: rows in dealing order
   __shared__ unsigned short s_hist[kSellClasses][256];   // per thread and class: rows, then their exclusive prefix
   __shared__ int s_tot[kSellClasses], s_cbase[kSellClasses];
-  __shared__ int s_max[4];
+  __shared__ int s_max[4], s_max2[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int rpt = (D.rr_rows + 255) / 256;               // consecutive rows per thread
   for (int tile = blockIdx.x; tile < D.nrr * D.ncb; tile += gridDim.x) {
@@ -419,6 +449,7 @@ __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cn
     const int nr = min(D.rr_rows, D.nrows - rr * D.rr_rows);
     const unsigned short *tc = cnt + static_cast<size_t>(tile) * D.rr_rows;
     unsigned *to = soff + static_cast<size_t>(tile) * D.rr_rows;
+    unsigned *to2 = soff2 ? soff2 + static_cast<size_t>(tile) * D.rr_rows : nullptr;
     for (int c = 0; c < kSellClasses; ++c) s_hist[c][t] = 0;
     const int r_lo = t * rpt, r_hi = min(nr, r_lo + rpt);
     for (int r = r_lo; r < r_hi; ++r) {
@@ -475,25 +506,70 @@ __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cn
     }
     __syncthreads();
     const int nne = s_cbase[0];
-    int longest = 0;
+    int longest = 0, longest2 = 0;
     for (int sidx = t; sidx < kSellStreams; sidx += 256) {
-      int run = 0;
+      auto kof = [&](int p) { return p * kSellStreams + ((p & 1) ? kSellStreams - 1 - sidx : sidx); };
+      int run = 0, np = 0;   // np: rows of this stream (only the last pass can miss one)
       for (int p = 0; p * kSellStreams < nne; ++p) {
-        const int k = p * kSellStreams + ((p & 1) ? kSellStreams - 1 - sidx : sidx);
+        const int k = kof(p);
         if (k >= nne) continue;
         const int r = s_sorted[k];
         if (run >= (1 << kSellOffBits)) atomicOr(err, 4);
         to[r] = (static_cast<unsigned>(sidx) << kSellOffBits) | static_cast<unsigned>(run & ((1 << kSellOffBits) - 1));
         run += tc[r];
+        ++np;
       }
       longest = max(longest, run);
+      if (to2) {
+        static_assert(kSellUB == 4, "the two-slot layout counts row ends per batch of 4");
+        int i = 0, j = np - 1, pos = 0, ends = 0;   // front (long rows), back (short rows), stream position, ends in its batch
+        int ri = 0, li = 0, rj = 0, lj = 0;
+        if (np > 0) {
+          ri = s_sorted[kof(0)]; li = tc[ri];
+          rj = s_sorted[kof(j)]; lj = tc[rj];
+        }
+        while (i <= j) {
+          const int slot = pos & 3;
+          if (slot == 0) ends = 0;
+          const int left = 4 - slot;
+          int r, len;
+          if (ends < 2 && lj <= left) {          // a short row that ends inside this batch
+            r = rj; len = lj;
+            --j;
+            if (i <= j) { rj = s_sorted[kof(j)]; lj = tc[rj]; }
+          } else if (ends < 2 || li > left) {    // the longest one left: li >= lj > left, it ends in a later batch
+            r = ri; len = li;
+            ++i;
+            if (i <= j) { ri = s_sorted[kof(i)]; li = tc[ri]; }
+          } else {                               // two ends and nothing leaves the batch: zeros up to its boundary
+            pos += left;
+            continue;
+          }
+          const int e = pos + len - 1;
+          const bool same = (e >> 2) == (pos >> 2);
+          const unsigned second = same ? static_cast<unsigned>(ends) : 0u;
+          ends = same ? ends + 1 : 1;
+          if (pos >= (1 << kSellOff2Bits)) atomicOr(err, 8);
+          to2[r] = (static_cast<unsigned>(sidx) << kSellOffBits) | (second << kSellOff2Bits) |
+                   static_cast<unsigned>(pos & ((1 << kSellOff2Bits) - 1));
+          pos += len;
+        }
+        longest2 = max(longest2, pos);
+      }
     }
-    for (int off = 32; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off, 64));
-    if (lane == 0) s_max[wave] = longest;
+    for (int off = 32; off > 0; off >>= 1) {
+      longest = max(longest, __shfl_xor(longest, off, 64));
+      longest2 = max(longest2, __shfl_xor(longest2, off, 64));
+    }
+    if (lane == 0) { s_max[wave] = longest; s_max2[wave] = longest2; }
     __syncthreads();
     if (t == 0) {
       const int K = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
       tile_nu[tile] = (K + kSellUB - 1) / kSellUB * kSellUB * kSellWaves;
+      if (tile_nu2) {
+        const int K2 = max(max(s_max2[0], s_max2[1]), max(s_max2[2], s_max2[3]));
+        tile_nu2[tile] = (K2 + kSellUB - 1) / kSellUB * kSellUB * kSellWaves;
+      }
     }
     __syncthreads();
   }
@@ -504,7 +580,7 @@ __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cn
 template <typename T>
 __global__ void sell_fill_kernel(const T *val, const int *ind, const int *ptr, SellDims D, const unsigned short *cnt,
                                  const unsigned *soff, unsigned short *cursor, const int *tile_unit, T *sval,
-                                 unsigned short *sloc, unsigned short *srid, unsigned *dst_out) {
+                                 unsigned short *sloc, unsigned short *srid, unsigned *dst_out, int two) {
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < D.nrows; r += gridDim.x * blockDim.x) {
     const int rr = r / D.rr_rows, lr = r - rr * D.rr_rows;
     for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
@@ -514,7 +590,8 @@ __global__ void sell_fill_kernel(const T *val, const int *ind, const int *ptr, S
       const int j = cursor[idx];
       cursor[idx] = static_cast<unsigned short>(j + 1);
       const unsigned so = soff[idx];
-      const int sidx = static_cast<int>(so >> kSellOffBits), off = static_cast<int>(so & ((1u << kSellOffBits) - 1));
+      const int sidx = static_cast<int>(so >> kSellOffBits);
+      const int off = static_cast<int>(so & ((1u << (two ? kSellOff2Bits : kSellOffBits)) - 1));
       const int u0 = tile_unit[tile];
       const int k_el = off + j;   // position in the lane's stream: step k_el / UB, wavefront-, then lane-major inside the step
       const size_t dst = static_cast<size_t>(u0) * 64 +
@@ -523,8 +600,15 @@ __global__ void sell_fill_kernel(const T *val, const int *ind, const int *ptr, S
       sval[dst] = val[k];
       if (dst_out) dst_out[k] = static_cast<unsigned>(dst);
       if (sloc) {
-        sloc[dst] = static_cast<unsigned short>(c - cb * D.bw);
-        if (j + 1 == cnt[idx]) srid[dst] = static_cast<unsigned short>(lr);
+        const bool last = j + 1 == cnt[idx];
+        const int lc = c - cb * D.bw;
+        if (!two) {
+          sloc[dst] = static_cast<unsigned short>(lc);
+          if (last) srid[dst] = static_cast<unsigned short>(lr);
+        } else {
+          sloc[dst] = static_cast<unsigned short>(lc | (last ? kSellEndBit : 0));
+          if (last) srid[(dst - static_cast<size_t>(k_el % kSellUB)) / 2 + ((so >> kSellOff2Bits) & 1u)] = static_cast<unsigned short>(lr);
+        }
       }
     }
   }

@@ -516,12 +516,13 @@ struct DevCsr {
   DevBuf<unsigned> sdst;         // position of every CSR element in the tiled copy, kept from the first fill to the refill
   bool sell_ready = false;
   int rr_rows = 0, nrr = 0, ncb = 0, ncg = 1;
+  int two = 0;                   // storage format (SellView::two)
   size_t sell_elems = 0;
   DevBuf<unsigned long long> stamps;      // debug time stamps (POGS_AMD_SELL_STAMPS)
   bool stamps_on = false;
   SellDims sdims() const { return SellDims{nrows, ncols, rr_rows, nrr, ncb, SellCfg<T>::BW}; }
   SellView<T> sview() const {
-    return SellView<T>{sval.p, sloc.p, srid.p, tile_unit.p, nrows, ncols, rr_rows, nrr, ncb, ncg,
+    return SellView<T>{sval.p, sloc.p, srid.p, tile_unit.p, nrows, ncols, rr_rows, nrr, ncb, ncg, two,
                        stamps_on ? stamps.p : nullptr};
   }
 };
@@ -849,11 +850,21 @@ class SparseSolver final : public SolverBase {
     }
     M.rr_rows = rr_rows; M.nrr = nrr; M.ncb = ncb; M.ncg = ncg;
     const SellDims D = M.sdims();
+    // storage format: the planner lays the tile out both ways and the smaller matrix is kept (7 bytes per stored
+    // fp32 element with two id slots per batch, 8 with a tag per element -- but the first needs padding when most
+    // rows of a tile hold a single element).  POGS_AMD_SELL_FORMAT=tags / two pins it (tests, A/B measurements).
+    static_assert(SellCfg<T>::BW <= 32768, "bit 15 of a local column is the row-end flag of the two-slot format");
+    int want_two = -1;
+    if (const char *f = std::getenv("POGS_AMD_SELL_FORMAT")) want_two = std::strcmp(f, "two") == 0 ? 1 : (std::strcmp(f, "tags") == 0 ? 0 : -1);
+    DevBuf<unsigned> soff2;
     M.scnt.alloc(nq); M.ssoff.alloc(nq);
+    if (want_two != 0) soff2.alloc(nq);
     M.scnt.zero(s);
     const int g = std::max(1, std::min((M.nrows + 255) / 256, ctx_.num_cu * 16));
     hipLaunchKernelGGL(sell_count_kernel, dim3(g), dim3(256), 0, s, M.ind.p, M.ptr.p, D, M.scnt.p);
-    DevBuf<int> nu(ntiles + 1), err(1);
+    DevBuf<int> nu(ntiles + 1), nu2, err(1);
+    DevBuf<int> tile_unit2;
+    if (soff2.p) { nu2.alloc(ntiles + 1); tile_unit2.alloc(ntiles + 1); }
     err.zero(s);
     M.tile_unit.alloc(ntiles + 1);
     const int gt = static_cast<int>(std::min<long long>(ntiles, ctx_.num_cu * 8));
@@ -862,12 +873,32 @@ class SparseSolver final : public SolverBase {
       ensure_dynamic_smem(reinterpret_cast<const void *>(&sell_plan_kernel), rr_rows * sizeof(unsigned short) + 20480, grants);
     }
     hipLaunchKernelGGL(sell_plan_kernel, dim3(gt), dim3(256), rr_rows * sizeof(unsigned short), s, M.scnt.p, D, nu.p,
-                       M.ssoff.p, err.p);
+                       M.ssoff.p, nu2.p, soff2.p, err.p);
     exclusive_scan(nu.p, static_cast<int>(ntiles), M.tile_unit.p);
-    int tot = 0, herr = 0;
+    int tot = 0, tot2 = 0, herr = 0;
     POGS_HIP_CHECK(hipMemcpyAsync(&tot, M.tile_unit.p + ntiles, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (soff2.p) {
+      exclusive_scan(nu2.p, static_cast<int>(ntiles), tile_unit2.p);
+      POGS_HIP_CHECK(hipMemcpyAsync(&tot2, tile_unit2.p + ntiles, sizeof(int), hipMemcpyDeviceToHost, s));
+    }
     POGS_HIP_CHECK(hipMemcpyAsync(&herr, err.p, sizeof(int), hipMemcpyDeviceToHost, s));
     ctx_.sync();
+    M.two = 0;
+    if (soff2.p && !(herr & 8) && tot2 > 0) {
+      // bytes per stored element: value + local column + (2 ids per 4 | a tag)
+      const double b2 = static_cast<double>(tot2) * (sizeof(T) + 3.0), b1 = static_cast<double>(tot) * (sizeof(T) + 4.0);
+      if (want_two == 1 || b2 < b1) {
+        M.two = 1;
+        tot = tot2;
+        M.ssoff = std::move(soff2);
+        M.tile_unit = std::move(tile_unit2);
+      }
+    }
+    herr &= ~8;
+    if (std::getenv("POGS_AMD_TRACE"))
+      std::fprintf(stderr, "[pogs_amd trace] tiled copy %d x %d: %s, %.3f stored elements per non-zero\n", M.nrows, M.ncols,
+                   M.two ? "two id slots per batch" : "a row tag per element",
+                   static_cast<double>(tot) * 64.0 / static_cast<double>(M.nnz));
     // (a padding blow-up beyond 4x the non-zeros -- a few very long rows among many short ones in
     // a tile -- is left to the plain kernel)
     if (herr != 0 || tot <= 0 || static_cast<size_t>(tot) * 64 > 4 * M.nnz + (static_cast<size_t>(1) << 22)) {
@@ -877,10 +908,10 @@ class SparseSolver final : public SolverBase {
     M.sell_elems = static_cast<size_t>(tot) * 64;
     M.sval.alloc(M.sell_elems);
     M.sloc.alloc(M.sell_elems);
-    M.srid.alloc(M.sell_elems);
+    M.srid.alloc(M.two ? M.sell_elems / 2 : M.sell_elems);
     M.sval.zero(s);
     M.sloc.zero(s);
-    POGS_HIP_CHECK(hipMemsetAsync(M.srid.p, 0xFF, M.sell_elems * sizeof(unsigned short), s));
+    POGS_HIP_CHECK(hipMemsetAsync(M.srid.p, 0xFF, M.srid.n * sizeof(unsigned short), s));
     M.sell_ready = true;
     fill_sell(M, true);
     if (ncg > 1) M.part.alloc(static_cast<size_t>(ncg) * M.nrows);
@@ -901,7 +932,7 @@ class SparseSolver final : public SolverBase {
     const int g = std::max(1, std::min((M.nrows + 255) / 256, ctx_.num_cu * 16));
     hipLaunchKernelGGL(sell_fill_kernel<T>, dim3(g), dim3(256), 0, s, M.val.p, M.ind.p, M.ptr.p, M.sdims(), M.scnt.p,
                        M.ssoff.p, cursor.p, M.tile_unit.p, M.sval.p, with_loc ? M.sloc.p : nullptr, M.srid.p,
-                       with_loc ? M.sdst.p : nullptr);
+                       with_loc ? M.sdst.p : nullptr, M.two);
     ctx_.sync();   // cursor is freed at scope exit
   }
   // the values are final (equilibrated): refill and drop the build temporaries

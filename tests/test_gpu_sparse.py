@@ -219,6 +219,94 @@ def test_stamps_diagnostic_prints_per_xcd_times_and_changes_nothing(monkeypatch,
     assert got["iterations"] == base["iterations"] and np.array_equal(got["x"], base["x"])
 
 
+def _format_line(err, shape):
+    lines = [ln for ln in err.splitlines() if ln.startswith("[pogs_amd trace] tiled copy") and shape in ln]
+    assert lines, err[-600:]
+    return lines[-1]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", ["two_per_tile", "single_elements", "mixed_long_rows"])
+def test_two_slot_storage_gives_the_tag_storages_bits(dtype, shape, monkeypatch, capfd):
+    """The tiled copy in its two storage formats (sell.h: a row tag per element, 8 B per stored fp32 element; a
+    row-end bit in the local column + two id slots per batch of 4, 7 B) holds every row's elements in the same
+    order, so both SpMVs return the same bits from either -- checked with each format pinned
+    (POGS_AMD_SELL_FORMAT) on structures where the two-slot planner (a) needs no padding, (b) has to pad nearly
+    every batch (single-element rows: three or four row ends per batch otherwise), (c) mixes rows far longer than a
+    batch with single elements, with empty rows and one row that spans several classes.  Left to itself the
+    planner keeps the smaller matrix: two slots for (a), tags for (b)."""
+    pogs = _pogs()
+    rng = np.random.default_rng(11)
+    if shape == "two_per_tile":      # ~2.2 elements per (row, column block), as at C4
+        m, n, per = 50000, 150000, 18
+        rows = np.arange(m).repeat(per)
+        A = sp.csr_matrix((rng.standard_normal(m * per), (rows, rng.integers(0, n, m * per))), shape=(m, n))
+    elif shape == "single_elements":   # exactly one element per (row, fp32 column block of 18432): 3-4 single-element rows per stream
+        m, n = 200000, 4 * 18432
+        rows = np.arange(m).repeat(4)
+        cols = (rng.integers(0, 18432, (m, 4)) + 18432 * np.arange(4)).ravel()
+        A = sp.csr_matrix((rng.standard_normal(4 * m), (rows, cols)), shape=(m, n))
+    else:
+        m, n = 40000, 30000
+        k = rng.choice([0, 1, 1, 1, 2, 3, 7, 40, 300], size=m)
+        k[77] = 20000
+        rows = np.arange(m).repeat(k)
+        cols = np.concatenate([rng.choice(n, size=int(c), replace=False) for c in k if c > 0])
+        A = sp.csr_matrix((rng.standard_normal(len(rows)), (rows, cols)), shape=(m, n))
+    A = A.astype(dtype)
+    A.sum_duplicates()
+    A.sort_indices()
+    x = rng.standard_normal(n).astype(dtype)
+    y = rng.standard_normal(m).astype(dtype)
+    monkeypatch.setenv("POGS_AMD_TRACE", "1")
+    got = {}
+    for fmt in ("tags", "two", "auto"):
+        monkeypatch.setenv("POGS_AMD_SELL_FORMAT", fmt)
+        capfd.readouterr()
+        with pogs.Solver(A, dtype=dtype) as s:
+            r = (s.mul("n", 1.0, x, 0.0, np.zeros(m, dtype)), s.mul("t", 1.0, y, 0.0, np.zeros(n, dtype)))
+        err = capfd.readouterr().err
+        got[fmt] = (r, _format_line(err, "%d x %d" % (m, n)), _format_line(err, "%d x %d" % (n, m)))
+    assert "a row tag per element" in got["tags"][1] and "two id slots" in got["two"][1], (got["tags"][1], got["two"][1])
+    for fmt in ("two", "auto"):
+        assert np.array_equal(got[fmt][0][0], got["tags"][0][0]) and np.array_equal(got[fmt][0][1], got["tags"][0][1]), fmt
+    # left alone the planner keeps the copy with fewer bytes: stored elements x (value + column + half an id | a tag)
+    size = np.dtype(dtype).itemsize
+    for k in (1, 2):
+        stored = {fmt: float(got[fmt][k].split(",")[-1].split()[0]) for fmt in ("tags", "two")}
+        want = "two id slots" if stored["two"] * (size + 3) < stored["tags"] * (size + 4) else "a row tag per element"
+        assert want in got["auto"][k], (stored, got["auto"][k])
+    if dtype == np.float32 and shape != "mixed_long_rows":
+        assert ("two id slots" if shape == "two_per_tile" else "a row tag per element") in got["auto"][1], got["auto"][1]
+    # and the product itself (the equilibrated matrix the handle holds)
+    from pogs_amd import _lib
+
+    monkeypatch.setenv("POGS_AMD_SELL_FORMAT", "two")
+    with pogs.Solver(A, dtype=dtype) as s:
+        buf = np.zeros(A.nnz, dtype)
+        nrm = ctypes.c_double()
+        assert _lib.lib.PogsAmdGetEquil(s._h, buf.ctypes.data_as(ctypes.c_void_p), None, None, ctypes.byref(nrm)) == 0
+        As = sp.csr_matrix((buf.astype(np.float64), A.indices, A.indptr), shape=(m, n))
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    assert relerr(got["two"][0][0], As @ x.astype(np.float64)) < tol
+    assert relerr(got["two"][0][1], As.T @ y.astype(np.float64)) < tol
+
+
+def test_solve_is_the_same_in_both_storage_formats(monkeypatch):
+    """A whole solve (Sinkhorn-Knopp passes over squared entries, CGLS loop, exact residuals) on the tag storage and
+    on the two-slot storage: the same iterations, the same bits."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, b, _ = synth.csr_lasso(60000, 150000, 20, seed=5, dtype=np.float32)
+    res = {}
+    for fmt in ("tags", "two"):
+        monkeypatch.setenv("POGS_AMD_SELL_FORMAT", fmt)
+        res[fmt] = pogs.solve_lasso(A, b, 0.1, dtype=np.float32)
+    assert res["two"]["status"] == 0 and res["two"]["iterations"] == res["tags"]["iterations"]
+    assert np.array_equal(res["two"]["x"], res["tags"]["x"]) and np.array_equal(res["two"]["y"], res["tags"]["y"])
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_cg_loop_variants_walk_the_same_trajectory(dtype, monkeypatch):
     """The device-resident CGLS loop (cg_fused.h) with y = A x from the CG recurrence every iteration
