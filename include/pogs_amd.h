@@ -290,6 +290,12 @@ int PogsAmdMul(PogsAmdSolver *s, char trans, double alpha, const void *x, double
  * row-block shape of the dense pass), `reps` timed launches each.  bench.py prints it as
  * roofline.peak_measured next to the data-sheet peak.  *pattern (may be NULL): 0 or 1, which one won. */
 int PogsAmdReadBandwidth(int device, size_t bytes, int reps, double *gb_per_s, int *pattern);
+/* Diagnostic: the 64-lane wavefront sums behind every row dot-product and scalar of the engine are formed in the
+ * vector ALU (v_permlane32_swap / v_permlane16_swap / DPP, csrc/reduce.h) in the order of the butterfly
+ * `v += shfl_xor(v, 32, 16, 8, 4, 2, 1)`.  For n (a multiple of 64) HOST values this returns, per value, its
+ * wavefront's total formed that way (alu) and by the butterfly through the LDS crossbar (lds): the two must agree
+ * bit for bit (tests/test_gpu_dense.py). */
+int PogsAmdWaveSumCheck(int dtype, size_t n, const void *in_host, void *alu_host, void *lds_host);
 /* The Norm2Est start vector (reference: gsl::rand, src/cpu/include/gsl/gsl_rand.h:8-16). */
 int PogsAmdRandUniform(int dtype, size_t n, void *out_host);
 

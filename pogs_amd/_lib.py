@@ -136,6 +136,7 @@ lib.PogsAmdProject.argtypes = [c_void_p, c_void_p, c_void_p, c_double, c_void_p,
 lib.PogsAmdMul.argtypes = [c_void_p, c_char, c_double, c_void_p, c_double, c_void_p]
 lib.PogsAmdRandUniform.argtypes = [c_int, c_size_t, c_void_p]
 lib.PogsAmdReadBandwidth.argtypes = [c_int, c_size_t, c_int, ctypes.POINTER(c_double), ctypes.POINTER(c_int)]
+lib.PogsAmdWaveSumCheck.argtypes = [c_int, c_size_t, c_void_p, c_void_p, c_void_p]
 
 
 class PogsAmdPoolInfo(ctypes.Structure):
@@ -170,7 +171,7 @@ ABI_SYMBOLS = [
     "PogsAmdIterate", "PogsAmdSetWarmStart", "PogsAmdGetStats", "PogsAmdResetStats", "PogsAmdDestroy", "PogsAmdLastError",
     "PogsAmdPoolStats", "PogsAmdPoolTrim",
     "PogsAmdProxEval", "PogsAmdFuncEval", "PogsAmdProjSubgradEval", "PogsAmdGetEquil", "PogsAmdProject", "PogsAmdMul", "PogsAmdRandUniform",
-    "PogsAmdReadBandwidth",
+    "PogsAmdReadBandwidth", "PogsAmdWaveSumCheck",
 ]
 
 
@@ -180,6 +181,18 @@ def read_bandwidth(device=-1, nbytes=4 << 30, reps=10):
     if lib.PogsAmdReadBandwidth(device, nbytes, reps, ctypes.byref(gbs), ctypes.byref(pat)) != 0:
         raise RuntimeError(last_error())
     return gbs.value, ("side-by-side grid stride", "row blocks")[pat.value]
+
+
+def wave_sum_check(values):
+    """(alu, lds): per input value its wavefront's total by the engine's ALU reduction and by the __shfl_xor
+    butterfly (include/pogs_amd.h: PogsAmdWaveSumCheck); `values`: float32 / float64, a multiple of 64 long."""
+    import numpy as np
+    v = np.ascontiguousarray(values)
+    assert v.dtype in (np.float32, np.float64) and v.size % 64 == 0
+    a, b = np.empty_like(v), np.empty_like(v)
+    if lib.PogsAmdWaveSumCheck(0 if v.dtype == np.float32 else 1, v.size, v.ctypes.data, a.ctypes.data, b.ctypes.data) != 0:
+        raise RuntimeError(last_error())
+    return a, b
 
 
 def last_error():

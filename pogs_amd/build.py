@@ -25,6 +25,9 @@ SOURCES = ["abi.hip", "sparse.hip", "gemm.hip", "vec_kernels.hip", "dist.hip"]
 PLAN_SOURCE = "dense_plan.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# development aid: extra -D flags for EVERY object (the experiment switches that sit in inline functions shared by
+# all translation units, e.g. POGS_C3_LEAN_BLOCKS; use a separate checkout: the objects are not tracked per flag set)
+FLAGS += os.environ.get("POGS_AMD_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():

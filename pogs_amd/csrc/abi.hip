@@ -494,6 +494,15 @@ int PogsAmdReadBandwidth(int device, size_t bytes, int reps, double *gb_per_s, i
   });
 }
 
+int PogsAmdWaveSumCheck(int dtype, size_t n, const void *in_host, void *alu_host, void *lds_host) {
+  return guarded([&]() {
+    POGS_CHECK(in_host && alu_host && lds_host, "null argument");
+    if (dtype == POGS_AMD_F32) wave_sum_check(static_cast<const float *>(in_host), n, static_cast<float *>(alu_host), static_cast<float *>(lds_host));
+    else wave_sum_check(static_cast<const double *>(in_host), n, static_cast<double *>(alu_host), static_cast<double *>(lds_host));
+    return 0;
+  });
+}
+
 int PogsAmdRandUniform(int dtype, size_t n, void *out_host) {
   return guarded([&]() {
     if (dtype == POGS_AMD_F32) rand_uniform_host(static_cast<float *>(out_host), n);

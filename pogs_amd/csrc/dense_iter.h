@@ -237,7 +237,10 @@ bool DenseSolver<T, Tag>::iteration_fused(unsigned verbose) {
   // evaluates them in a pass of its own (the two-pass iteration's, below), drops the speculation so that
   // the next iteration rebuilds both column-sum sets (PreAccOp), and from there on the full pass runs.
   // Same arithmetic for everything that is used, so the same trajectory.
-  constexpr bool kLeanType = std::is_same<T, double>::value;
+#ifndef POGS_LEAN_F32_NV5   // (experiment switch, scripts/build_variant.py: the lean form in fp32 at 256 x 5, C3's shape)
+#define POGS_LEAN_F32_NV5 0
+#endif
+  constexpr bool kLeanType = std::is_same<T, double>::value || (POGS_LEAN_F32_NV5 != 0 && Tag::has(256, 5) && !Tag::windows);
   const bool lean = kLeanType && !multi_ && !exact_mode_;
   int nparts = colparts_ > 0 ? colparts_ : stream2_grid<2>(planA_, m_);
   if (!spec) {

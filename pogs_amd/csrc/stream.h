@@ -68,6 +68,7 @@ struct StreamPlan {
   int nv = 0;    // 16-byte vectors per thread per row
   int grid_max = 0;    // most workgroups any launch of this plan uses (sizes the partial-sum buffers)
   int grid_dot = 0;    // single-dot kernels (stream_rows_kernel): the workgroups resident at once
+  int num_cu = 0;      // (256-thread plans) the device's CUs: the one-pass kernel's grid is a multiple of it, per form
   bool ok = false;
   // rows wider than one register tile: the pass is run window by window (tpb * nv vectors of
   // columns each) -- column sums window-wise, row dots as partial dots that a small kernel adds
@@ -108,6 +109,27 @@ struct WindowPlans {   // StreamPlan::xl: the two window shapes only
   static constexpr bool windows = true;
 };
 
+// Workgroups per CU the one-pass kernel (stream_rows2_kernel, ND > 0) is launched with: the plan's grid_max AND the
+// kernel's register budget (__launch_bounds__'s second argument) -- at 256 x 5 the kernel sits at the edge of the 168
+// VGPRs that three workgroups per CU leave a wavefront, and without the bound a change of a few registers silently
+// costs a resident workgroup (measured in round 5: 174 VGPRs -> two per CU -> C3's pass 0.63 -> 0.88 ms).
+#ifndef POGS_C3_LEAN_BLOCKS   // (experiment switches, whole-library builds with POGS_AMD_EXTRA_FLAGS: workgroups per CU at 256 x 5
+#define POGS_C3_LEAN_BLOCKS 3 //  of the one-dot / one-accumulator form and of the full one)
+#endif
+#ifndef POGS_C3_FULL_BLOCKS
+#define POGS_C3_FULL_BLOCKS 3
+#endif
+constexpr int stream2_blocks_per_cu(int tpb, int nv, int nd = 2, int na = 2) {
+  return tpb == 64 ? 8
+         : tpb == 256 ? (nv == 5 ? ((nd == 1 && na == 1) ? POGS_C3_LEAN_BLOCKS : POGS_C3_FULL_BLOCKS) : nv <= 2 ? 3 : 2)
+                      : 1;
+}
+// (hipcc reads the second argument of __launch_bounds__ as wavefronts per SIMD, not workgroups per CU: 8 x 64 threads
+// per CU are 2 per SIMD -- passed as 8 it bounded the 64-thread kernels to 64 VGPRs and they spilled)
+constexpr int stream2_waves_per_simd(int tpb, int nv, int nd = 2, int na = 2) {
+  return (stream2_blocks_per_cu(tpb, nv, nd, na) * (tpb / 64) + 3) / 4;
+}
+
 // Chooses the workgroup shape for rows of n_pad elements.
 template <typename T>
 inline StreamPlan make_stream_plan(int n_pad, int num_cu) {
@@ -130,7 +152,8 @@ inline StreamPlan make_stream_plan(int n_pad, int num_cu) {
       p.tpb = 256; p.nv = nv; p.grid_dot = num_cu * 2;
       // at nv = 5 the one-pass iteration kernel takes two rows per step (stream2_rows_c), needs 167
       // VGPRs and fits three workgroups per CU: a slow row functor (logistic prox) hides better
-      p.grid_max = num_cu * ((nv == 5 || nv <= 2) ? 3 : 2);   // (nv <= 2: 8 rows per step, 158 VGPRs; 500000 x 2000: 0.694 -> 0.657 ms)
+      p.num_cu = num_cu;
+      p.grid_max = num_cu * std::max(stream2_blocks_per_cu(256, nv), stream2_blocks_per_cu(256, nv, 1, 1));   // (nv <= 2: 8 rows per step, 158 VGPRs; 500000 x 2000: 0.694 -> 0.657 ms)
       p.ok = true;
       return p;
     }
@@ -613,7 +636,7 @@ struct StreamArgs2 {
 // of up to 120: C3's pass 0.657 -> 0.725 ms.  The register file (512 KB per CU) holds more bytes in flight than the
 // LDS (160 KB) can; profiles/NOTES_r05.md.)
 template <typename T, int TPB, int NV, int R, int ND, int NA, typename Op>
-__global__ void __launch_bounds__(TPB) stream_rows2_kernel(StreamArgs2<T> a, Op op) {
+__global__ void __launch_bounds__(TPB, (ND > 0 ? stream2_waves_per_simd(TPB, NV, ND, NA) : 1)) stream_rows2_kernel(StreamArgs2<T> a, Op op) {
   using V = typename Vec16<T>::type;
   constexpr int VEC = Vec16<T>::N;
   constexpr int NW = TPB / 64;
@@ -767,7 +790,8 @@ template <int ND, int NA = 2>
 inline int stream2_grid(const StreamPlan &p, int m) {
   const int R = stream2_rows<ND, NA>(p);
   const int nblk = (m + R - 1) / R;
-  const int gmax = ND > 0 ? p.grid_max : p.grid_dot;   // (the column-sum-only form keeps the two-per-CU grid)
+  const int gmax = ND > 0 ? (p.tpb == 256 && p.num_cu > 0 ? p.num_cu * stream2_blocks_per_cu(256, p.nv, ND, NA) : p.grid_max)
+                          : p.grid_dot;   // (the column-sum-only form keeps the two-per-CU grid)
   return nblk < gmax ? (nblk > 0 ? nblk : 1) : gmax;
 }
 

@@ -171,6 +171,9 @@ void launch_sum_cg(const SumJob &job, double *S, double *cg, int mode, double sh
 // grid stride, 1 = row blocks.
 double measure_read_bandwidth_gbs(size_t bytes, int reps, int *pattern);
 
+// Diagnostic: the wavefront sums of n (a multiple of 64) host values, by dev::wave_sum and by the __shfl_xor butterfly.
+template <typename T> void wave_sum_check(const T *in_host, size_t n, T *alu_host, T *lds_host);
+
 // Misc vector helpers.
 template <typename T> void launch_fill(T *p, T v, size_t n, hipStream_t s);
 void launch_fill_int(int *p, int v, size_t n, hipStream_t s);

@@ -545,6 +545,33 @@ double measure_read_bandwidth_gbs(size_t bytes, int reps, int *pattern) {
   return best;
 }
 
+// Diagnostic (PogsAmdWaveSumCheck): dev::wave_sum -- the wavefront total formed in the vector ALU -- next to the same
+// butterfly through __shfl_xor, per wavefront of 64 consecutive inputs; every lane's total is written.
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256) wave_sum_check_kernel(const T *in, size_t n, T *out_alu, T *out_lds) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;   // (n is a multiple of 64: whole wavefronts leave together)
+  const T v = in[i];
+  out_alu[i] = dev::wave_sum(v);
+  out_lds[i] = dev::wave_sum_shfl(v);
+}
+}  // namespace
+template <typename T>
+void wave_sum_check(const T *in_host, size_t n, T *alu_host, T *lds_host) {
+  POGS_CHECK(n > 0 && n % 64 == 0, "whole wavefronts of 64 values");
+  DevBuf<T> in(n), a(n), b(n);
+  hipStream_t s = nullptr;
+  POGS_HIP_CHECK(hipMemcpyAsync(in.p, in_host, n * sizeof(T), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL((wave_sum_check_kernel<T>), dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, in.p, n, a.p, b.p);
+  POGS_HIP_CHECK(hipGetLastError());
+  POGS_HIP_CHECK(hipMemcpyAsync(alu_host, a.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+  POGS_HIP_CHECK(hipMemcpyAsync(lds_host, b.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+  POGS_HIP_CHECK(hipDeviceSynchronize());
+}
+template void wave_sum_check<float>(const float *, size_t, float *, float *);
+template void wave_sum_check<double>(const double *, size_t, double *, double *);
+
 #define POGS_INST(T)                                                                                     \
   template void launch_scale_objective<T>(FnView<T>, T *, T *, T *, T *, const T *, int, bool, hipStream_t); \
   template void launch_admm_pre<T>(const AdmmPreArgs<T> &, hipStream_t);                                 \

@@ -215,6 +215,29 @@ def test_sinkhorn_knopp_stationarity_probe_small_shapes(shape, monkeypatch):
     assert nrm == pytest.approx(nrm_full, rel=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_wavefront_sum_in_the_alu_is_the_butterfly_bit_for_bit(dtype):
+    """csrc/reduce.h: dev::wave_sum (v_permlane32_swap, v_permlane16_swap, four DPP adds) against the same tree
+    through __shfl_xor -- every lane of every wavefront, values of mixed sign and magnitude so that the order of
+    the additions shows in the last bits."""
+    from pogs_amd import _lib
+    rng = np.random.default_rng(5)
+    v = (rng.standard_normal(64 * 4096) * np.exp(rng.uniform(-12, 12, 64 * 4096))).astype(dtype)
+    v[:64] = np.arange(64)                      # each lane distinguishable
+    v[64:128] = 0
+    v[128:192] = np.where(np.arange(64) == 37, 1.0, 0.0)
+    alu, lds = _lib.wave_sum_check(v)
+    assert np.array_equal(alu.view(np.uint8), lds.view(np.uint8))
+    assert alu[0] == 2016 and np.all(alu[:64] == 2016) and np.all(alu[128:192] == 1)
+    w = v.reshape(-1, 64).astype(np.float64)
+    # the tree itself: partners at distance 32, then 16, ..., 1
+    t = v.reshape(-1, 64).copy()
+    for off in (32, 16, 8, 4, 2, 1):
+        t = t + t[:, np.arange(64) ^ off]
+    assert np.array_equal(t.ravel().view(np.uint8), alu.view(np.uint8))
+    assert np.allclose(alu.reshape(-1, 64)[:, 0], w.sum(axis=1), rtol=0, atol=np.abs(w).sum(axis=1).max() * 64 * np.finfo(dtype).eps)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_mul_matches_numpy(dtype, shape):
