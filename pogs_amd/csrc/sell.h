@@ -105,8 +105,17 @@ struct SellView {
 template <typename T, bool TWO>
 struct SellBatch {
   T v[kSellUB];
-  unsigned short c[kSellUB], r[TWO ? 2 : kSellUB];
+  unsigned short c[kSellUB], r[TWO ? 1 : kSellUB];
+  unsigned rr;   // (two id slots) both ids as loaded: first end's row in the low half, second's in the high half
 };
+#ifndef POGS_SELL_FLAT_FLUSH   // (0: the two-slot format's row ends flushed under exec masks, as the tag format's: round 5's A / B)
+#define POGS_SELL_FLAT_FLUSH 1
+#endif
+constexpr bool kSellFlatFlush = POGS_SELL_FLAT_FLUSH != 0;
+// LDS words of the streaming body: x slice, row sums, and (two id slots) one scratch word per lane for the flat flush
+template <typename T> constexpr size_t sell_lds_bytes() {
+  return (static_cast<size_t>(SellCfg<T>::BW) + SellCfg<T>::RR + kSellTpb) * sizeof(T);
+}
 constexpr unsigned short kSellEndBit = 0x8000;   // (two id slots) set in loc on the last element of a row
 template <typename V> __device__ __forceinline__ V dev_vzero() {
   V v;
@@ -117,7 +126,7 @@ template <int BYTES> struct SellRaw;
 template <> struct SellRaw<4> { typedef unsigned int type; };
 template <> struct SellRaw<8> { typedef unsigned int type __attribute__((ext_vector_type(2))); };
 template <> struct SellRaw<16> { typedef unsigned int type __attribute__((ext_vector_type(4))); };
-template <typename E, int N>
+template <typename E, int N, bool NT = true>
 __device__ __forceinline__ void sell_load(const E *p, E (&out)[N]) {   // N * sizeof(E) bytes, non-temporal, in <= 16-byte pieces
   constexpr int BYTES = N * static_cast<int>(sizeof(E));
   constexpr int PIECE = BYTES >= 16 ? 16 : (BYTES >= 8 ? 8 : 4);
@@ -125,7 +134,8 @@ __device__ __forceinline__ void sell_load(const E *p, E (&out)[N]) {   // N * si
   typedef typename SellRaw<PIECE>::type R;
   R raw[BYTES / PIECE];
 #pragma unroll
-  for (int i = 0; i < BYTES / PIECE; ++i) raw[i] = __builtin_nontemporal_load(reinterpret_cast<const R *>(p) + i);
+  for (int i = 0; i < BYTES / PIECE; ++i)
+    raw[i] = NT ? __builtin_nontemporal_load(reinterpret_cast<const R *>(p) + i) : *(reinterpret_cast<const R *>(p) + i);
   __builtin_memcpy(out, raw, BYTES);
 }
 
@@ -159,9 +169,22 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
   auto tu = [&](int cb) { return sell_uniform_load(a_tu + cb); };
 
   auto fetch = [&](size_t e0, SellBatch<T, TWO> &B) {   // e0: first element of this lane's batch
-    sell_load<T, UB>(a_val + e0, B.v);
-    sell_load<unsigned short, UB>(a_loc + e0, B.c);
-    if constexpr (TWO) sell_load<unsigned short, 2>(a_rid + e0 / 2, B.r);
+#ifndef POGS_SELL_VAL_NT
+#define POGS_SELL_VAL_NT 1
+#endif
+#ifndef POGS_SELL_LOC_NT
+#define POGS_SELL_LOC_NT 1
+#endif
+    sell_load<T, UB, POGS_SELL_VAL_NT != 0>(a_val + e0, B.v);
+    sell_load<unsigned short, UB, POGS_SELL_LOC_NT != 0>(a_loc + e0, B.c);
+    // (measured at C4, round 5, alternating runs on one box: the values and the columns plain instead of non-temporal
+    // cost 12 % / 7 % of the it/s; the id pair -- 1 byte per element -- is the other way round, plain 1283 against 1276 it/s.
+    // As a 4-byte load into two uint16 it had lost its non-temporal mark in the optimiser anyway: it is loaded as one word now)
+#ifndef POGS_SELL_RID_NT
+#define POGS_SELL_RID_NT 0
+#endif
+    if constexpr (TWO) B.rr = POGS_SELL_RID_NT ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(a_rid + e0 / 2))
+                                               : *reinterpret_cast<const unsigned *>(a_rid + e0 / 2);
     else sell_load<unsigned short, UB>(a_rid + e0, B.r);
   };
   T acc = 0;   // running sum of the lane's current row (rows never straddle tiles)
@@ -184,7 +207,7 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
       acc += (SQ ? v * v : v) * xg[j];
       if constexpr (TWO) {
         en[j] = (B.c[j] & kSellEndBit) != 0;
-        row[j] = seen ? B.r[1] : B.r[0];
+        row[j] = static_cast<unsigned short>(seen ? B.rr >> 16 : B.rr & 0xFFFFu);
         seen = seen || en[j];
       } else {
         en[j] = B.r[j] != kSellNoRow;
@@ -193,12 +216,27 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
       fl[j] = acc;
       acc = en[j] ? static_cast<T>(0) : acc;
     }
+    if constexpr (TWO && kSellFlatFlush) {
+      // Flat flush: EVERY element reads and writes one LDS word -- a row end its row sum, any other element the lane's own
+      // scratch word behind the row sums (conflict-free) -- so the batch is straight-line code: no exec mask is saved and
+      // restored around each of the eight accesses, no branch skips a write that some lane of the wavefront needs anyway
+      // (with ~0.45 row ends per element every one of the four positions has ends in every wavefront).  Unused id slots
+      // hold 0, so a look-up of a non-end is in range whatever it names.
+      int at[UB];
 #pragma unroll
-    for (int j = 0; j < UB; ++j)
-      if (en[j]) old[j] = s_y[row[j]];
+      for (int j = 0; j < UB; ++j) at[j] = en[j] ? static_cast<int>(row[j]) : SellCfg<T>::RR + t;
 #pragma unroll
-    for (int j = 0; j < UB; ++j)
-      if (en[j]) s_y[row[j]] = old[j] + fl[j];
+      for (int j = 0; j < UB; ++j) old[j] = s_y[at[j]];
+#pragma unroll
+      for (int j = 0; j < UB; ++j) s_y[at[j]] = old[j] + fl[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < UB; ++j)
+        if (en[j]) old[j] = s_y[row[j]];
+#pragma unroll
+      for (int j = 0; j < UB; ++j)
+        if (en[j]) s_y[row[j]] = old[j] + fl[j];
+    }
   };
 
   // column blocks of this group: an even split of the ncb blocks

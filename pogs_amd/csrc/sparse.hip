@@ -911,7 +911,8 @@ class SparseSolver final : public SolverBase {
     M.srid.alloc(M.two ? M.sell_elems / 2 : M.sell_elems);
     M.sval.zero(s);
     M.sloc.zero(s);
-    POGS_HIP_CHECK(hipMemsetAsync(M.srid.p, 0xFF, M.srid.n * sizeof(unsigned short), s));
+    // (tags: kSellNoRow everywhere but on row ends; two id slots: an unused slot names row 0 -- it is looked up, never written)
+    POGS_HIP_CHECK(hipMemsetAsync(M.srid.p, M.two ? 0x00 : 0xFF, M.srid.n * sizeof(unsigned short), s));
     M.sell_ready = true;
     fill_sell(M, true);
     if (ncg > 1) M.part.alloc(static_cast<size_t>(ncg) * M.nrows);
@@ -1079,7 +1080,7 @@ class SparseSolver final : public SolverBase {
     int grid;
     if (timed) ctx_.stream_timer.begin(s);
     if (M.sell_ready) {
-      constexpr size_t smem = (static_cast<size_t>(SellCfg<T>::BW) + SellCfg<T>::RR) * sizeof(T);
+      constexpr size_t smem = sell_lds_bytes<T>();
       const int g1 = M.nrr * M.ncg;
       if (M.ncg == 1) {
         static SmemGrants grants;
@@ -1135,7 +1136,7 @@ class SparseSolver final : public SolverBase {
   template <typename Op>
   int spmv_cg(const DevCsr<T> &M, const T *x, const Op &op, double *rec, int run_if_done, size_t *ev) {
     hipStream_t s = ctx_.stream;
-    constexpr size_t smem = (static_cast<size_t>(SellCfg<T>::BW) + SellCfg<T>::RR) * sizeof(T);
+    constexpr size_t smem = sell_lds_bytes<T>();
     const double *S = ctx_.S.p;
     const double *guard = run_if_done == 0 ? S + kFcDone : nullptr;
     const int g1 = M.nrr * M.ncg;
