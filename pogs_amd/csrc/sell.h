@@ -440,19 +440,38 @@ __global__ void __launch_bounds__(kSellTpb) spmv_sell_kernel(SellView<T> A, cons
 
 // ---------------------------------------------------------------------------------------------
 // Build (device).  Temporaries per (tile, local row): cnt (non-zeros, uint16: a tile is at most
-// 24576 wide), soff (stream << 23 | offset of the row inside its stream), cursor (fill position).
+// 24576 wide), soff (stream << 23 | offset of the row inside its stream).
 // ---------------------------------------------------------------------------------------------
 struct SellDims {
   int nrows, ncols, rr_rows, nrr, ncb, bw;
 };
 
-// cnt[tile * rr_rows + local row] = non-zeros of that row inside the tile (one thread per row)
-__global__ void sell_count_kernel(const int *ind, const int *ptr, SellDims D, unsigned short *cnt) {
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < D.nrows; r += gridDim.x * blockDim.x) {
+// cnt[tile * rr_rows + local row] = non-zeros of that row inside the tile; cnt is zero on entry.  A wavefront per row: in a
+// row whose column blocks do not decrease the first element of every run of equal blocks walks forward to the run's end and
+// writes its length; any other row is counted by one lane, element by element (as every row was, one thread per row, until
+// round 5: 2.3 ms per copy at C4).
+__global__ void __launch_bounds__(256) sell_count_kernel(const int *ind, const int *ptr, SellDims D, unsigned short *cnt) {
+  const int lane = threadIdx.x & 63;
+  const int w = static_cast<int>((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nw = static_cast<int>((gridDim.x * blockDim.x) >> 6);
+  for (int r = w; r < D.nrows; r += nw) {
     const int rr = r / D.rr_rows, lr = r - rr * D.rr_rows;
-    for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
-      const int cb = ind[k] / D.bw;
-      cnt[(static_cast<size_t>(rr) * D.ncb + cb) * D.rr_rows + lr] += 1;
+    const int p0 = ptr[r], p1 = ptr[r + 1];
+    bool mono = true;
+    for (int k = p0 + 1 + lane; k < p1; k += 64) mono = mono && (ind[k] / D.bw >= ind[k - 1] / D.bw);
+    mono = __all(mono);
+    if (mono) {
+      for (int k = p0 + lane; k < p1; k += 64) {
+        const int cb = ind[k] / D.bw;
+        if (k > p0 && ind[k - 1] / D.bw == cb) continue;   // not the first of its run
+        int e = k + 1;
+        while (e < p1 && ind[e] / D.bw == cb) ++e;
+        cnt[(static_cast<size_t>(rr) * D.ncb + cb) * D.rr_rows + lr] = static_cast<unsigned short>(e - k);
+      }
+    } else if (lane == 0) {
+      for (int k = p0; k < p1; ++k) {
+        const int cb = ind[k] / D.bw;
+        cnt[(static_cast<size_t>(rr) * D.ncb + cb) * D.rr_rows + lr] += 1;
+      }
     }
   }
 }
@@ -615,20 +634,38 @@ __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cn
   }
 }
 
-// copies every non-zero to its place (one thread per row, non-zeros in their CSR order); cursor
-// must be zero on entry.  sloc == nullptr: values only (after a rescaling of the CSR copy).
+// copies every non-zero to its place: element j (in CSR order) of a row's non-zeros inside a tile goes to position
+// offset + j of the row's stream.  One WAVEFRONT per row, a lane per non-zero: j is the number of the row's earlier
+// non-zeros in the same column block -- for a row whose column blocks do not decrease (every row of the transposed
+// copy, every row of a sorted input) the distance to the start of its run of equal blocks, found by walking back
+// (~2 steps at C4); for any other row a count over the row's prefix.  (One thread per row with a cursor per (row, tile)
+// in global memory -- 50 to 200 dependent read-modify-writes per thread -- took 8.7 ms per copy at C4.)
+// sloc == nullptr: values only (after a rescaling of the CSR copy).
 template <typename T>
-__global__ void sell_fill_kernel(const T *val, const int *ind, const int *ptr, SellDims D, const unsigned short *cnt,
-                                 const unsigned *soff, unsigned short *cursor, const int *tile_unit, T *sval,
-                                 unsigned short *sloc, unsigned short *srid, unsigned *dst_out, int two) {
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < D.nrows; r += gridDim.x * blockDim.x) {
+__global__ void __launch_bounds__(256) sell_fill_kernel(const T *val, const int *ind, const int *ptr, SellDims D,
+                                                        const unsigned short *cnt, const unsigned *soff, const int *tile_unit,
+                                                        T *sval, unsigned short *sloc, unsigned short *srid, unsigned *dst_out,
+                                                        int two) {
+  const int lane = threadIdx.x & 63;
+  const int w = static_cast<int>((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nw = static_cast<int>((gridDim.x * blockDim.x) >> 6);
+  for (int r = w; r < D.nrows; r += nw) {
     const int rr = r / D.rr_rows, lr = r - rr * D.rr_rows;
-    for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
+    const int p0 = ptr[r], p1 = ptr[r + 1];
+    bool mono = true;
+    for (int k = p0 + 1 + lane; k < p1; k += 64) mono = mono && (ind[k] / D.bw >= ind[k - 1] / D.bw);
+    mono = __all(mono);
+    for (int k = p0 + lane; k < p1; k += 64) {
       const int c = ind[k], cb = c / D.bw;
+      int j = 0;
+      if (mono) {
+        int kk = k;
+        while (kk > p0 && ind[kk - 1] / D.bw == cb) --kk;
+        j = k - kk;
+      } else {
+        for (int q = p0; q < k; ++q) j += (ind[q] / D.bw == cb) ? 1 : 0;
+      }
       const int tile = rr * D.ncb + cb;
       const size_t idx = static_cast<size_t>(tile) * D.rr_rows + lr;
-      const int j = cursor[idx];
-      cursor[idx] = static_cast<unsigned short>(j + 1);
       const unsigned so = soff[idx];
       const int sidx = static_cast<int>(so >> kSellOffBits);
       const int off = static_cast<int>(so & ((1u << (two ? kSellOff2Bits : kSellOffBits)) - 1));

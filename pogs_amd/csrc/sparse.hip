@@ -838,7 +838,7 @@ class SparseSolver final : public SolverBase {
     const long long nq = ntiles * rr_rows;
     if (ntiles >= (1LL << 30) || nq >= (1LL << 31)) return;
     {
-      // The plan keeps 8 bytes per (row, column block) pair (count, stream offset, fill cursor) --
+      // The plan keeps 6 bytes per (row, column block) pair (count, stream offset; 8 are budgeted below, as when the fill kept a cursor too) --
       // on a matrix with many column blocks and few non-zeros per row that outweighs the matrix
       // itself (5e6 x 5e6: 272 blocks x 5e6 rows x 8 B = 10 GB).  Beyond 4x the CSR bytes, or half of
       // what the device has free, the plain CSR kernel stays (the same exit as a padding blow-up).
@@ -860,7 +860,7 @@ class SparseSolver final : public SolverBase {
     M.scnt.alloc(nq); M.ssoff.alloc(nq);
     if (want_two != 0) soff2.alloc(nq);
     M.scnt.zero(s);
-    const int g = std::max(1, std::min((M.nrows + 255) / 256, ctx_.num_cu * 16));
+    const int g = std::max(1, std::min((M.nrows + 3) / 4, ctx_.num_cu * 32));   // a wavefront per row, four per workgroup
     hipLaunchKernelGGL(sell_count_kernel, dim3(g), dim3(256), 0, s, M.ind.p, M.ptr.p, D, M.scnt.p);
     DevBuf<int> nu(ntiles + 1), nu2, err(1);
     DevBuf<int> tile_unit2;
@@ -923,18 +923,15 @@ class SparseSolver final : public SolverBase {
   void fill_sell(DevCsr<T> &M, bool with_loc) {
     if (!M.sell_ready) return;
     hipStream_t s = ctx_.stream;
-    const size_t nq = static_cast<size_t>(M.nrr) * M.ncb * M.rr_rows;
-    DevBuf<unsigned short> cursor(nq);
-    cursor.zero(s);
     // the first fill records where every CSR element went (4 B per non-zero until refill_sell): the
     // values are written once more after equilibration, and walking the (row, tile) bookkeeping a
     // second time costs 6.7 ms per copy at C4 against 1 ms for a gather through that table
     if (with_loc && M.sell_elems < (static_cast<size_t>(1) << 32)) M.sdst.alloc(M.nnz);
-    const int g = std::max(1, std::min((M.nrows + 255) / 256, ctx_.num_cu * 16));
+    const int g = std::max(1, std::min((M.nrows + 3) / 4, ctx_.num_cu * 32));   // a wavefront per row, four per workgroup
     hipLaunchKernelGGL(sell_fill_kernel<T>, dim3(g), dim3(256), 0, s, M.val.p, M.ind.p, M.ptr.p, M.sdims(), M.scnt.p,
-                       M.ssoff.p, cursor.p, M.tile_unit.p, M.sval.p, with_loc ? M.sloc.p : nullptr, M.srid.p,
+                       M.ssoff.p, M.tile_unit.p, M.sval.p, with_loc ? M.sloc.p : nullptr, M.srid.p,
                        with_loc ? M.sdst.p : nullptr, M.two);
-    ctx_.sync();   // cursor is freed at scope exit
+    ctx_.sync();
   }
   // the values are final (equilibrated): refill and drop the build temporaries
   void refill_sell(DevCsr<T> &M) {
