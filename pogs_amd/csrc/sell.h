@@ -67,7 +67,10 @@ constexpr int kSellTpb = 512;           // one workgroup per CU (LDS), 8 wavefro
 constexpr int kSellWaves = kSellTpb / 64;
 constexpr int kSellStreams = kSellTpb;  // lane streams per tile
 constexpr int kSellUB = 4;              // elements per lane and batch (a tile's stream length is a multiple of it)
-constexpr int kSellNB = 8;              // batches in flight per wavefront (3 x 16- / 8-byte loads each)
+#ifndef POGS_SELL_NB   // (compile-time override: ring-depth A / B runs through scripts/build_variant.py; two-slot format at C4: 6 = 8, 10 and 12 are 1.5-2 % slower)
+#define POGS_SELL_NB 8
+#endif
+constexpr int kSellNB = POGS_SELL_NB;   // batches in flight per wavefront (3 x 16- / 8- / 4-byte loads each)
 constexpr int kSellLmax = 32;           // sort classes: row lengths 1..32 each, longer rows together
 template <typename T> struct SellCfg;
 #ifndef POGS_SELL_BW_F32   // (compile-time overrides: tile-shape experiments through scripts/build_variant.py, scripts/spmv_probe.sh)
