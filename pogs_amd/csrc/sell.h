@@ -251,6 +251,7 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
   using V = typename Vec16<T>::type;
   constexpr int VEC = Vec16<T>::N;
   constexpr int XV = BW / (kSellTpb * VEC);
+  static_assert(BW % (kSellTpb * VEC) == 0, "the x slice is loaded as whole 16-byte vectors per thread (an override of the tile width must keep that)");
   V xreg[XV];
   int x_cb = cb0 - 1, x_w = 0;   // block whose slice is in xreg, its width
   auto x_prefetch = [&]() {   // advance x_cb to the next non-empty tile and request its slice
