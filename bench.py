@@ -57,8 +57,15 @@ rate as `value / N`, marked `extrapolated` (every per-iteration term of the refe
 whole C5 problem is beyond its int-sized views), and `roofline.traffic` is measured on rank 0's GPU.
 The line also carries both roofline peaks (`peak_datasheet`, `peak_measured`: the library's read probe),
 `exact_setup` (the same create + solve with the setup's two shortcuts off), `one_shot_host_call` (the
-reference's entry point with a HOST matrix, and the upload on its own) and ends with `headline`: the
-headline workload's own wall-clock figures (the driver keeps the tail of stdout).  Dense: the compiled reference in
+reference's entry point with a HOST matrix, and the upload on its own).
+
+OUTPUT: two lines on stdout.  First `BENCH_DETAIL {...}`: the long record, every workload's whole dictionary
+(also written to gpurun_out/bench_detail.json).  Then, LAST, the contract line (summary_line): starts with
+{"metric", at most 6000 characters, with `roofline`, `cpu_baseline`, the wall-clock and parity scalars of the
+headline workload and a short block (value, roofline, parity, CPU figure) per secondary workload -- the driver
+parses the last line out of an 8 KB tail of stdout.
+
+CPU leg.  Dense: the compiled reference in
 both BLAS builds -- oracle/_ref/libpogs_cpu_openblas.so (scipy's OpenBLAS, which threads its
 gemv: the "best configuration") and oracle/_ref/libpogs_cpu.so (MKL, the build the oracle is
 pinned to; on the GPU box's AMD host its sgemv runs on one thread,
@@ -997,6 +1004,104 @@ def run_config(env, name, with_cpu):
     return line
 
 
+SUMMARY_MAX_CHARS = 6000   # the driver keeps an 8 KB tail of stdout and parses its last line (BENCH_r05: a 24 KB line was lost)
+DETAIL_PREFIX = "BENCH_DETAIL "
+
+
+def _short(x, sig=6):
+    """Floats to `sig` significant digits, strings cut to 160 characters, containers walked."""
+    if isinstance(x, bool) or x is None or isinstance(x, int):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, str):
+        return x if len(x) <= 160 else x[:157] + "..."
+    if isinstance(x, dict):
+        return {k: _short(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_short(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _workload_summary(d):
+    """The few figures of one secondary workload the contract line keeps (its whole dictionary is in the detail line)."""
+    if not isinstance(d, dict) or not d.get("value"):
+        return _short(_pick(d, ("value", "error")))
+    rf, par, cb = d.get("roofline") or {}, d.get("parity_vs_reference") or {}, d.get("cpu_baseline") or {}
+    out = _pick(d, ("value", "unit", "dtype", "ms_per_step", "time_to_converge_s", "init_s", "solve_iterations", "solve_status"))
+    out["workload"] = (d.get("config") or {}).get("workload", "")[:110]
+    out["roofline"] = _pick(rf, ("frac", "achieved", "traffic", "bytes_per_launch", "avg_launch_ms", "iteration_frac",
+                                 "frac_of_peak_measured"))
+    out["roofline"]["kernel"] = (rf.get("kernel") or "")[:60]
+    out["parity_rel_x"] = par.get("rel_x")
+    if "iterations_engine" in par:
+        out["parity_iterations"] = "%d engine / %d reference" % (par["iterations_engine"], par["iterations_reference"])
+    if cb:
+        out["cpu_baseline"] = _pick(cb, ("value", "cores", "kind", "time_to_converge_s", "converged"))
+    return _short(out)
+
+
+def summary_line(line):
+    """The contract line: starts with `metric`, carries `roofline` and `cpu_baseline` whole enough to check, the
+    headline workload's wall-clock and parity scalars, and a short summary per secondary workload; at most
+    SUMMARY_MAX_CHARS characters (the reference prints its totals in two short lines, src/cpu/pogs.cpp:485-490)."""
+    rf, cf = line["roofline"], line["config"]
+    out = _pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"))
+    out["config"] = _pick(cf, ("workload", "name", "rows_per_gpu", "cols", "projector", "parallelism", "rccl_nranks"))
+    out["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "bytes_per_launch",
+                                 "avg_launch_ms", "launches", "peak_measured", "frac_of_peak_measured", "iteration_frac"))
+    src = rf.get("traffic_source") or rf.get("traffic_live")
+    if src:
+        out["roofline"]["traffic_source"] = src[:100]
+    if isinstance(rf.get("iteration"), dict):
+        out["roofline"]["iteration_bytes"] = rf["iteration"].get("bytes")
+    cb = line.get("cpu_baseline")
+    if cb is not None:
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "time_to_converge_s", "init_s", "loop_s",
+                                         "iterations", "converged", "extrapolated", "host_threads_visible"))
+    out.update(_pick(line, ("time_to_converge_s", "init_s", "loop_s", "solve_iterations", "solve_status",
+                            "time_to_converge_exact_setup_s", "setup_ms", "gram_tflops", "windows", "windows_cover")))
+    if "handle_cycles" in line:
+        out["handle_cycles_max_time_to_converge_s"] = line["handle_cycles"]["max_time_to_converge_s"]
+        out["handle_cycles_max_init_s"] = line["handle_cycles"]["max_init_s"]
+    if isinstance(line.get("one_shot_host_call"), dict):
+        out["one_shot_host_call_s"] = line["one_shot_host_call"].get("one_shot_host_call_s")
+        out["h2d_s"] = line["one_shot_host_call"].get("h2d_s")
+    par = line.get("parity_vs_reference")
+    if isinstance(par, dict):
+        out["parity"] = _pick(par, ("rel_x", "rel_optval", "iterations_engine", "iterations_reference", "tolerance",
+                                    "rel_x_vs_reference_fp32_build", "against", "error"))
+    if "secondary" in line:
+        out["secondary"] = {k: _workload_summary(v) for k, v in line["secondary"].items()}
+    out["detail"] = "stdout line before this one (prefix %r) and gpurun_out/bench_detail.json" % DETAIL_PREFIX.strip()
+    out = _short(out)
+    # a hard stop, never reached by the shapes above (tests/test_gpu_bench.py holds the line under the limit)
+    for drop in ("detail", "setup_ms", "windows_cover", "handle_cycles_max_init_s", "h2d_s"):
+        if len(json.dumps(out)) <= SUMMARY_MAX_CHARS:
+            break
+        out.pop(drop, None)
+    return out
+
+
+def write_detail(detail_line):
+    """The long record: one prefixed stdout line BEFORE the contract line, and a file next to the profiles."""
+    if detail_line is None:
+        return
+    print(DETAIL_PREFIX + detail_line, flush=True)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_detail.json"), "w") as fh:
+            fh.write(detail_line + "\n")
+    except OSError:
+        pass
+
+
 LIVE_TRAFFIC_LATEST_START_S = 420.0   # the counter passes are skipped when the run has already taken longer (a cold box)
 
 
@@ -1049,37 +1154,12 @@ def main():
             rf["traffic"], rf["traffic_source"] = live, how
         else:
             rf["traffic_live"] = "not measured: " + how
+    detail_line = None
     if line is not None:
-        # the line ENDS with the headline workload's own short summary (the driver keeps the tail of stdout: it must
-        # not end inside a secondary workload's fields) -- `secondary` and the long per-workload dictionaries first
-        tail_keys = ("time_to_converge_s", "init_s", "loop_s", "solve_iterations", "solve_status", "time_to_converge_exact_setup_s")
-        head_sum = {k: line[k] for k in tail_keys if k in line}
-        if "handle_cycles" in line:
-            head_sum["handle_cycles_max_time_to_converge_s"] = line["handle_cycles"]["max_time_to_converge_s"]
-            head_sum["handle_cycles_max_init_s"] = line["handle_cycles"]["max_init_s"]
-        if isinstance(line.get("one_shot_host_call"), dict):
-            head_sum["one_shot_host_call_s"] = line["one_shot_host_call"].get("one_shot_host_call_s")
-            head_sum["h2d_s"] = line["one_shot_host_call"].get("h2d_s")
-        par = line.get("parity_vs_reference")
-        if isinstance(par, dict) and "rel_x" in par:
-            head_sum["parity_rel_x"] = par["rel_x"]
-            head_sum["parity_iterations_engine"] = par["iterations_engine"]
-            head_sum["parity_iterations_reference"] = par["iterations_reference"]
-        head_sum.update(value=line["value"], unit=line["unit"], workload=line["config"]["name"],
-                        roofline_frac=line["roofline"]["frac"], iteration_frac=line["roofline"]["iteration"]["frac"])
-        ordered = {}
-        first = ("secondary", "handle_cycles", "parity_vs_reference", "first_handle_of_the_process", "time_to_converge_includes",
-                 "exact_setup", "one_shot_host_call", "window_s")
-        for k in first:
-            if k in line:
-                ordered[k] = line[k]
-        for k, v in line.items():
-            if k not in ordered and k != "cpu_baseline":
-                ordered[k] = v
-        if "cpu_baseline" in line:
-            ordered["cpu_baseline"] = line["cpu_baseline"]
-        ordered["headline"] = head_sum
-        line = ordered
+        # TWO lines: the long record (every workload's full dictionary) first, prefixed so that nothing mistakes
+        # it for the contract line, and then ONE short line that starts with {"metric" (summary_line)
+        detail_line = json.dumps(line)
+        line = summary_line(line)
     out_line = json.dumps(line) if line is not None else None
     # The JSON line must be the LAST line of the job's stdout.  C libraries print through stdio
     # (RCCL's version banner: on a pipe it sits in the buffer until exit), so every rank empties
@@ -1095,6 +1175,7 @@ def main():
         env.long_barrier()
         env.dist.destroy_process_group()
     if out_line is not None:
+        write_detail(detail_line)
         print(out_line, flush=True)
 
 

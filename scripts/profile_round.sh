@@ -4,7 +4,7 @@
 #   kernel_stats.csv          rocprofv3 --kernel-trace --stats summary of the same command
 #   pmc_traffic.json          FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes, corrected)
 # usage: profile_round.sh <tag> [c2|c3|c4|c2f64]       (then copy the three files into profiles/)
-tag=${1:-r05}
+tag=${1:-r06}
 cfg=${2:-c2}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_${tag}_${cfg}
@@ -24,5 +24,8 @@ rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 # the plain run comes last so that its line quotes the counters collected above (same sources, same box)
 cp $O/pmc_traffic.json $R/profiles/pmc_traffic_${cfg}.json
 # (third argument "--no-cpu": skip the CPU leg of the plain run -- minutes at c2 / c3 / c4)
-python $R/bench.py --config $cfg --steps 200 --warmup 20 $([ "$3" = "--no-cpu" ] && echo --no-cpu-baseline) > $O/bench.json 2> $O/bench.err
-tail -c 600 $O/bench.json
+# (stdout: the long record on a BENCH_DETAIL line, then the short contract line; bench.json keeps the long one)
+python $R/bench.py --config $cfg --steps 200 --warmup 20 $([ "$3" = "--no-cpu" ] && echo --no-cpu-baseline) > $O/bench.out 2> $O/bench.err
+tail -n 1 $O/bench.out > $O/bench_line.json
+grep '^BENCH_DETAIL ' $O/bench.out | tail -n 1 | cut -c14- > $O/bench.json
+cat $O/bench_line.json

@@ -18,8 +18,22 @@ def _bench(args, env_extra=None, timeout=600):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
                        timeout=timeout, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = r.stdout.strip().splitlines()[-1]          # the JSON line is the LAST line of stdout
-    return json.loads(line)
+    lines = r.stdout.strip().splitlines()
+    last = lines[-1]                                  # the contract line is the LAST line of stdout ...
+    assert last.startswith('{"metric"') and len(last) < 6000, (len(last), last[:80])   # ... short, and starts with `metric`
+    summary = json.loads(last)
+    assert [ln for ln in lines if ln.startswith("{")] == [last]          # the only line a JSON scanner can pick up
+    detail = [ln for ln in lines if ln.startswith("BENCH_DETAIL ")]
+    assert len(detail) == 1 and lines.index(detail[0]) < len(lines) - 1
+    d = json.loads(detail[0][len("BENCH_DETAIL "):])     # the long record: every workload's whole dictionary
+    with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json")) as fh:
+        assert json.load(fh) == d
+    d["_summary"] = summary
+    return d
+
+
+def _close(a, b, rel=1e-5):
+    return abs(a - b) <= rel * abs(b)
 
 
 @pytest.fixture(scope="module")
@@ -59,10 +73,7 @@ def test_default_invocation_carries_the_contract_fields_and_the_secondary_worklo
     cf = d["config"]
     assert cf["time_to_converge_s"] == d["time_to_converge_s"] and cf["init_s"] == d["init_s"]
     assert cf["handle_cycles_max_time_to_converge_s"] == d["handle_cycles"]["max_time_to_converge_s"]
-    assert list(d)[-1] == "headline" and list(d)[0] == "secondary"
-    hl = d["headline"]
-    assert hl["workload"] == "c2" and hl["time_to_converge_s"] == d["time_to_converge_s"] and hl["value"] == d["value"]
-    assert hl["parity_rel_x"] == d["parity_vs_reference"]["rel_x"] == cf["parity_rel_x"]
+    assert d["parity_vs_reference"]["rel_x"] == cf["parity_rel_x"]
     # the setup with its two shortcuts switched off (native fp32 Gram, all 50 Sinkhorn-Knopp passes): same solve,
     # a dearer setup, stated next to the default
     ex = d["exact_setup"]
@@ -100,6 +111,40 @@ def test_default_invocation_carries_the_contract_fields_and_the_secondary_worklo
         assert s["init_s"] <= init_cap and s["time_to_converge_s"] <= ttc_cap, (name, s["init_s"], s["time_to_converge_s"])
 
 
+def test_the_contract_line_is_short_and_carries_every_workloads_figures(plain):
+    """BENCH_r05.parsed was null: the line had grown to 24 KB and began with `secondary`, the driver keeps an 8 KB
+    tail.  The LAST line is now a summary (bench.summary_line): it starts with `metric`, stays under 6 KB, and
+    still holds `roofline`, the wall-clock and parity scalars and a short block per secondary workload; the long
+    record is the line before it (asserted in _bench) and gpurun_out/bench_detail.json."""
+    d, sm = plain, plain["_summary"]
+    assert list(sm)[0] == "metric" and len(json.dumps(sm)) < 6000
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "time_to_converge_s", "init_s", "parity", "secondary"):
+        assert key in sm, key
+    assert sm["metric"] == d["metric"] and sm["n_gpus"] == 1 and sm["steps"] == 20 and sm["warmup"] == 5
+    assert sm["config"]["name"] == "c2" and "configs[1]" in sm["config"]["workload"] and "model" not in sm["config"]
+    assert _close(sm["value"], d["value"]) and _close(sm["ms_per_step"], d["ms_per_step"])
+    assert _close(sm["value"], 1e3 / sm["ms_per_step"], 1e-4)
+    rf, rd = sm["roofline"], d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "peak_measured", "iteration_frac",
+                "bytes_per_launch", "avg_launch_ms"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and _close(rf["frac"], rf["achieved"] / rf["peak"], 1e-4)
+    assert _close(rf["frac"], rd["frac"]) and _close(rf["traffic"], rd["traffic"]) and _close(rf["iteration_frac"], rd["iteration_frac"])
+    assert _close(sm["time_to_converge_s"], d["time_to_converge_s"]) and _close(sm["init_s"], d["init_s"])
+    assert sm["solve_iterations"] == d["solve_iterations"] and sm["solve_status"] == 0
+    assert _close(sm["parity"]["rel_x"], d["parity_vs_reference"]["rel_x"]) and sm["parity"]["iterations_engine"] == sm["parity"]["iterations_reference"] == 106
+    assert _close(sm["handle_cycles_max_time_to_converge_s"], d["handle_cycles"]["max_time_to_converge_s"])
+    assert _close(sm["one_shot_host_call_s"], d["one_shot_host_call"]["one_shot_host_call_s"])
+    for name in ("c3", "c4", "c2f64"):
+        s, full = sm["secondary"][name], d["secondary"][name]
+        assert _close(s["value"], full["value"]) and _close(s["roofline"]["frac"], full["roofline"]["frac"])
+        assert _close(s["roofline"]["iteration_frac"], full["roofline"]["iteration_frac"])
+        assert _close(s["parity_rel_x"], full["parity_vs_reference"]["rel_x"]) and s["parity_rel_x"] < 1e-4
+        assert s["solve_status"] == 0 and s["parity_iterations"].split()[0] == str(full["parity_vs_reference"]["iterations_engine"])
+    assert "cpu_baseline" not in sm          # this fixture runs with --no-cpu-baseline (the forced-communicator test has it)
+
+
 def test_forced_communicator_line_is_contract_complete():
     """The first multi-GPU line must not be the first time its extra legs run: the driver's
     command through the one-rank RCCL path carries `cpu_baseline`, a `roofline.traffic` measured in the run (the
@@ -118,7 +163,10 @@ def test_forced_communicator_line_is_contract_complete():
     assert 0.97 * 4.0e9 < rf["traffic"] < 1.10 * 4.0e9, rf["traffic"]
     par = d["parity_vs_reference"]
     assert par["rel_x"] < 1e-4 and abs(par["iterations_engine"] - par["iterations_reference"]) <= 3, par
-    assert d["headline"]["time_to_converge_s"] == d["time_to_converge_s"] == d["config"]["time_to_converge_s"]
+    assert d["time_to_converge_s"] == d["config"]["time_to_converge_s"]
+    sm = d["_summary"]
+    assert sm["cpu_baseline"]["kind"] == "reference" and _close(sm["cpu_baseline"]["value"], cb["value"])
+    assert sm["config"]["rccl_nranks"] == 1 and "secondary" not in sm and sm["parity"]["iterations_reference"] == par["iterations_reference"]
 
 
 @pytest.mark.parametrize("cfg", ["c2", "c4"])

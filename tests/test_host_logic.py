@@ -261,3 +261,52 @@ def test_bench_windows_cover_whole_solves():
     assert bench.pick_windows(1000, 106, 0.68e-3)[0] == 1               # K spans many solves already
     w, _ = bench.pick_windows(20, 2500, 1e-3)                          # a solve longer than 40 windows: as many as allowed
     assert w == 40
+
+
+def test_bench_contract_line_is_short_and_starts_with_metric(capsys, tmp_path, monkeypatch):
+    """BENCH_r05.parsed was null: a 24 KB line that began with `secondary`, of which the driver's 8 KB stdout
+    tail held the end.  bench.summary_line turns a full record (here: round 5's committed one,
+    profiles/r05_bench_driver_cmd.json) into the contract line -- first key `metric`, under 6 KB, `roofline` and
+    `cpu_baseline` with the contract's fields, a short block per secondary workload -- and write_detail puts the
+    long record on its own prefixed line BEFORE it."""
+    import json
+
+    import bench
+
+    full = json.load(open(os.path.join(os.path.dirname(bench.__file__), "profiles", "r05_bench_driver_cmd.json")))
+    full.pop("headline", None)
+    sm = bench.summary_line(full)
+    text = json.dumps(sm)
+    assert text.startswith('{"metric"') and len(text) < bench.SUMMARY_MAX_CHARS <= 6000, len(text)
+    assert "NaN" not in text and "Infinity" not in text
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in sm, key
+    assert sm["config"]["name"] == "c2" and "configs[1]" in sm["config"]["workload"] and "model" not in sm["config"]
+    rf = sm["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf)
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5 and abs(rf["frac"] - full["roofline"]["frac"]) < 1e-5
+    cb = sm["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] == "reference" and cb["cores"] == 16
+    assert abs(sm["value"] - full["value"]) < 1e-5 * full["value"]
+    assert abs(sm["value"] - 1e3 / sm["ms_per_step"]) < 1e-4 * sm["value"]
+    assert sm["parity"]["iterations_engine"] == sm["parity"]["iterations_reference"] == 106
+    for name in ("c3", "c4", "c2f64"):
+        s, f = sm["secondary"][name], full["secondary"][name]
+        assert abs(s["value"] - f["value"]) < 1e-5 * f["value"]
+        assert abs(s["roofline"]["frac"] - f["roofline"]["frac"]) < 1e-5
+        assert abs(s["parity_rel_x"] - f["parity_vs_reference"]["rel_x"]) <= 1e-5 * f["parity_vs_reference"]["rel_x"]
+    # a record with oversized strings / lists still comes out under the limit
+    fat = json.loads(json.dumps(full))
+    fat["config"]["workload"] = "w" * 5000
+    fat["cpu_baseline"]["sample"] = "s" * 5000
+    fat["secondary"]["c3"]["roofline"]["kernel"] = "k" * 5000
+    assert len(json.dumps(bench.summary_line(fat))) < bench.SUMMARY_MAX_CHARS
+    # the long record goes out first, prefixed: it neither starts with "{" nor ends the output
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.write_detail(json.dumps(full))
+    print(text)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 2 and out[0].startswith(bench.DETAIL_PREFIX) and out[1] == text
+    assert json.loads(out[0][len(bench.DETAIL_PREFIX):]) == full
+    assert json.load(open(tmp_path / "gpurun_out" / "bench_detail.json")) == full
