@@ -111,8 +111,10 @@ def parse():
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
                     help="default: c2 as the headline line, and at --gpus 1 also c3 and c4 as `secondary`")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--m", type=int, default=0, help="rows per GPU (default: the configuration's)")
-    ap.add_argument("--n", type=int, default=0)
+    # (--rows-per-gpu / --cols: under `python -m torch.distributed.run ... bench.py ARGS` the launcher's own parser
+    # reads a bare --m or --n as an ambiguous abbreviation of ITS options -- found by the two-process rehearsal)
+    ap.add_argument("--m", "--rows-per-gpu", dest="m", type=int, default=0, help="rows per GPU (default: the configuration's)")
+    ap.add_argument("--n", "--cols", dest="n", type=int, default=0)
     ap.add_argument("--projector", choices=["default", "cgls"], default="default",
                     help="dense configurations: 'cgls' selects the matrix-free CGLS projector (the reference's "
                          "ProjectorCgls on a dense matrix, src/cpu/projector/projector_cgls.cpp) instead of the direct one")
@@ -591,8 +593,20 @@ class Env:
         if self.world != args.gpus and self.rank == 0:
             print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d"
                   % (args.gpus, self.world, self.world), file=sys.stderr)
+        # Rehearsal of the N > 1 launcher path on a box with fewer GPUs than ranks (tests/test_gpu_bench.py;
+        # POGS_AMD_BENCH_REHEARSAL=1, test-only): the ranks share the devices there are, the process group is gloo
+        # and the solver handles are joined by the shared-memory communicator of the test transport plug-in
+        # (tests/transport/test_transport.hip) -- RCCL refuses two ranks on one device.  Everything else is the
+        # real run's code: rank environment, the 128-byte id broadcast, per-rank shards, the barriers, rank 0's
+        # CPU leg and unsharded parity solve while the others wait, the line's assembly.
+        self.rehearsal = os.environ.get("POGS_AMD_BENCH_REHEARSAL", "0") == "1" and self.world > 1
+        if self.rehearsal:
+            self.local = self.local % max(torch.cuda.device_count(), 1)
+            os.environ.setdefault("POGS_AMD_TRANSPORT_PLUGIN",
+                                  os.path.join(ROOT, "tests", "transport", "libpogs_test_transport.so"))
         torch.cuda.set_device(self.local)
         self.dev = torch.device("cuda", self.local)
+        self.coll_dev = torch.device("cpu") if self.rehearsal else self.dev   # where the process group's tensors live
         self.dist = None
         self.force_dist = os.environ.get("POGS_AMD_FORCE_DIST", "0") == "1"  # exercise the RCCL path with 1 rank
         if self.world > 1 or self.force_dist:
@@ -607,7 +621,7 @@ class Env:
                 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
             # rank 0 works alone for minutes after the timed region (the CPU baseline, the unsharded parity solve,
             # the counter passes): no collective may time out meanwhile
-            dist.init_process_group("nccl", timeout=datetime.timedelta(minutes=60))
+            dist.init_process_group("gloo" if self.rehearsal else "nccl", timeout=datetime.timedelta(minutes=60))
             self.dist = dist
             # the other ranks wait for rank 0 on sockets (gloo), not spinning on a GPU collective: rank 0's CPU
             # baseline needs the host cores
@@ -657,9 +671,14 @@ def run_config(env, name, with_cpu):
         """(rank, world, global rows, a FRESH RCCL unique id from rank 0): one per solver handle."""
         if dist is None:
             return None
-        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        uid = torch.zeros(128, dtype=torch.uint8, device=env.coll_dev)
         if rank == 0:
-            uid = torch.tensor(list(pogs_amd.dist_unique_id()), dtype=torch.uint8, device=dev)
+            if env.rehearsal:   # an id of the test plug-in's shared-memory communicator instead of RCCL's
+                env.shm_ids = getattr(env, "shm_ids", 0) + 1
+                raw = ("POGSSHM:%d-%d-%s" % (os.getpid(), env.shm_ids, os.urandom(4).hex())).encode().ljust(128, b"\0")
+            else:
+                raw = pogs_amd.dist_unique_id()
+            uid = torch.tensor(list(raw), dtype=torch.uint8, device=env.coll_dev)
         dist.broadcast(uid, 0)
         return (rank, world, m * world, bytes(uid.cpu().tolist()))
 
@@ -717,7 +736,7 @@ def run_config(env, name, with_cpu):
     per_step_guess = max(st_solve["t_loop_s"] / max(st_solve["iterations"], 1), 1e-6)
     windows, cover = pick_windows(args.steps, int(res["iterations"]) + 1, per_step_guess)
     if dist is not None:   # every rank must run the same number of windows (barriers): rank 0's choice
-        wt = torch.tensor([windows], dtype=torch.int64, device=dev)
+        wt = torch.tensor([windows], dtype=torch.int64, device=env.coll_dev)
         dist.broadcast(wt, 0)
         windows = int(wt.item())
     times = []
@@ -729,7 +748,7 @@ def run_config(env, name, with_cpu):
         env.barrier()
         elapsed = time.time() - t0
         if dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=env.coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         times.append(elapsed)
@@ -829,7 +848,7 @@ def run_config(env, name, with_cpu):
     # solves it unsharded -- the sharded solution must land on that solve's
     unsharded = None
     if world > 1 and not sparse and args.projector == "default":
-        bsum = torch.tensor([float(np.asarray(b, np.float64).sum())], dtype=torch.float64, device=dev)
+        bsum = torch.tensor([float(np.asarray(b, np.float64).sum())], dtype=torch.float64, device=env.coll_dev)
         sums = [torch.zeros_like(bsum) for _ in range(world)]
         dist.all_gather(sums, bsum)
         if rank == 0 and float(m) * world * n * esize <= UNSHARDED_CHECK_MAX_BYTES:
@@ -952,6 +971,10 @@ def run_config(env, name, with_cpu):
         }
         if not sparse:
             line["gram_tflops"] = st_solve["gram_flops"] / max(st_solve["gram_ms"], 1e-9) / 1e9
+        if env.rehearsal:
+            line["config"]["rehearsal"] = ("POGS_AMD_BENCH_REHEARSAL=1: %d ranks on %d GPU(s), process group gloo, solver handles joined by "
+                                           "the test plug-in's shared-memory communicator -- a plumbing rehearsal, not a measurement"
+                                           % (world, torch.cuda.device_count()))
         if cycles is not None:
             line["handle_cycles"] = cycles
             line["config"]["handle_cycles_max_time_to_converge_s"] = cycles["max_time_to_converge_s"]
@@ -1052,7 +1075,7 @@ def summary_line(line):
     rf, cf = line["roofline"], line["config"]
     out = _pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                        "vs_baseline", "dtype", "data"))
-    out["config"] = _pick(cf, ("workload", "name", "rows_per_gpu", "cols", "projector", "parallelism", "rccl_nranks"))
+    out["config"] = _pick(cf, ("workload", "name", "rows_per_gpu", "cols", "projector", "parallelism", "rccl_nranks", "rehearsal"))
     out["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "bytes_per_launch",
                                  "avg_launch_ms", "launches", "peak_measured", "frac_of_peak_measured", "iteration_frac"))
     src = rf.get("traffic_source") or rf.get("traffic_live")

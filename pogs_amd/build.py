@@ -19,12 +19,25 @@ LIB = os.path.join(_HERE, "libpogs_amd.so")
 # linked) into the reference's `pogs/` directory it is picked up by the UNMODIFIED loader
 # (INTEGRATION.md section 1).
 ALIAS = os.path.join(_HERE, "libpogs_cpu.so")
+# The test-suite's communicators (ranks as threads / as processes on ONE GPU) are a transport plug-in of the
+# library (csrc/transport_plugin.h), built next to its source under tests/ -- test infrastructure, not product.
+PLUGIN_SRC = os.path.join(_HERE, "..", "tests", "transport", "test_transport.hip")
+PLUGIN_LIB = os.path.join(_HERE, "..", "tests", "transport", "libpogs_test_transport.so")
 SOURCES = ["abi.hip", "sparse.hip", "gemm.hip", "vec_kernels.hip", "dist.hip"]
 # dense_plan.hip is compiled once per arithmetic type and streaming shape (csrc/stream.h:
 # POGS_STREAM_PLANS) plus the windowed form -- one small code object per shape, see dense_plan.hip
 PLAN_SOURCE = "dense_plan.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# Floating-point contraction OFF everywhere but gemm.hip: a product is fused with a sum exactly where the source says
+# fma (csrc/stream.h: vdot / vfma / vscale_add, csrc/sell.h: the SpMV's accumulate) and nowhere else, so the roundings
+# of the iteration no longer follow instruction selection (round 5: an edit to a reduction changed which products of the
+# row dots were fused in OTHER kernels and moved a 33 x 40001 problem by 1e-4).  The scalar algebra around the dots --
+# prox, over-relaxation, residual sums -- then runs unfused, which is also what the reference's x86-64 build does.
+# gemm.hip keeps the default: its products are the matrix cores' (fixed by the hardware) and the scalar loops of the
+# diagonal-block Cholesky, where an unfused multiply-subtract would double the single-workgroup chain.
+NO_CONTRACT = "-ffp-contract=off"
+CONTRACT_DEFAULT_SOURCES = ("gemm.hip",)
 # development aid: extra -D flags for EVERY object (the experiment switches that sit in inline functions shared by
 # all translation units, e.g. POGS_C3_LEAN_BLOCKS; use a separate checkout: the objects are not tracked per flag set)
 FLAGS += os.environ.get("POGS_AMD_EXTRA_FLAGS", "").split()
@@ -83,7 +96,9 @@ def _deps_newer_than(obj):
 def _compile(job):
     src, objname, defs = job
     obj = os.path.join(OBJ, objname)
-    cmd = [_hipcc()] + FLAGS + defs + ["-MMD", "-MF", obj[:-2] + ".d", "-c", os.path.join(CSRC, src), "-o", obj]
+    # (an explicit -ffp-contract in POGS_AMD_EXTRA_FLAGS -- an A / B build -- takes precedence)
+    fp = [] if src in CONTRACT_DEFAULT_SOURCES or any(f.startswith("-ffp-contract") for f in FLAGS) else [NO_CONTRACT]
+    cmd = [_hipcc()] + FLAGS + fp + defs + ["-MMD", "-MF", obj[:-2] + ".d", "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s (%s):\n%s\n%s" % (src, objname, r.stdout, r.stderr))
@@ -101,8 +116,26 @@ def _alias():
         pass   # a file system without symlinks: the alias is a convenience, not a dependency
 
 
+def build_plugin(force=False, verbose=False):
+    """tests/transport/libpogs_test_transport.so (skipped when the tests directory is not there)."""
+    if not os.path.exists(PLUGIN_SRC):
+        return None
+    hdr = os.path.join(CSRC, "transport_plugin.h")
+    if not force and os.path.exists(PLUGIN_LIB) and \
+            os.path.getmtime(PLUGIN_LIB) >= max(os.path.getmtime(PLUGIN_SRC), os.path.getmtime(hdr)):
+        return PLUGIN_LIB
+    if verbose:
+        print("pogs_amd.build: compiling the test transport plug-in", file=sys.stderr)
+    cmd = [_hipcc()] + FLAGS + [NO_CONTRACT, "-shared", PLUGIN_SRC, "-o", PLUGIN_LIB, "-lrt"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for the test transport plug-in:\n%s\n%s" % (r.stdout, r.stderr))
+    return PLUGIN_LIB
+
+
 def build(force=False, verbose=False):
     """Compile (if stale) and return the path of libpogs_amd.so."""
+    build_plugin(force, verbose)
     dep = _newest_dep()
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= dep:
         _alias()

@@ -128,6 +128,16 @@ SolveParams make_params(double rho, double abs_tol, double rel_tol, unsigned max
   return p;
 }
 
+// The array entry points (the reference's four and PogsAmdSolve / PogsAmdBeginRun) take TWELVE arrays: a null one is a
+// caller's mistake there, not a broadcast field (that reading belongs to the *Fn entry points alone) -- without the
+// check the solve would run on the defaults (a = c = 1, b = d = e = 0, h = kZero) and return a plausible wrong answer.
+FnHost fn_arrays(const void *a, const void *b, const void *c, const void *d, const void *e, const int *h, const char *which) {
+  if (!(a && b && c && d && e && h))
+    throw Error(std::string("null coefficient array in the description of ") + which +
+                " (a, b, c, d, e, h must all be given; broadcast fields: PogsAmdSolveFn)");
+  return FnHost{a, b, c, d, e, h};
+}
+
 // One-shot dense solve: src/interface_c/pogs_c.cpp:9-55.
 template <typename T>
 int pogs_dense(enum ORD ord, size_t m, size_t n, const T *A, const T *f_a, const T *f_b, const T *f_c,
@@ -136,10 +146,10 @@ int pogs_dense(enum ORD ord, size_t m, size_t n, const T *A, const T *f_a, const
                unsigned max_iter, unsigned verbose, int adaptive_rho, int gap_stop, T *x, T *y, T *l, T *optval,
                unsigned *final_iter) {
   return guarded([&]() {
+    const FnHost f = fn_arrays(f_a, f_b, f_c, f_d, f_e, reinterpret_cast<const int *>(f_h), "f");
+    const FnHost g = fn_arrays(g_a, g_b, g_c, g_d, g_e, reinterpret_cast<const int *>(g_h), "g");
     std::unique_ptr<SolverBase> s(make_dense_solver(sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64, ord, m, n, A,
                                                     POGS_AMD_HOST, nullptr, nullptr));
-    FnHost f{f_a, f_b, f_c, f_d, f_e, reinterpret_cast<const int *>(f_h)};
-    FnHost g{g_a, g_b, g_c, g_d, g_e, reinterpret_cast<const int *>(g_h)};
     double ov = 0;
     const int st = s->solve(f, g, make_params(rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop),
                             x, y, l, nullptr, &ov, final_iter);
@@ -156,10 +166,10 @@ int pogs_sparse(enum ORD ord, size_t m, size_t n, size_t nnz, const T *data, con
                 T rho, T abs_tol, T rel_tol, unsigned max_iter, unsigned verbose, int adaptive_rho, int gap_stop,
                 T *x, T *y, T *l, T *optval, unsigned *final_iter) {
   return guarded([&]() {
+    const FnHost f = fn_arrays(f_a, f_b, f_c, f_d, f_e, reinterpret_cast<const int *>(f_h), "f");
+    const FnHost g = fn_arrays(g_a, g_b, g_c, g_d, g_e, reinterpret_cast<const int *>(g_h), "g");
     std::unique_ptr<SolverBase> s(make_sparse_solver(sizeof(T) == 4 ? POGS_AMD_F32 : POGS_AMD_F64, ord, m, n, nnz,
                                                      data, ptr, ind, POGS_AMD_HOST, nullptr, nullptr));
-    FnHost f{f_a, f_b, f_c, f_d, f_e, reinterpret_cast<const int *>(f_h)};
-    FnHost g{g_a, g_b, g_c, g_d, g_e, reinterpret_cast<const int *>(g_h)};
     double ov = 0;
     const int st = s->solve(f, g, make_params(rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop),
                             x, y, l, nullptr, &ov, final_iter);
@@ -302,8 +312,8 @@ int PogsAmdSolve(PogsAmdSolver *s, const void *f_a, const void *f_b, const void 
   return guarded([&]() {
     POGS_CHECK(s && s->impl, "null solver");
     DeviceGuard guard(s->impl->device());
-    FnHost f{f_a, f_b, f_c, f_d, f_e, f_h};
-    FnHost g{g_a, g_b, g_c, g_d, g_e, g_h};
+    const FnHost f = fn_arrays(f_a, f_b, f_c, f_d, f_e, f_h, "f");
+    const FnHost g = fn_arrays(g_a, g_b, g_c, g_d, g_e, g_h, "g");
     return s->impl->solve(f, g, make_params(rho, abs_tol, rel_tol, max_iter, verbose, adaptive_rho, gap_stop), x,
                           y, l, mu, optval, final_iter);
   }, s);
@@ -350,8 +360,8 @@ int PogsAmdBeginRun(PogsAmdSolver *s, const void *f_a, const void *f_b, const vo
   return guarded([&]() {
     POGS_CHECK(s && s->impl, "null solver");
     DeviceGuard guard(s->impl->device());
-    FnHost f{f_a, f_b, f_c, f_d, f_e, f_h};
-    FnHost g{g_a, g_b, g_c, g_d, g_e, g_h};
+    const FnHost f = fn_arrays(f_a, f_b, f_c, f_d, f_e, f_h, "f");
+    const FnHost g = fn_arrays(g_a, g_b, g_c, g_d, g_e, g_h, "g");
     s->impl->begin_run(f, g, make_params(rho, abs_tol, rel_tol, max_iter, 0, adaptive_rho, gap_stop));
     return 0;
   }, s);

@@ -98,7 +98,7 @@ struct SpCgInitOp {
     if (u) u[j] = dot;
     s[j] = v;
     p[j] = v;
-    acc[0] += static_cast<double>(v) * v;
+    dev::prod_acc(acc[0], v, v);
   }
 };
 
@@ -233,18 +233,18 @@ __global__ void __launch_bounds__(kCgfTpb) cgf_step_a_kernel(CgfStepA<T> a) {
     for (int i = t0; i < n_end; i += stride_n) {
       const T v = a.x[i] + alpha * a.p[i];
       a.x[i] = v;
-      acc[0] += static_cast<double>(v) * v;
+      dev::prod_acc(acc[0], v, v);
       const T un = a.u[i] + neg_alpha * a.t[i];
       a.u[i] = un;
       const T sv = un - sh * v;                  // cgls.h:281-286 with A^T r from the recurrence
       a.s[i] = sv;
-      acc_s[0] += static_cast<double>(sv) * sv;
+      dev::prod_acc(acc_s[0], sv, sv);
     }
   } else {
     for (int i = t0; i < n_end; i += stride_n) {
       const T v = a.x[i] + alpha * a.p[i];
       a.x[i] = v;
-      acc[0] += static_cast<double>(v) * v;
+      dev::prod_acc(acc[0], v, v);
     }
   }
   if (a.ynew) {
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(kCgfTpb) cgf_step_b_kernel(CgfStepB<T> a) {
   for (int i = blockIdx.x * kCgfTpb + threadIdx.x; i < a.n; i += stride) {
     const T v = a.s[i] + beta * a.p[i];
     a.p[i] = v;
-    acc[0] += static_cast<double>(v) * v;
+    dev::prod_acc(acc[0], v, v);
   }
   dev::block_sum<1, kCgfTpb>(acc, s_red);
   if (threadIdx.x == 0) a.rec_p[blockIdx.x] = acc[0];
@@ -346,8 +346,8 @@ __global__ void __launch_bounds__(kVecTpb) cgf_close_kernel(CgfClose<T> a) {
         const T zn = xc[u] + x0[u];   // the reference: x <- 1 * x0 + x (blas_axpy)
         a.x[i] = zn;
         const T d1 = xp[u] - zn, d2 = xh[u] - zn;
-        acc[0] += static_cast<double>(d1) * d1;
-        acc[1] += static_cast<double>(d2) * d2;
+        dev::prod_acc(acc[0], d1, d1);
+        dev::prod_acc(acc[1], d2, d2);
         a.xtemp[i] = x0[u] - zn;
       }
     }
@@ -366,8 +366,8 @@ __global__ void __launch_bounds__(kVecTpb) cgf_close_kernel(CgfClose<T> a) {
         const T zn = yn[u];
         a.ynew[i] = zn;
         const T d1 = yp[u] - zn, d2 = yh[u] - zn;
-        acc[0] += static_cast<double>(d1) * d1;
-        acc[1] += static_cast<double>(d2) * d2;
+        dev::prod_acc(acc[0], d1, d1);
+        dev::prod_acc(acc[1], d2, d2);
         a.ytemp[i] = yt[u] - zn;
       }
     }

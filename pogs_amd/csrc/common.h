@@ -372,4 +372,15 @@ inline void ensure_dynamic_smem(const void *fn, size_t want, SmemGrants &g) {
   while (cur < want && !slot.compare_exchange_weak(cur, want)) {}
 }
 
+// Fused multiply-adds are WRITTEN (every translation unit but gemm.hip is compiled with -ffp-contract=off,
+// pogs_amd/build.py): dev::fma_ where one rounding is meant, plain operators where two are.  sq_acc / prod_acc: the
+// fp64 scalar sums of the row and column functors, s += (double) x * y in one rounding (the form the contracting
+// compiler had given every one of them).
+namespace dev {
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename X, typename Y>
+__device__ __forceinline__ void prod_acc(double &s, X x, Y y) { s = __builtin_fma(static_cast<double>(x), static_cast<double>(y), s); }
+}  // namespace dev
+
 }  // namespace pogs_amd

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) scale_de_kernel(const T *src, T *dst, siz
         if (WRITE) {
           ap[c] = val * post;
         } else {
-          acc[0] += static_cast<double>(val) * val;
+          dev::prod_acc(acc[0], val, val);
           amax = fmax(amax, fabs(val));
         }
       }

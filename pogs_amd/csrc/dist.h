@@ -16,18 +16,11 @@
 // type must travel at the same point (sparse.hip: a CG step's A^T q and its |q|^2 records) groups
 // the two calls (group_begin / group_end) so that they are still one launch.
 //
-// Test transport (only with POGS_AMD_TEST_TRANSPORT set in the environment; otherwise such an id
-// is refused): a unique id that starts with "POGSLOCAL:" selects an in-process communicator
-// instead of RCCL -- the ranks are threads of one process, each with its own solver, on the same
-// GPU.  It exists so that the row-sharded decomposition of the engine itself can be verified on a
-// single GPU (RCCL refuses two ranks on one device); it is not a performance path.
-//   POGS_AMD_TEST_TRANSPORT=1     stream-ordered, like ncclAllReduce: every rank copies its buffer
-//       into a device slot on ITS stream and records an event; the threads meet (host barrier, no
-//       stream is waited for); every rank makes its stream wait for the peers' events and sums the
-//       slots in rank order with a kernel.  The host never waits for the device, so a kernel that
-//       reads the result too early, or overwrites an operand too soon, shows up as a wrong answer.
-//   POGS_AMD_TEST_TRANSPORT=host  round 1's form: buffers staged through the host and summed there
-//       (hipStreamSynchronize on both sides of the exchange).
+// Other transports: a unique id that starts with "POGS" (RCCL's ids are binary and never do) is served by the
+// plug-in named by POGS_AMD_TRANSPORT_PLUGIN (transport_plugin.h); without that variable such an id is refused.
+// The test-suite's communicators -- ranks as threads of one process, or as processes joined by shared memory,
+// on ONE GPU, which RCCL refuses -- are such a plug-in (tests/transport/test_transport.hip); none of that code
+// is in this library.
 #pragma once
 #include <exception>
 #include <hip/hip_runtime.h>
@@ -58,7 +51,7 @@ class DistComm {
   void allreduce(const double *in, double *out, size_t count, hipStream_t stream) const;
   // The all-reduces issued between group_begin() and group_end() are independent of each other and
   // travel as ONE RCCL launch (ncclGroupStart / ncclGroupEnd): the n-vector and the record array of a
-  // row-sharded CG step (sparse.hip).  The test transport runs them one after the other.
+  // row-sharded CG step (sparse.hip).  A plug-in transport runs them one after the other.
   void group_begin() const;
   void group_end() const;
   // RAII form: ncclGroupEnd is called on every way out of the scope.  When an exception unwinds
@@ -87,8 +80,8 @@ class DistComm {
   template <typename T>
   void allreduce3(T *buf, size_t count, double *s1, size_t n1, double *s2, size_t n2, hipStream_t stream);
   unsigned long long collectives() const { return ncoll_; }   // all-reduce calls issued so far
-  // Ranks of the communicator as RCCL itself reports them (ncclCommCount); world() for the test
-  // transport, 0 when there is no communicator.
+  // Ranks of the communicator as RCCL itself reports them (ncclCommCount); world() for a
+  // plug-in transport, 0 when there is no communicator.
   int comm_nranks() const;
   // A collective that a peer never joined leaves this rank's stream inside the all-reduce kernel for
   // ever.  abort() tears the communicator down (ncclCommAbort: the kernel returns, later calls on
@@ -105,7 +98,8 @@ class DistComm {
   void reduce_raw(const void *in, void *out, size_t count, int dtype, hipStream_t stream) const;
   int rank_ = 0, world_ = 1;
   void *comm_ = nullptr;
-  void *local_ = nullptr;   // std::shared_ptr<LocalGroup>* (test transport)
+  void *local_ = nullptr;   // handle of a plug-in transport (transport_plugin.h)
+  const void *plug_ = nullptr;   // its PogsAmdTransportApi
   double *pack_ = nullptr;  // fp64 staging of allreduce2 / allreduce3 (device)
   size_t pack_cap_ = 0;
   mutable unsigned long long ncoll_ = 0;

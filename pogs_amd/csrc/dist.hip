@@ -3,18 +3,13 @@
 
 #include <dlfcn.h>
 
-#include <chrono>
-#include <condition_variable>
 #include <cstdlib>
-#include <algorithm>
 #include <cstring>
-#include <map>
-#include <memory>
 #include <mutex>
 #include <string>
-#include <vector>
 
 #include "common.h"
+#include "transport_plugin.h"
 
 namespace pogs_amd {
 
@@ -75,156 +70,26 @@ void check(int r, const char *what) {
   }
 }
 
-// ---- in-process test transport (see dist.h) --------------------------------------------
-constexpr char kLocalTag[] = "POGSLOCAL:";
+// ---- transport plug-in (transport_plugin.h): ids that start with "POGS" are not RCCL's ----------------
+constexpr char kPluginTag[] = "POGS";
 
-struct LocalGroup {
-  int world = 0;
-  bool host_staged = false;   // POGS_AMD_TEST_TRANSPORT=host
-  std::mutex mu;
-  std::condition_variable cv;
-  int arrived = 0;
-  unsigned long long gen = 0;
-  std::vector<std::vector<unsigned char>> slots;   // host-staged form
-  // stream-ordered form: one device slot and two events per rank
-  std::vector<void *> dslot;
-  std::vector<size_t> dcap;
-  std::vector<hipEvent_t> ready, done;
-  std::vector<int> device;
-  std::vector<unsigned long long> calls;   // collectives each rank has taken part in
-
-  ~LocalGroup() {
-    for (void *p : dslot) if (p) (void)hipFree(p);
-    for (hipEvent_t e : ready) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
-  }
-
-  void barrier() {
-    std::unique_lock<std::mutex> lk(mu);
-    const unsigned long long g = gen;
-    if (++arrived == world) {
-      arrived = 0;
-      ++gen;
-      cv.notify_all();
-      return;
-    }
-    // (the same limit as the RCCL path's, Ctx::wait_publish: POGS_AMD_COLL_TIMEOUT_S, at most 120 s here)
-    const char *te = std::getenv("POGS_AMD_COLL_TIMEOUT_S");
-    const double lim = std::min(120.0, te && std::atof(te) > 0 ? std::atof(te) : 120.0);
-    if (!cv.wait_for(lk, std::chrono::duration<double>(lim), [&] { return gen != g; })) {
-      // leave the group consistent for the ranks that did arrive: this collective is void
-      --arrived;
-      throw Error("local communicator: a rank did not reach the collective within " + std::to_string(static_cast<int>(lim)) + " s");
-    }
-  }
-};
-
-std::shared_ptr<LocalGroup> local_group(const std::string &key, int world, bool host_staged) {
+const PogsAmdTransportApi *plugin_api() {
+  static const PogsAmdTransportApi *table = nullptr;
   static std::mutex mu;
-  static std::map<std::string, std::weak_ptr<LocalGroup>> groups;
   std::lock_guard<std::mutex> lk(mu);
-  std::shared_ptr<LocalGroup> g = groups[key].lock();
-  if (!g) {
-    g = std::make_shared<LocalGroup>();
-    g->world = world;
-    g->host_staged = host_staged;
-    g->slots.resize(world);
-    g->dslot.assign(world, nullptr);
-    g->dcap.assign(world, 0);
-    g->ready.assign(world, nullptr);
-    g->done.assign(world, nullptr);
-    g->device.assign(world, -1);
-    g->calls.assign(world, 0);
-    groups[key] = g;
-  }
-  POGS_CHECK(g->world == world, "local communicator: ranks disagree on the world size");
-  return g;
-}
-
-template <typename T>
-void local_allreduce_host(LocalGroup &g, int rank, const T *in, T *out, size_t count, hipStream_t stream) {
-  const size_t bytes = count * sizeof(T);
-  std::vector<unsigned char> &mine = g.slots[rank];
-  mine.resize(bytes);
-  POGS_HIP_CHECK(hipMemcpyAsync(mine.data(), in, bytes, hipMemcpyDeviceToHost, stream));
-  POGS_HIP_CHECK(hipStreamSynchronize(stream));
-  g.barrier();
-  std::vector<T> sum(count, static_cast<T>(0));
-  for (int r = 0; r < g.world; ++r) {   // rank order: every rank forms the identical sum
-    POGS_CHECK(g.slots[r].size() == bytes, "local communicator: ranks disagree on the element count");
-    const T *p = reinterpret_cast<const T *>(g.slots[r].data());
-    for (size_t i = 0; i < count; ++i) sum[i] += p[i];
-  }
-  g.barrier();   // nobody overwrites a slot that is still being read
-  POGS_HIP_CHECK(hipMemcpyAsync(out, sum.data(), bytes, hipMemcpyHostToDevice, stream));
-  POGS_HIP_CHECK(hipStreamSynchronize(stream));
-}
-
-// out[i] = slot_0[i] + slot_1[i] + ... in rank order (every rank forms the identical sum)
-constexpr int kLocalMaxWorld = 16;
-struct LocalSlots {
-  const void *p[kLocalMaxWorld];
-};
-template <typename T>
-__global__ void __launch_bounds__(256) local_sum_kernel(LocalSlots slots, int world, size_t count, T *out) {
-  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += static_cast<size_t>(gridDim.x) * 256) {
-    T v = static_cast<T>(0);
-    for (int r = 0; r < world; ++r) v += static_cast<const T *>(slots.p[r])[i];
-    out[i] = v;
-  }
-}
-
-// Stream-ordered exchange (dist.h): no call in here waits for a stream.  Per collective and rank:
-//   wait (on the stream) for the peers' `done` of the previous collective -- my slot may still be read;
-//   copy in -> own slot, record `ready`
-//   ---- host barrier: every `ready` has been RECORDED (not necessarily reached) ----
-//   wait (on the stream) for every peer's `ready`; sum kernel over the slots -> out; record `done`
-//   ---- host barrier: every `done` has been recorded ----
-template <typename T>
-void local_allreduce_stream(LocalGroup &g, int rank, const T *in, T *out, size_t count, hipStream_t stream) {
-  POGS_CHECK(g.world <= kLocalMaxWorld, "local communicator: at most 16 ranks");
-  const size_t bytes = count * sizeof(T);
-  int dev = 0;
-  POGS_HIP_CHECK(hipGetDevice(&dev));
-  if (!g.ready[rank]) {
-    POGS_HIP_CHECK(hipEventCreateWithFlags(&g.ready[rank], hipEventDisableTiming));
-    POGS_HIP_CHECK(hipEventCreateWithFlags(&g.done[rank], hipEventDisableTiming));
-    g.device[rank] = dev;
-  }
-  if (bytes > g.dcap[rank]) {
-    // the slot grows (the first collective of each size): drain the device first -- a peer's sum
-    // kernel of the previous collective may still read the old slot
-    POGS_HIP_CHECK(hipDeviceSynchronize());
-    if (g.dslot[rank]) POGS_HIP_CHECK(hipFree(g.dslot[rank]));
-    g.dslot[rank] = nullptr;
-    POGS_HIP_CHECK(hipMalloc(&g.dslot[rank], bytes));
-    g.dcap[rank] = bytes;
-  }
-  if (g.calls[rank] > 0) {
-    for (int r = 0; r < g.world; ++r)
-      if (r != rank) POGS_HIP_CHECK(hipStreamWaitEvent(stream, g.done[r], 0));
-  }
-  POGS_HIP_CHECK(hipMemcpyAsync(g.dslot[rank], in, bytes, hipMemcpyDeviceToDevice, stream));
-  POGS_HIP_CHECK(hipEventRecord(g.ready[rank], stream));
-  g.barrier();
-  LocalSlots slots;
-  for (int r = 0; r < g.world; ++r) {
-    POGS_CHECK(g.device[r] == dev, "local communicator (stream-ordered form): all ranks must use one device");
-    POGS_CHECK(g.dcap[r] >= bytes, "local communicator: ranks disagree on the element count");
-    slots.p[r] = g.dslot[r];
-    if (r != rank) POGS_HIP_CHECK(hipStreamWaitEvent(stream, g.ready[r], 0));
-  }
-  const unsigned grid = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(1024, (count + 255) / 256)));
-  hipLaunchKernelGGL(local_sum_kernel<T>, dim3(grid), dim3(256), 0, stream, slots, g.world, count, out);
-  POGS_HIP_CHECK(hipEventRecord(g.done[rank], stream));
-  ++g.calls[rank];
-  g.barrier();
-}
-
-template <typename T>
-void local_allreduce(LocalGroup &g, int rank, const T *in, T *out, size_t count, hipStream_t stream) {
-  if (g.host_staged) local_allreduce_host(g, rank, in, out, count, stream);
-  else local_allreduce_stream(g, rank, in, out, count, stream);
+  if (table) return table;
+  const char *path = std::getenv("POGS_AMD_TRANSPORT_PLUGIN");
+  POGS_CHECK(path && path[0], "a unique id that starts with \"POGS\" names a transport plug-in: set POGS_AMD_TRANSPORT_PLUGIN "
+                              "to its shared object (the test-suite's is tests/transport/libpogs_test_transport.so)");
+  void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!lib) throw Error(std::string("cannot load the transport plug-in: ") + dlerror());
+  auto entry = reinterpret_cast<PogsAmdTransportEntry>(dlsym(lib, "pogs_amd_transport"));
+  POGS_CHECK(entry != nullptr, "the transport plug-in lacks the symbol pogs_amd_transport");
+  const PogsAmdTransportApi *t = entry();
+  POGS_CHECK(t && t->abi == POGS_AMD_TRANSPORT_ABI && t->open && t->allreduce && t->close && t->last_error,
+             "the transport plug-in speaks another interface version");
+  table = t;
+  return table;
 }
 
 }  // namespace
@@ -259,7 +124,7 @@ DistComm::~DistComm() {
     // not destroyed: ncclCommDestroy would wait for the stuck kernel)
     try { if (!aborted_) api().CommDestroy(comm_); } catch (...) {}
   }
-  delete static_cast<std::shared_ptr<LocalGroup> *>(local_);
+  if (local_ && plug_) static_cast<const PogsAmdTransportApi *>(plug_)->close(local_);
   if (pack_) (void)hipFree(pack_);
 }
 
@@ -273,11 +138,11 @@ void DistComm::init(int rank, int world, const char *unique_id) {
   POGS_CHECK(world >= 1 && rank >= 0 && rank < world, "bad rank/world");
   rank_ = rank;
   world_ = world;
-  if (std::strncmp(unique_id, kLocalTag, sizeof(kLocalTag) - 1) == 0) {
-    const char *tt = std::getenv("POGS_AMD_TEST_TRANSPORT");
-    POGS_CHECK(tt && (tt[0] == '1' || tt[0] == 'h'), "the in-process test transport needs POGS_AMD_TEST_TRANSPORT=1");
-    const std::string key(unique_id, strnlen(unique_id, kUniqueIdBytes));
-    local_ = new std::shared_ptr<LocalGroup>(local_group(key, world, tt[0] == 'h'));
+  if (std::strncmp(unique_id, kPluginTag, sizeof(kPluginTag) - 1) == 0) {
+    const PogsAmdTransportApi *t = plugin_api();
+    local_ = t->open(unique_id, rank, world);
+    if (!local_) throw Error(std::string("transport plug-in: ") + t->last_error());
+    plug_ = t;
     return;
   }
   UniqueId id;
@@ -312,9 +177,9 @@ void DistComm::reduce_raw(const void *in, void *out, size_t count, int dtype, hi
   if (aborted_) throw Error("the RCCL communicator of this handle was aborted (a collective timed out or failed)");
   ++ncoll_;
   if (local_) {
-    LocalGroup &g = **static_cast<std::shared_ptr<LocalGroup> *>(local_);
-    if (dtype == kNcclFloat) local_allreduce(g, rank_, static_cast<const float *>(in), static_cast<float *>(out), count, stream);
-    else local_allreduce(g, rank_, static_cast<const double *>(in), static_cast<double *>(out), count, stream);
+    const PogsAmdTransportApi *t = static_cast<const PogsAmdTransportApi *>(plug_);
+    if (t->allreduce(local_, rank_, in, out, count, dtype == kNcclFloat ? 0 : 1, stream) != 0)
+      throw Error(std::string("transport plug-in: ") + t->last_error());
     return;
   }
   check(api().AllReduce(in, out, count, dtype, kNcclSum, comm_, stream), "ncclAllReduce");

@@ -31,11 +31,11 @@ __device__ __forceinline__ typename Vec16<T>::type colsum_group(const T *partial
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const V *>(partials + static_cast<size_t>(b + 8 * q) * n_pad + col);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) dev::vfma(sum, static_cast<T>(1), v[q]);
+    for (int q = 0; q < 8; ++q) dev::vadd(sum, v[q]);
   }
   for (; b < nparts; b += 8) {
     const V v = *reinterpret_cast<const V *>(partials + static_cast<size_t>(b) * n_pad + col);
-    dev::vfma(sum, static_cast<T>(1), v);
+    dev::vadd(sum, v);
   }
   return sum;
 }
@@ -83,27 +83,27 @@ __global__ void __launch_bounds__(256) pre_cols_kernel(PreColsArgs<T> a) {
           const V u1 = *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b) * a.n_pad + col);
           const V w0 = *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b + kPreColsGroups) * a.n_pad + col);
           const V w1 = *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b + kPreColsGroups) * a.n_pad + col);
-          dev::vfma(s0, static_cast<T>(1), u0);
-          dev::vfma(s1, static_cast<T>(1), u1);
-          dev::vfma(t0, static_cast<T>(1), w0);
-          dev::vfma(t1, static_cast<T>(1), w1);
+          dev::vadd(s0, u0);
+          dev::vadd(s1, u1);
+          dev::vadd(t0, w0);
+          dev::vadd(t1, w1);
         }
         if (b < a.nparts) {
-          dev::vfma(s0, static_cast<T>(1), *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col));
-          dev::vfma(s1, static_cast<T>(1), *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b) * a.n_pad + col));
+          dev::vadd(s0, *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col));
+          dev::vadd(s1, *reinterpret_cast<const V *>(a.part1 + static_cast<size_t>(b) * a.n_pad + col));
         }
       } else {   // the first set alone, in the same order
         for (; b + kPreColsGroups < a.nparts; b += 2 * kPreColsGroups) {
           const V u0 = *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col);
           const V w0 = *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b + kPreColsGroups) * a.n_pad + col);
-          dev::vfma(s0, static_cast<T>(1), u0);
-          dev::vfma(t0, static_cast<T>(1), w0);
+          dev::vadd(s0, u0);
+          dev::vadd(t0, w0);
         }
         if (b < a.nparts)
-          dev::vfma(s0, static_cast<T>(1), *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col));
+          dev::vadd(s0, *reinterpret_cast<const V *>(a.part0 + static_cast<size_t>(b) * a.n_pad + col));
       }
-      dev::vfma(s0, static_cast<T>(1), t0);
-      dev::vfma(s1, static_cast<T>(1), t1);
+      dev::vadd(s0, t0);
+      dev::vadd(s1, t1);
     }
     *reinterpret_cast<V *>(&s_v[0][g][cx * VEC]) = s0;
     *reinterpret_cast<V *>(&s_v[1][g][cx * VEC]) = s1;
@@ -207,8 +207,8 @@ __global__ void __launch_bounds__(256) pack_cols_kernel(const T *part0, const T 
     V tot0 = s_v[0][0][cx], tot1 = s_v[1][0][cx];
 #pragma unroll
     for (int q = 1; q < 8; ++q) {
-      dev::vfma(tot0, static_cast<T>(1), s_v[0][q][cx]);
-      dev::vfma(tot1, static_cast<T>(1), s_v[1][q][cx]);
+      dev::vadd(tot0, s_v[0][q][cx]);
+      dev::vadd(tot1, s_v[1][q][cx]);
     }
     T t0[VEC], t1[VEC];
     __builtin_memcpy(t0, &tot0, sizeof(V));

@@ -85,7 +85,7 @@ struct StoreNormRowOp {
   template <int N>
   __device__ __forceinline__ T row(int j, T dot, double (&s)[N]) const {
     out[j] = dot;
-    s[0] += static_cast<double>(dot) * dot;
+    dev::prod_acc(s[0], dot, dot);
     return dot;
   }
   __device__ __forceinline__ T u(int) const { return 0; }
@@ -102,7 +102,7 @@ struct ExactTRowOp {
   template <int N>
   __device__ __forceinline__ T row(int j, T dot, double (&s)[N]) const {
     const T v = dot + x12[j] + zt_scale * xt[j] - xprev[j];
-    s[0] += static_cast<double>(v) * v;
+    dev::prod_acc(s[0], v, v);
     return x12[j];
   }
   __device__ __forceinline__ T u(int) const { return 0; }
@@ -116,7 +116,7 @@ struct ExactTColOp {   // r_i = (A x12)_i - y12_i
   __device__ __forceinline__ void col(int i, T total, double (&s)[N]) const {
     if (i < m) {
       const T r = total - y12[i];
-      s[0] += static_cast<double>(r) * r;
+      dev::prod_acc(s[0], r, r);
     }
   }
 };
@@ -154,7 +154,7 @@ struct PowerRowOp {
   static constexpr int NS = 1;
   template <int N>
   __device__ __forceinline__ T row(int, T dot, double (&s)[N]) const {
-    s[0] += static_cast<double>(dot) * dot;
+    dev::prod_acc(s[0], dot, dot);
     return dot;
   }
   __device__ __forceinline__ T u(int) const { return 0; }
@@ -174,8 +174,8 @@ struct ProjTailOp {
   __device__ __forceinline__ T row(int i, T dot, double (&s)[N]) const {
     znew[i] = dot;
     const T a = zprev[i] - dot, b = z12[i] - dot;
-    s[0] += static_cast<double>(a) * a;
-    s[1] += static_cast<double>(b) * b;
+    dev::prod_acc(s[0], a, a);
+    dev::prod_acc(s[1], b, b);
     ztemp[i] -= dot;
     return dot;
   }
@@ -205,8 +205,8 @@ struct ProjTailSumColOp {
     if (j >= n) return;
     znew[j] = total;
     const T a = zprev[j] - total, b = z12[j] - total;
-    s[0] += static_cast<double>(a) * a;
-    s[1] += static_cast<double>(b) * b;
+    dev::prod_acc(s[0], a, a);
+    dev::prod_acc(s[1], b, b);
     ztemp[j] -= total;
   }
 };
@@ -222,7 +222,7 @@ struct ExactRowOp {
   template <int N>
   __device__ __forceinline__ T row(int i, T dot, double (&s)[N]) const {
     const T r = dot - y12[i];
-    s[0] += static_cast<double>(r) * r;
+    dev::prod_acc(s[0], r, r);
     return y12[i] + zt_scale * yt[i] - yprev[i];
   }
   __device__ __forceinline__ T u(int) const { return 0; }
@@ -259,8 +259,8 @@ struct ProjTailAddOp {
     tout[i] = dot;
     znew[i] = zn;
     const T a = zprev[i] - zn, b = z12[i] - zn;
-    s[0] += static_cast<double>(a) * a;
-    s[1] += static_cast<double>(b) * b;
+    dev::prod_acc(s[0], a, a);
+    dev::prod_acc(s[1], b, b);
     ztemp[i] -= zn;
     return dot;
   }
@@ -283,8 +283,8 @@ struct ProjTailAddColOp {
     tout[j] = total;
     znew[j] = zn;
     const T a = zprev[j] - zn, b = z12[j] - zn;
-    s[0] += static_cast<double>(a) * a;
-    s[1] += static_cast<double>(b) * b;
+    dev::prod_acc(s[0], a, a);
+    dev::prod_acc(s[1], b, b);
     ztemp[j] -= zn;
   }
 };
@@ -319,7 +319,7 @@ struct CgQRowOp {
   template <int N>
   __device__ __forceinline__ T row(int i, T dot, double (&s)[N]) const {
     q[i] = dot;
-    s[0] += static_cast<double>(dot) * dot;
+    dev::prod_acc(s[0], dot, dot);
     return dot;
   }
   __device__ __forceinline__ T u(int) const { return 0; }
@@ -433,11 +433,11 @@ struct FusedIterOp {
     const T h0 = p.y12;
     ynew[i] = yn;
     const T a = p.ycur - yn, b = h0 - yn;
-    s[0] += static_cast<double>(a) * a;
-    s[1] += static_cast<double>(b) * b;
+    dev::prod_acc(s[0], a, a);
+    dev::prod_acc(s[1], b, b);
     if constexpr (ND > 1) {   // (ND = 1: the pass without the exact residuals, dense_solver.h: lean iterations)
       const T r = XSIDE ? dot[1] + h0 + c_old * p.zt - p.ycur : dot[1] - h0;
-      s[2] += static_cast<double>(r) * r;
+      dev::prod_acc(s[2], r, r);
     }
     const T ztn = p.ytemp - yn;
     ytemp[i] = ztn;
@@ -456,9 +456,9 @@ struct FusedIterOp {
     y12s[i] = h;
     const T yh = zts + alpha * h + (static_cast<T>(1) - alpha) * yn;
     ytemps[i] = yh;
-    s[3] += static_cast<double>(w) * h;
-    s[4] += static_cast<double>(w) * w;
-    s[5] += static_cast<double>(h) * h;
+    dev::prod_acc(s[3], w, h);
+    dev::prod_acc(s[4], w, w);
+    dev::prod_acc(s[5], h, h);
     u[0] = yh;
     if constexpr (NA > 1) u[1] = XSIDE ? h : h + zts - yn;
   }
@@ -521,7 +521,7 @@ struct PowerColOp {
   __device__ __forceinline__ void col(int j, T total, double (&s)[N]) const {
     const T v = (j < n) ? total : static_cast<T>(0);
     x[j] = v;
-    s[0] += static_cast<double>(v) * v;
+    dev::prod_acc(s[0], v, v);
   }
 };
 
@@ -536,7 +536,7 @@ struct ExactColOp {
   __device__ __forceinline__ void col(int j, T total, double (&s)[N]) const {
     if (j < n) {
       const T v = total + x12[j] + zt_scale * xt[j] - xprev[j];
-      s[0] += static_cast<double>(v) * v;
+      dev::prod_acc(s[0], v, v);
     }
   }
 };
@@ -556,8 +556,8 @@ struct ProjTailColOp {
       const T zn = ztemp[j] - total;
       znew[j] = zn;
       const T a = zprev[j] - zn, b = z12[j] - zn;
-      s[0] += static_cast<double>(a) * a;
-      s[1] += static_cast<double>(b) * b;
+      dev::prod_acc(s[0], a, a);
+      dev::prod_acc(s[1], b, b);
       ztemp[j] -= zn;
     }
   }
@@ -577,8 +577,8 @@ struct SymColOp {
       const T sc = x_nrm2 ? static_cast<T>(1.0 / sqrt(*x_nrm2)) : static_cast<T>(1);
       const T v = total + lowdot[j];
       xnext[j] = v;
-      s[0] += static_cast<double>(v) * v;
-      s[1] += static_cast<double>(x[j] * sc) * v;
+      dev::prod_acc(s[0], v, v);
+      dev::prod_acc(s[1], x[j] * sc, v);
     } else {
       xnext[j] = 0;
     }
@@ -598,7 +598,7 @@ struct CgSColOp {
     if (j < n) {
       const T v = total - shift * x[j];
       sout[j] = v;
-      s[0] += static_cast<double>(v) * v;
+      dev::prod_acc(s[0], v, v);
     } else {
       sout[j] = 0;
     }

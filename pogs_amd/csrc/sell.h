@@ -72,6 +72,8 @@ constexpr int kSellUB = 4;              // elements per lane and batch (a tile's
 #endif
 constexpr int kSellNB = POGS_SELL_NB;   // batches in flight per wavefront (3 x 16- / 8- / 4-byte loads each)
 constexpr int kSellLmax = 32;           // sort classes: row lengths 1..32 each, longer rows together
+__device__ __forceinline__ float sell_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double sell_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <typename T> struct SellCfg;
 #ifndef POGS_SELL_BW_F32   // (compile-time overrides: tile-shape experiments through scripts/build_variant.py, scripts/spmv_probe.sh)
 #define POGS_SELL_BW_F32 18432
@@ -207,7 +209,7 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
       const T v = B.v[j];
-      acc += (SQ ? v * v : v) * xg[j];
+      acc = sell_fma(SQ ? v * v : v, xg[j], acc);   // fused, written out: this unit is compiled with -ffp-contract=off
       if constexpr (TWO) {
         en[j] = (B.c[j] & kSellEndBit) != 0;
         row[j] = static_cast<unsigned short>(seen ? B.rr >> 16 : B.rr & 0xFFFFu);

@@ -79,7 +79,7 @@ struct SpAxpbyNormOp {  // y[i] = alpha * dot + beta * yin[i]; s0 += y[i]^2
     T v = alpha * dot;
     if (beta != static_cast<T>(0)) v += beta * yin[i];
     y[i] = v;
-    s[0] += static_cast<double>(v) * v;
+    dev::prod_acc(s[0], v, v);
   }
   // the same in two steps (sell.h: spmv_sell_fin_kernel requests the operands of several rows
   // before it uses any)
@@ -90,7 +90,7 @@ struct SpAxpbyNormOp {  // y[i] = alpha * dot + beta * yin[i]; s0 += y[i]^2
     T v = alpha * dot;
     if (beta != static_cast<T>(0)) v += beta * in.yin;
     y[i] = v;
-    s[0] += static_cast<double>(v) * v;
+    dev::prod_acc(s[0], v, v);
   }
 };
 
@@ -126,8 +126,8 @@ struct SpTailOp {  // ProjTailOp for the y half: see ops.h
   __device__ __forceinline__ void row(int i, T dot, double (&s)[N]) const {
     znew[i] = dot;
     const T a = zprev[i] - dot, b = z12[i] - dot;
-    s[0] += static_cast<double>(a) * a;
-    s[1] += static_cast<double>(b) * b;
+    dev::prod_acc(s[0], a, a);
+    dev::prod_acc(s[1], b, b);
     ztemp[i] -= dot;
   }
   struct In { T zprev, z12, ztemp; };
@@ -136,8 +136,8 @@ struct SpTailOp {  // ProjTailOp for the y half: see ops.h
   __device__ __forceinline__ void apply(int i, T dot, const In &in, double (&s)[N]) const {
     znew[i] = dot;
     const T a = in.zprev - dot, b = in.z12 - dot;
-    s[0] += static_cast<double>(a) * a;
-    s[1] += static_cast<double>(b) * b;
+    dev::prod_acc(s[0], a, a);
+    dev::prod_acc(s[1], b, b);
     ztemp[i] = in.ztemp - dot;
   }
 };
@@ -149,7 +149,7 @@ struct SpExactROp {  // r_i = (A x12)_i - y12_i (pogs.cpp:353-364)
   template <int N>
   __device__ __forceinline__ void row(int i, T dot, double (&s)[N]) const {
     const T r = dot - y12[i];
-    s[0] += static_cast<double>(r) * r;
+    dev::prod_acc(s[0], r, r);
   }
 };
 
@@ -161,7 +161,7 @@ struct SpExactSOp {  // s_j = (A^T u)_j + x12_j + c xt_j - xprev_j (pogs.cpp:366
   template <int N>
   __device__ __forceinline__ void row(int j, T dot, double (&s)[N]) const {
     const T v = dot + x12[j] + zt_scale * xt[j] - xprev[j];
-    s[0] += static_cast<double>(v) * v;
+    dev::prod_acc(s[0], v, v);
   }
 };
 
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(kSpTpb) spmv_kernel(Csr<T> A, const T *__restr
       for (int k = t; k < cnt; k += kSpTpb) {
         T v = A.val[p0 + k];
         if (SQ) v *= v;
-        s += v * (x[A.ind[p0 + k]] * xs);
+        s = sell_fma(v, x[A.ind[p0 + k]] * xs, s);
       }
       s = dev::wave_sum(s);
       if (lane == 0) s_long[wave] = s;
@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(256) scale_csr_kernel(T *val, const int *ind, 
     for (int k = ptr[r] + lane; k < ptr[r + 1]; k += 64) {
       const T v = val[k] * (dr * ecol[ind[k]]);
       val[k] = v;
-      acc[0] += static_cast<double>(v) * v;
+      dev::prod_acc(acc[0], v, v);
     }
   }
   dev::block_sum<1, 256>(acc, s_red);
@@ -837,25 +837,25 @@ class SparseSolver final : public SolverBase {
     const long long ntiles = static_cast<long long>(nrr) * ncb;
     const long long nq = ntiles * rr_rows;
     if (ntiles >= (1LL << 30) || nq >= (1LL << 31)) return;
-    {
-      // The plan keeps 6 bytes per (row, column block) pair (count, stream offset; 8 are budgeted below, as when the fill kept a cursor too) --
-      // on a matrix with many column blocks and few non-zeros per row that outweighs the matrix
-      // itself (5e6 x 5e6: 272 blocks x 5e6 rows x 8 B = 10 GB).  Beyond 4x the CSR bytes, or half of
-      // what the device has free, the plain CSR kernel stays (the same exit as a padding blow-up).
-      size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-      const double tmp_bytes = 8.0 * static_cast<double>(nq);
-      const double csr_bytes = static_cast<double>(M.nnz) * (sizeof(T) + 4.0);
-      if (tmp_bytes > 4.0 * csr_bytes + 64e6 || (free_b && tmp_bytes > 0.5 * static_cast<double>(free_b))) return;
-    }
-    M.rr_rows = rr_rows; M.nrr = nrr; M.ncb = ncb; M.ncg = ncg;
-    const SellDims D = M.sdims();
     // storage format: the planner lays the tile out both ways and the smaller matrix is kept (7 bytes per stored
     // fp32 element with two id slots per batch, 8 with a tag per element -- but the first needs padding when most
     // rows of a tile hold a single element).  POGS_AMD_SELL_FORMAT=tags / two pins it (tests, A/B measurements).
     static_assert(SellCfg<T>::BW <= 32768, "bit 15 of a local column is the row-end flag of the two-slot format");
     int want_two = -1;
     if (const char *f = std::getenv("POGS_AMD_SELL_FORMAT")) want_two = std::strcmp(f, "two") == 0 ? 1 : (std::strcmp(f, "tags") == 0 ? 0 : -1);
+    {
+      // The plan keeps 6 bytes per (row, column block) pair (count, stream offset) and 4 more (the second layout's
+      // offsets) unless the tag format is pinned -- on a matrix with many column blocks and few non-zeros per row
+      // that outweighs the matrix itself (5e6 x 5e6: 272 blocks x 5e6 rows x 10 B = 13.6 GB).  Beyond 4x the CSR
+      // bytes, or half of what the device has free, the plain CSR kernel stays (the same exit as a padding blow-up).
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+      const double tmp_bytes = (want_two != 0 ? 10.0 : 6.0) * static_cast<double>(nq);
+      const double csr_bytes = static_cast<double>(M.nnz) * (sizeof(T) + 4.0);
+      if (tmp_bytes > 4.0 * csr_bytes + 64e6 || (free_b && tmp_bytes > 0.5 * static_cast<double>(free_b))) return;
+    }
+    M.rr_rows = rr_rows; M.nrr = nrr; M.ncb = ncb; M.ncg = ncg;
+    const SellDims D = M.sdims();
     DevBuf<unsigned> soff2;
     M.scnt.alloc(nq); M.ssoff.alloc(nq);
     if (want_two != 0) soff2.alloc(nq);
@@ -894,7 +894,9 @@ class SparseSolver final : public SolverBase {
         M.tile_unit = std::move(tile_unit2);
       }
     }
-    herr &= ~8;
+    // each layout has its own range check (bit 4: the tag layout's 23-bit stream offsets, bit 8: the two-slot
+    // layout's 22-bit ones): only the chosen layout's decides whether the tiled copy is usable
+    herr &= M.two ? ~4 : ~8;
     if (std::getenv("POGS_AMD_TRACE"))
       std::fprintf(stderr, "[pogs_amd trace] tiled copy %d x %d: %s, %.3f stored elements per non-zero\n", M.nrows, M.ncols,
                    M.two ? "two id slots per batch" : "a row tag per element",

@@ -177,27 +177,40 @@ inline StreamPlan make_stream_plan(int n_pad, int num_cu) {
 
 namespace dev {
 
+// The roundings of the row dots and column sums are WRITTEN OUT (round 6): this translation unit is compiled with
+// -ffp-contract=off (pogs_amd/build.py), so a product is fused with a sum exactly where an fma() says so and nowhere
+// else -- which products of a dot get fused no longer follows instruction selection (round 5: an edit to the wavefront
+// reduction moved a 33 x 40001 problem by 1e-4 through the dots of OTHER kernels).  One form for every kernel:
+//   vdot   a.x b.x  rounded, then the y, z, w products fused onto it in that order (what -ffp-contract=fast made of the
+//          first dot of the one-pass kernel, the one on the trajectory; its second dot used to run unfused);
+//   vfma   acc + u a  fused per element;   vscale_add  a s + b  fused per element;   vadd  plain adds.
 __device__ __forceinline__ float vdot(const float4 &a, const float4 &b) {
-  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  return fma_(a.w, b.w, fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)));
 }
 __device__ __forceinline__ double vdot(const double2 &a, const double2 &b) {
-  return a.x * b.x + a.y * b.y;
+  return fma_(a.y, b.y, a.x * b.x);
 }
 __device__ __forceinline__ void vfma(float4 &acc, float u, const float4 &a) {
-  acc.x += u * a.x; acc.y += u * a.y; acc.z += u * a.z; acc.w += u * a.w;
+  acc.x = fma_(u, a.x, acc.x); acc.y = fma_(u, a.y, acc.y); acc.z = fma_(u, a.z, acc.z); acc.w = fma_(u, a.w, acc.w);
 }
 __device__ __forceinline__ void vfma(double2 &acc, double u, const double2 &a) {
-  acc.x += u * a.x; acc.y += u * a.y;
+  acc.x = fma_(u, a.x, acc.x); acc.y = fma_(u, a.y, acc.y);
+}
+__device__ __forceinline__ void vadd(float4 &acc, const float4 &a) {
+  acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+}
+__device__ __forceinline__ void vadd(double2 &acc, const double2 &a) {
+  acc.x += a.x; acc.y += a.y;
 }
 __device__ __forceinline__ float4 vsq(const float4 &a) {
   return make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
 }
 __device__ __forceinline__ double2 vsq(const double2 &a) { return make_double2(a.x * a.x, a.y * a.y); }
 __device__ __forceinline__ float4 vscale_add(const float4 &a, float s, const float4 &b) {
-  return make_float4(a.x * s + b.x, a.y * s + b.y, a.z * s + b.z, a.w * s + b.w);
+  return make_float4(fma_(a.x, s, b.x), fma_(a.y, s, b.y), fma_(a.z, s, b.z), fma_(a.w, s, b.w));
 }
 __device__ __forceinline__ double2 vscale_add(const double2 &a, double s, const double2 &b) {
-  return make_double2(a.x * s + b.x, a.y * s + b.y);
+  return make_double2(fma_(a.x, s, b.x), fma_(a.y, s, b.y));
 }
 template <typename V> __device__ __forceinline__ V vzero();
 template <> __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -768,6 +781,144 @@ __global__ void __launch_bounds__(TPB, (ND > 0 ? stream2_waves_per_simd(TPB, NV,
   }
 }
 
+// ---------------------------------------------------------------------------
+// stream_rows2_db_kernel: the one-pass iteration kernel with ONE row per step and the NEXT row in flight.
+// At 256 x 5 (rows of <= 1280 vectors: C3) stream_rows2_kernel takes two rows per step and holds them through
+// dot -> barrier -> row functor (one lane per row) -> barrier -> column sums before it asks for the next two:
+// every workgroup's loads stop for the length of that chain, and at this row length nothing else on the CU
+// covers it (the pass ran at 0.77 of the data-sheet peak where Sinkhorn-Knopp's pass over the same matrix,
+// the same skeleton with a three-instruction functor, reaches 0.86).  Here the register tile is the same size
+// -- two rows -- but they are consecutive STEPS: row k + 1 (and its functor operands) is requested before row
+// k is reduced, so the chain of row k runs under the load of row k + 1.  Same arithmetic per row, same
+// round-robin dealing of rows to workgroups (row = blockIdx.x + k gridDim.x): the column partials of a workgroup
+// add the same rows in the same order as a two-row step's did only when the grid is the same, so results are
+// compared through the usual tolerances, not bit for bit (the second stage's partial count changes with R).
+// ---------------------------------------------------------------------------
+#ifndef POGS_STREAM2_DB   // 1: use it where stream2_db_c says (experiment switch until measured)
+#define POGS_STREAM2_DB 0
+#endif
+constexpr bool stream2_db_c(int nd, int nv) { return POGS_STREAM2_DB != 0 && nd > 0 && nv == 5; }
+
+template <typename T, int TPB, int NV, int ND, int NA, typename Op>
+__global__ void __launch_bounds__(TPB, stream2_waves_per_simd(TPB, NV, ND, NA)) stream_rows2_db_kernel(StreamArgs2<T> a, Op op) {
+  using V = typename Vec16<T>::type;
+  using Pre = typename Op::Pre;
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int NW = TPB / 64;
+  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+  static_assert(ND > 0, "the column-sum-only form has no chain to hide");
+  __shared__ T s_part[2 * ND * NW];
+  __shared__ T s_u[2 * NA];
+  __shared__ double s_red[NS * NW];
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  T *s_x1 = reinterpret_cast<T *>(s_dyn);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+  V xv[NV];
+  V acc[NA][NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int col = (v * TPB + t) * VEC;
+    xv[v] = (col < a.n_pad) ? *reinterpret_cast<const V *>(a.xin0 + col) : dev::vzero<V>();
+    if (ND > 1 && col < a.n_pad) *reinterpret_cast<V *>(s_x1 + col) = *reinterpret_cast<const V *>(a.xin1 + col);
+  }
+  if (ND > 1) __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NA; ++q)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[q][v] = dev::vzero<V>();
+  double sacc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
+
+  int row = blockIdx.x;
+  V cur[NV];
+  Pre pre_cur;
+  if (t == 0 && row < a.m) pre_cur = op.prefetch(row);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int col = (v * TPB + t) * VEC;
+    cur[v] = (col < a.n_pad && row < a.m) ? stream_load<V>(a.A + static_cast<size_t>(row) * a.lda + col) : dev::vzero<V>();
+  }
+  int slot = 0;
+  for (; row < a.m; row += gridDim.x, slot ^= 1) {
+    // the next row of this workgroup and its functor's operands: requested first (the functor's operands before
+    // the tile, so that waiting for them next step does not wait for anything younger)
+    const int nrow = row + gridDim.x;
+    Pre pre_nxt;
+    if (t == 0 && nrow < a.m) pre_nxt = op.prefetch(nrow);
+    V nxt[NV];
+    {
+      const T *rp = a.A + static_cast<size_t>(nrow) * a.lda;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int col = (v * TPB + t) * VEC;
+        nxt[v] = (col < a.n_pad && nrow < a.m) ? stream_load<V>(rp + col) : dev::vzero<V>();
+      }
+    }
+    T s0 = 0, s1 = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      s0 += dev::vdot(cur[v], xv[v]);
+      if (ND > 1) {
+        const int col = (v * TPB + t) * VEC;
+        if (col < a.n_pad) s1 += dev::vdot(cur[v], *reinterpret_cast<const V *>(s_x1 + col));
+      }
+    }
+    s0 = dev::wave_sum(s0);
+    if (ND > 1) s1 = dev::wave_sum(s1);
+    if (lane == 0) {
+      s_part[(slot * ND + 0) * NW + wave] = s0;
+      if (ND > 1) s_part[(slot * ND + 1) * NW + wave] = s1;
+    }
+    __syncthreads();
+    if (t == 0) {
+      T uu[NA];
+      T dots[ND];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        T s = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += s_part[(slot * ND + d) * NW + w];
+        dots[d] = s;
+      }
+      op.row(row, pre_cur, dots, sacc, uu);
+#pragma unroll
+      for (int q = 0; q < NA; ++q) s_u[slot * NA + q] = uu[q];
+    }
+    __syncthreads();
+    {
+      T uu[NA];
+#pragma unroll
+      for (int q = 0; q < NA; ++q) uu[q] = s_u[slot * NA + q];
+#pragma unroll
+      for (int q = 0; q < NA; ++q)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dev::vfma(acc[q][v], uu[q], cur[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) cur[v] = nxt[v];
+    pre_cur = pre_nxt;
+  }
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    T *out = (q == 0 ? a.col_partials0 : a.col_partials1) + static_cast<size_t>(blockIdx.x) * a.n_pad;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * TPB + t) * VEC;
+      if (col < a.n_pad) *reinterpret_cast<V *>(out + col) = acc[q][v];
+    }
+  }
+  if (Op::NS > 0) {
+    __syncthreads();
+    dev::block_sum<NS, TPB>(sacc, s_red);
+    if (t == 0) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) a.scalar_partials[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
+    }
+  }
+}
+
 // Whether the two-dot / two-accumulator kernel fits the register file for this plan
 // (row tile 4*R*NV + 2 x vectors 8*NV + 2 accumulators 8*NV VGPRs, R = 1).
 inline bool stream2_supported(const StreamPlan &p) {
@@ -781,7 +932,7 @@ inline bool stream2_supported(const StreamPlan &p) {
 // (one dot product and one accumulator -- the pass without the exact residuals -- leave room for a
 // second row at 8 .. 10 vectors per thread: 4*NV*(R + 1 + 1) + ~70)
 constexpr int stream2_rows_c(int nd, int nv, int na = 2) {
-  return nd > 0 ? ((nd == 1 && na == 1 && nv > 8) ? 2 : (nv <= 2 ? 8 : nv <= 4 ? 4 : nv == 5 ? 2 : nv <= 6 ? 3 : nv <= 8 ? 2 : 1))
+  return stream2_db_c(nd, nv) ? 1 : nd > 0 ? ((nd == 1 && na == 1 && nv > 8) ? 2 : (nv <= 2 ? 8 : nv <= 4 ? 4 : nv == 5 ? 2 : nv <= 6 ? 3 : nv <= 8 ? 2 : 1))
                 : (nv <= 4 ? 8 : nv <= 8 ? 4 : 2);
 }
 template <int ND, int NA = 2>
@@ -804,6 +955,12 @@ void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, 
   if (p.tpb == TPB_ && p.nv == NV_) {                                                           \
     constexpr int R_ = stream2_rows_c(ND, NV_, NA);                                             \
     const size_t lds = (ND > 1) ? static_cast<size_t>(a.n_pad) * sizeof(T) : 0;                 \
+    if constexpr (stream2_db_c(ND, NV_)) {                                                      \
+      static SmemGrants grants_db;                                                              \
+      ensure_dynamic_smem(reinterpret_cast<const void *>(&stream_rows2_db_kernel<T, TPB_, NV_, ND, NA, Op>), lds, grants_db); \
+      hipLaunchKernelGGL((stream_rows2_db_kernel<T, TPB_, NV_, ND, NA, Op>), dim3(grid), dim3(TPB_), lds, s, a, op); \
+      return;                                                                                   \
+    }                                                                                           \
     static SmemGrants grants;   /* per device; concurrent solvers share it */                   \
     ensure_dynamic_smem(reinterpret_cast<const void *>(&stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>), lds, grants); \
     hipLaunchKernelGGL((stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>), dim3(grid),         \
@@ -841,11 +998,11 @@ __global__ void __launch_bounds__(256) reduce_cols_kernel(const T *partials, int
       for (int q = 0; q < 8; ++q)
         v[q] = *reinterpret_cast<const V *>(partials + static_cast<size_t>(b + 8 * q) * n_pad + col);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) dev::vfma(sum, static_cast<T>(1), v[q]);
+      for (int q = 0; q < 8; ++q) dev::vadd(sum, v[q]);
     }
     for (; b < nparts; b += 8) {
       const V v = *reinterpret_cast<const V *>(partials + static_cast<size_t>(b) * n_pad + col);
-      dev::vfma(sum, static_cast<T>(1), v);
+      dev::vadd(sum, v);
     }
   }
   s_v[g][cx] = sum;
@@ -856,7 +1013,7 @@ __global__ void __launch_bounds__(256) reduce_cols_kernel(const T *partials, int
   if (g == 0 && col < n_pad) {
     V tot = s_v[0][cx];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) dev::vfma(tot, static_cast<T>(1), s_v[q][cx]);
+    for (int q = 1; q < 8; ++q) dev::vadd(tot, s_v[q][cx]);
     const T *tp = reinterpret_cast<const T *>(&tot);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) op.col(col + i, tp[i], sacc);

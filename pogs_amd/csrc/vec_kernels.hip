@@ -73,9 +73,9 @@ __global__ void __launch_bounds__(kVecTpb) admm_pre_kernel(AdmmPreArgs<T> a) {
       const T zt_new = zs + a.alpha * h + (static_cast<T>(1) - a.alpha) * prev[u];   // :276-278
       ztemp[i] = zt_new;
       if (aux) aux[i] = is_x ? prev[u] - zt_new : zt_new - prev[u];
-      acc[0] += static_cast<double>(w) * h;                         // :268
-      acc[1] += static_cast<double>(w) * w;
-      acc[2] += static_cast<double>(h) * h;
+      dev::prod_acc(acc[0], w, h);                         // :268
+      dev::prod_acc(acc[1], w, w);
+      dev::prod_acc(acc[2], h, h);
     }
   }
   dev::block_sum<3, kVecTpb>(acc, s_red);

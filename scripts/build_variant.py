@@ -17,6 +17,8 @@ out_dir = os.path.join(ROOT, "pogs_amd", "variants")
 os.makedirs(out_dir, exist_ok=True)
 obj = os.path.join(out_dir, "%s_%s.o" % (src.replace(".hip", ""), tag))
 flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+if src != "gemm.hip" and not any(d.startswith("-ffp-contract") for d in defs):
+    flags.append("-ffp-contract=off")   # as pogs_amd/build.py
 subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + defs + ["-c", os.path.join(CSRC, src), "-o", obj])
 objs = [os.path.join(OBJ, f) for f in sorted(os.listdir(OBJ)) if f.endswith(".o") and f != replace] + [obj]
 lib = os.path.join(out_dir, "libpogs_amd_%s.so" % tag)

@@ -1,0 +1,215 @@
+// Bisection between the library's two row-streaming skeletons at C3's shape (200000 x 5000 fp32, 256 threads x 5
+// vectors): Sinkhorn-Knopp's pass (stream_rows_kernel, 0.58 ms) and the one-pass iteration kernel
+// (stream_rows2_kernel, 0.63-0.65 ms).  Timing only: the kernels are the library's own templates (csrc/stream.h,
+// csrc/ops.h), instantiated here with functors that morph one into the other one element at a time.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I pogs_amd/csrc scripts/micro/c3_bisect.hip -o scripts/micro/bin/c3_bisect
+//   scripts/micro/bin/c3_bisect [m n reps]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "ops.h"
+#include "stream.h"
+
+using namespace pogs_amd;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+// Sinkhorn-Knopp's row functor in the one-pass kernel's interface (prefetch + row with dot / accumulator arrays)
+template <typename T>
+struct Sk2Op {
+  static constexpr int NS = 0;
+  struct Pre {};
+  T nn, c;
+  T *d;
+  __device__ __forceinline__ Pre prefetch(int) const { return Pre{}; }
+  template <int N, int ND, int NA>
+  __device__ __forceinline__ void row(int i, const Pre &, const T (&dot)[ND], double (&)[N], T (&u)[NA]) const {
+    const T v = nn / (dot[0] + c);
+    d[i] = v;
+    u[0] = v;
+    if constexpr (NA > 1) u[1] = ND > 1 ? dot[1] : v;
+  }
+  template <int NA>
+  __device__ __forceinline__ void uonly(int, T (&)[NA]) const {}
+};
+// ... with the six fp64 scalar sums of the iteration's functor and nothing else of it
+template <typename T>
+struct Sk2SumsOp {
+  static constexpr int NS = 6;
+  struct Pre {};
+  T nn, c;
+  T *d;
+  __device__ __forceinline__ Pre prefetch(int) const { return Pre{}; }
+  template <int N, int ND, int NA>
+  __device__ __forceinline__ void row(int i, const Pre &, const T (&dot)[ND], double (&s)[N], T (&u)[NA]) const {
+    const T v = nn / (dot[0] + c);
+    d[i] = v;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] += static_cast<double>(v) * (dot[0] + static_cast<T>(k));
+    u[0] = v;
+    if constexpr (NA > 1) u[1] = ND > 1 ? dot[1] : v;
+  }
+  template <int NA>
+  __device__ __forceinline__ void uonly(int, T (&)[NA]) const {}
+};
+// the iteration's functor in the single-dot kernel's interface (operands loaded inside row())
+template <typename T, bool LOGISTIC>
+struct Fused1Op {
+  static constexpr int NS = 6;
+  FusedIterOp<T, LOGISTIC> f;
+  template <int N>
+  __device__ __forceinline__ T row(int i, T dot, double (&s)[N]) const {
+    const auto pre = f.prefetch(i);
+    T dots[1] = {dot};
+    T u[1];
+    f.template row<N, 1, 1>(i, pre, dots, s, u);
+    return u[0];
+  }
+  __device__ __forceinline__ T u(int) const { return 0; }
+};
+
+struct Timer {
+  hipEvent_t a, b;
+  Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
+  template <typename F>
+  double run(F &&launch, int reps) {
+    for (int i = 0; i < 3; ++i) launch();
+    CK(hipDeviceSynchronize());
+    std::vector<float> ms(reps);
+    for (int i = 0; i < reps; ++i) {
+      CK(hipEventRecord(a));
+      launch();
+      CK(hipEventRecord(b));
+      CK(hipEventSynchronize(b));
+      CK(hipEventElapsedTime(&ms[i], a, b));
+    }
+    std::sort(ms.begin(), ms.end());
+    return ms[reps / 2];
+  }
+};
+
+template <typename K>
+int regs_of(K kernel) {
+  hipFuncAttributes at;
+  CK(hipFuncGetAttributes(&at, reinterpret_cast<const void *>(kernel)));
+  return at.numRegs;
+}
+
+int main(int argc, char **argv) {
+  const int m = argc > 1 ? atoi(argv[1]) : 200000, n = argc > 2 ? atoi(argv[2]) : 5000, reps = argc > 3 ? atoi(argv[3]) : 15;
+  using T = float;
+  constexpr int TPB = 256, NV = 5;
+  const int n_pad = (n + 3) / 4 * 4;
+  if (n_pad > TPB * NV * 4) { printf("n too wide for 256 x 5\n"); return 1; }
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int ncu = prop.multiProcessorCount;
+  printf("device %s, %d CUs; A = %d x %d fp32 (%.2f GB), median of %d launches each\n", prop.name, ncu, m, n, 4.0 * m * n_pad / 1e9, reps);
+
+  T *A, *xv, *x1, *vec[12], *cp0, *cp1;
+  int *h;
+  double *sp;
+  const size_t gmax = static_cast<size_t>(ncu) * 4;
+  CK(hipMalloc(&A, sizeof(T) * static_cast<size_t>(m) * n_pad));
+  CK(hipMalloc(&xv, sizeof(T) * n_pad));
+  CK(hipMalloc(&x1, sizeof(T) * n_pad));
+  for (auto &p : vec) CK(hipMalloc(&p, sizeof(T) * m));
+  CK(hipMalloc(&h, sizeof(int) * m));
+  CK(hipMalloc(&cp0, sizeof(T) * gmax * n_pad));
+  CK(hipMalloc(&cp1, sizeof(T) * gmax * n_pad));
+  CK(hipMalloc(&sp, sizeof(double) * gmax * 8));
+  {
+    std::vector<T> host(static_cast<size_t>(m) * n_pad);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (static_cast<int>(s >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+    for (auto &v : host) v = rnd() * 0.05f;
+    CK(hipMemcpy(A, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    std::vector<T> v1(std::max(m, n_pad));
+    for (auto &v : v1) v = rnd();
+    CK(hipMemcpy(xv, v1.data(), n_pad * sizeof(T), hipMemcpyHostToDevice));
+    CK(hipMemcpy(x1, v1.data(), n_pad * sizeof(T), hipMemcpyHostToDevice));
+    for (int k = 0; k < 12; ++k) {
+      for (int i = 0; i < m; ++i) v1[i] = (k == 5 || k == 7) ? 1.0f : (k == 6 || k == 8 || k == 9) ? 0.0f : rnd();   // a = c = 1, b = d = e = 0
+      CK(hipMemcpy(vec[k], v1.data(), m * sizeof(T), hipMemcpyHostToDevice));
+    }
+    std::vector<int> hh(m, 0);   // kAbs: a cheap prox
+    CK(hipMemcpy(h, hh.data(), m * sizeof(int), hipMemcpyHostToDevice));
+  }
+  // vec: 0 ynew, 1 ycur, 2 y12, 3 ytemp, 4 d (SK), 5 a, 6 b, 7 c, 8 d, 9 e, 10 y12s, 11 ytemps
+  const FnView<T> fv{h, vec[5], vec[6], vec[7], vec[8], vec[9]};
+  const FusedIterOp<T, false> fcheap{vec[0], vec[1], vec[2], vec[3], fv, 1.0f, 1.7f, 1.0f, vec[10], vec[11]};
+  const FusedIterOp<T, true> flog{vec[0], vec[1], vec[2], vec[3], fv, 1.0f, 1.7f, 1.0f, vec[10], vec[11]};
+  const SkRowOp<T> sk1{static_cast<T>(n), 1e-4f, vec[4]};
+  const Sk2Op<T> sk2{static_cast<T>(n), 1e-4f, vec[4]};
+  const Sk2SumsOp<T> sk2s{static_cast<T>(n), 1e-4f, vec[4]};
+
+  StreamArgs<T> a1{};
+  a1.A = A; a1.lda = n_pad; a1.m = m; a1.n_pad = n_pad; a1.xin = xv; a1.xin_add = nullptr; a1.xin_nrm2 = nullptr;
+  a1.col_partials = cp0; a1.scalar_partials = sp;
+  StreamArgs2<T> a2{A, static_cast<size_t>(n_pad), m, n_pad, xv, x1, cp0, cp1, sp};
+  const size_t lds2 = static_cast<size_t>(n_pad) * sizeof(T);
+  using F1C = Fused1Op<T, false>;
+  using F1L = Fused1Op<T, true>;
+  using FIC = FusedIterOp<T, false>;
+  using FIL = FusedIterOp<T, true>;
+  Timer tm;
+  const double gb = 4.0 * m * n_pad / 1e9;
+  auto report = [&](const char *name, int grid, int regs, double ms) {
+    printf("%-78s grid %4d (%d/CU)  %3d VGPR  %.4f ms  %.0f GB/s\n", name, grid, grid / ncu, regs, ms, gb / ms * 1e3);
+    fflush(stdout);
+  };
+
+#define ROWS(NAME, R, DOT, ACC, SQ, OPT, OP, GRID)                                                              \
+  {                                                                                                             \
+    auto k = stream_rows_kernel<T, TPB, NV, R, DOT, ACC, SQ, kFull, OPT>;                                       \
+    const int g = (GRID);                                                                                       \
+    report(NAME, g, regs_of(k), tm.run([&] { hipLaunchKernelGGL(k, dim3(g), dim3(TPB), 0, 0, a1, OP); }, reps)); \
+  }
+#define ROWS2(NAME, R, ND, NA, OPT, OP, GRID)                                                                    \
+  {                                                                                                             \
+    auto k = stream_rows2_kernel<T, TPB, NV, R, ND, NA, OPT>;                                                    \
+    const int g = (GRID);                                                                                       \
+    const size_t l = (ND > 1) ? lds2 : 0;                                                                       \
+    report(NAME, g, regs_of(k), tm.run([&] { hipLaunchKernelGGL(k, dim3(g), dim3(TPB), l, 0, a2, OP); }, reps)); \
+  }
+#define ROWS2DB(NAME, ND, NA, OPT, OP, GRID)                                                                     \
+  {                                                                                                             \
+    auto k = stream_rows2_db_kernel<T, TPB, NV, ND, NA, OPT>;                                                    \
+    const int g = (GRID);                                                                                       \
+    const size_t l = (ND > 1) ? lds2 : 0;                                                                       \
+    report(NAME, g, regs_of(k), tm.run([&] { hipLaunchKernelGGL(k, dim3(g), dim3(TPB), l, 0, a2, OP); }, reps)); \
+  }
+
+  for (int round = 0; round < 2; ++round) {
+    printf("---- round %d\n", round);
+    ROWS("A  rows  R2 dot+acc SQ  SkRowOp            (Sinkhorn-Knopp's pass)", 2, true, true, true, SkRowOp<T>, sk1, 2 * ncu);
+    ROWS("B  rows  R2 dot+acc     SkRowOp            (no squaring)", 2, true, true, false, SkRowOp<T>, sk1, 2 * ncu);
+    ROWS("B3 rows  R2 dot+acc     SkRowOp            (three per CU)", 2, true, true, false, SkRowOp<T>, sk1, 3 * ncu);
+    ROWS("C  rows  R2 dot+acc     Fused1Op cheap     (the iteration's functor, lean, in the rows skeleton)", 2, true, true, false,
+         F1C, F1C{fcheap}, 2 * ncu);
+    ROWS("C3 rows  R2 dot+acc     Fused1Op cheap     (three per CU)", 2, true, true, false, F1C, F1C{fcheap}, 3 * ncu);
+    ROWS("CL rows  R2 dot+acc     Fused1Op logistic", 2, true, true, false, F1L, F1L{flog}, 2 * ncu);
+    ROWS2("D  rows2 R2 1 dot 1 acc Sk2Op              (SK's functor in the rows2 skeleton)", 2, 1, 1, Sk2Op<T>, sk2, 2 * ncu);
+    ROWS2("D3 rows2 R2 1 dot 1 acc Sk2Op              (three per CU)", 2, 1, 1, Sk2Op<T>, sk2, 3 * ncu);
+    ROWS2("E3 rows2 R2 1 dot 1 acc Sk2SumsOp          (+ six fp64 sums)", 2, 1, 1, Sk2SumsOp<T>, sk2s, 3 * ncu);
+    ROWS2("F3 rows2 R2 2 dot 1 acc Sk2Op              (+ second dot from LDS)", 2, 2, 1, Sk2Op<T>, sk2, 3 * ncu);
+    ROWS2("G3 rows2 R2 1 dot 2 acc Sk2Op              (+ second accumulator)", 2, 1, 2, Sk2Op<T>, sk2, 3 * ncu);
+    ROWS2("H3 rows2 R2 2 dot 2 acc Sk2Op              (both)", 2, 2, 2, Sk2Op<T>, sk2, 3 * ncu);
+    ROWS2("H2 rows2 R2 2 dot 2 acc Sk2Op              (both, two per CU)", 2, 2, 2, Sk2Op<T>, sk2, 2 * ncu);
+    ROWS2("I3 rows2 R2 2 dot 2 acc Sk2SumsOp          (both + sums)", 2, 2, 2, Sk2SumsOp<T>, sk2s, 3 * ncu);
+    ROWS2("J3 rows2 R2 1 dot 1 acc FusedIterOp cheap  (lean iteration pass)", 2, 1, 1, FIC, fcheap, 3 * ncu);
+    ROWS2("J2 rows2 R2 1 dot 1 acc FusedIterOp cheap  (two per CU)", 2, 1, 1, FIC, fcheap, 2 * ncu);
+    ROWS2("K3 rows2 R2 2 dot 2 acc FusedIterOp cheap  (full iteration pass, lasso)", 2, 2, 2, FIC, fcheap, 3 * ncu);
+    ROWS2("L3 rows2 R2 2 dot 2 acc FusedIterOp logistic (the shipped C3 pass)", 2, 2, 2, FIL, flog, 3 * ncu);
+    ROWS2DB("M3 rows2-db R1+next 2 dot 2 acc FusedIterOp logistic", 2, 2, FIL, flog, 3 * ncu);
+    ROWS2DB("N3 rows2-db R1+next 2 dot 2 acc Sk2Op", 2, 2, Sk2Op<T>, sk2, 3 * ncu);
+    ROWS2DB("O3 rows2-db R1+next 1 dot 1 acc Sk2Op", 1, 1, Sk2Op<T>, sk2, 3 * ncu);
+    ROWS2DB("O4 rows2-db R1+next 1 dot 1 acc Sk2Op   (four per CU)", 1, 1, Sk2Op<T>, sk2, 4 * ncu);
+  }
+  return 0;
+}

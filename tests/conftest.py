@@ -21,6 +21,9 @@ def pytest_configure(config):
     # the GPU tests hand torch device pointers to the library: torch has to bring its HIP runtime
     # first (pogs_amd/_lib.py: the package does not import torch on its own)
     os.environ.setdefault("POGS_AMD_TORCH_PRELOAD", "1")
+    # the suite's one-GPU communicators (ranks as threads / processes) are a transport plug-in of the library,
+    # tests/transport/test_transport.hip, built by pogs_amd/build.py
+    os.environ.setdefault("POGS_AMD_TRANSPORT_PLUGIN", os.path.join(ROOT, "tests", "transport", "libpogs_test_transport.so"))
     import oracle_binding
 
     oracle_binding.build_oracle()

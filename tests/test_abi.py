@@ -135,3 +135,30 @@ def test_the_build_leaves_a_libpogs_cpu_alias_the_reference_loader_finds():
     lib = ctypes.CDLL(alias)
     for sym in ("PogsD", "PogsS", "PogsSparseD", "PogsSparseS"):
         getattr(lib, sym)
+
+
+def test_a_null_coefficient_array_is_refused_by_the_array_entry_points(capfd):
+    """The reference's four entry points take twelve coefficient arrays (src/interface_c/pogs_c.h:75-119); a NULL
+    among them is a caller's mistake.  Since the *Fn entry points read a null field as a broadcast scalar, the
+    array entry points must say no themselves -- before a solver is built, so this runs without a GPU: the call
+    returns POGS_ERROR (6, pogs_c.h:20-26 via PogsStatus) and names the vector."""
+    import numpy as np
+
+    m, n = 6, 4
+    A = np.ones((m, n), np.float32)
+    one_m, one_n = np.ones(m, np.float32), np.ones(n, np.float32)
+    hm, hn = np.zeros(m, np.int32), np.zeros(n, np.int32)
+    x, y, l_ = np.zeros(n, np.float32), np.zeros(m, np.float32), np.zeros(m, np.float32)
+    opt, it = ctypes.c_float(0), ctypes.c_uint(0)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    f = [P(one_m)] * 5 + [P(hm)]
+    g = [P(one_n)] * 5 + [P(hn)]
+    for which, pos in (("f", 2), ("g", 5), ("g", 0)):
+        ff, gg = list(f), list(g)
+        (ff if which == "f" else gg)[pos] = None
+        rc = _lib.lib.PogsS(_lib.ROW_MAJ, m, n, P(A), *ff, *gg, 1.0, 1e-4, 1e-4, 10, 0, 1, 1, P(x), P(y), P(l_),
+                            ctypes.byref(opt), ctypes.byref(it))
+        assert rc == 6, rc
+        msg = _lib.last_error()
+        assert "null coefficient array" in msg and "description of %s" % which in msg, msg
+    capfd.readouterr()

@@ -214,3 +214,56 @@ def test_the_n_gt_1_parity_leg_on_two_in_process_ranks():
     assert par["rel_x"] < 1e-4 and abs(par["iterations_engine"] - par["iterations_reference"]) <= 3, par
     with pytest.raises(AssertionError):      # rows that are not the rank's own are noticed
         bench.unsharded_parity(cfg, m, n, world, dev, 0, res[0], [1.0, 2.0])
+
+
+def test_two_process_rehearsal_of_the_launcher_path():
+    """The first SCALE_r*.json will be produced by the driver on a node this build has never seen: everything
+    around the collective must have run before.  Two PROCESSES under torch.distributed.run exactly as the driver
+    starts them (`--nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`),
+    both on cuda:0 -- RCCL refuses that, so the process group is gloo and the solver handles are joined by the test
+    plug-in's shared-memory communicator (POGS_AMD_BENCH_REHEARSAL=1, tests/transport/test_transport.hip).  Runs at
+    a reduced shape through: rank environment, the 128-byte id broadcast (once per handle: the timed one, five
+    create / solve / destroy cycles, the exact-setup handle), per-rank shard generation, windows agreed by broadcast,
+    max-over-ranks timing, the all-gather of the shards' checksums, rank 0's unsharded parity solve and CPU leg
+    while rank 1 waits in long_barrier, and the assembly of the two output lines."""
+    import socket
+    import time
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, POGS_AMD_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "POGS_AMD_FORCE_DIST"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "5", "--rows-per-gpu", "12000", "--cols", "1500"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    last = lines[-1]
+    assert last.startswith('{"metric"') and len(last) < 6000, last[:200]
+    assert [ln for ln in lines if ln.startswith("{")] == [last]      # ONE contract line: rank 0's
+    sm = json.loads(last)
+    det = json.loads([ln for ln in lines if ln.startswith("BENCH_DETAIL ")][-1][len("BENCH_DETAIL "):])
+    assert sm["n_gpus"] == 2 and sm["steps"] == 20 and sm["warmup"] == 5 and sm["scaling"] == "weak"
+    cf = sm["config"]
+    assert cf["rows_per_gpu"] == 12000 and cf["cols"] == 1500 and cf["parallelism"] == "row-shard x2"
+    assert cf["rccl_nranks"] == 2 and "rehearsal" in cf and "row-sharded 24000x1500" in cf["workload"]
+    assert sm["value"] > 0 and _close(sm["value"], 2 * 1e3 / sm["ms_per_step"], 1e-4)      # summed over the two ranks
+    assert sm["solve_status"] == 0 and sm["roofline"]["frac"] > 0
+    # the sharded solution against rank 0's UNSHARDED solve of the regenerated whole problem
+    par = det["parity_vs_reference"]
+    assert "UNSHARDED" in par["against"] and par["rel_x"] < 1e-4, par
+    assert abs(par["iterations_engine"] - par["iterations_reference"]) <= 3, par
+    assert _close(sm["parity"]["rel_x"], par["rel_x"])
+    # rank 0's CPU leg on its own shard, extrapolated to the whole problem (t_iter ~ m)
+    cb = det["cpu_baseline"]
+    assert cb["kind"] == "reference" and cb["value"] > 0 and "extrapolated" in cb, cb
+    assert _close(cb["value"], cb["value_on_one_shard"] / 2) and "extrapolated" in sm["cpu_baseline"]
+    # five create / solve / destroy cycles, every one a fresh id broadcast and a fresh communicator
+    assert det["handle_cycles"]["n"] == 5 and det["exact_setup"]["status"] == 0
+    print("two-process rehearsal: %.1f s wall" % wall)
+    assert wall < 240.0, wall       # (about 40 s on a warm box; the bound only catches a hang-and-timeout path)

@@ -75,6 +75,12 @@ def test_five_consecutive_handles_on_c2_set_up_at_the_speed_of_the_fastest():
     if not steady(setups, totals):
         # one repetition: in a full-suite run of round 5 ONE of five set-ups took 0.120 s instead of 0.053 (all blocks from the
         # pool, no hipMalloc / hipFree; three isolated runs of this file: 0.054-0.055 throughout) -- a systematic stall fails twice
+        # (the repetition is REPORTED -- a warning in the run's summary with the first attempt's figures and pool counters --
+        # so that an intermittent stall stays visible instead of passing silently)
+        import warnings
+
+        warnings.warn("five-cycle timing was not steady on the first attempt (repeated once): setup_s %s, create+solve+destroy_s %s, "
+                      "pool deltas %s" % ([round(v, 4) for v in setups], [round(v, 4) for v in totals], pool))
         setups, totals, runs, pool = five_cycles()
     assert max(setups) < 1.3 * min(setups), setups
     assert max(totals) < 1.3 * min(totals), totals
