@@ -105,16 +105,6 @@ void DenseSolver<T, Tag>::factor() {
           gp.tile_map = tmap256.p;
         }
       }
-      if (const char *rep = std::getenv("POGS_AMD_GRAM_REPEAT")) {
-        // telemetry aid (scripts/gpu_pmc_gram.sh): the first launch's product `rep` times back to back -- seconds
-        // of nothing but gram_f16s_kernel for a power / clock sampler to look at; the real launches below
-        // overwrite what these leave in the slabs (the first one does not accumulate)
-        gp.nslabs = std::min(4, nunits);
-        gp.accumulate = 0;
-        launch_split_f16(reinterpret_cast<const float *>(A_.p), lda_, kdim, k_, 0, gp.nslabs * urows, npad, scale16, H, L, s);
-        for (int r = std::max(0, std::atoi(rep)); r > 0; --r) launch_gram_f16p(gp, s);
-        ctx_.sync();
-      }
       for (int u0 = 0; u0 < nunits; u0 += 4) {
         gp.nslabs = std::min(4, nunits - u0);
         gp.accumulate = u0 > 0 ? 1 : 0;

@@ -91,7 +91,13 @@ void launch_gemm(bool a_kmaj, bool b_kmaj, bool lower_only, const GemmArgs<T> &g
 
 // Diagonal block size of the blocked Cholesky / first TRTRI level.
 template <typename T> struct CholBlock;
-template <> struct CholBlock<float> { static constexpr int NB = 128; };
+#ifndef POGS_CHOL_NB_F32   // (compile-time overrides for A / B builds: scripts/build_variant.py <tag> gemm.hip -D...)
+#define POGS_CHOL_NB_F32 128
+#endif
+#ifndef POGS_CHOL_GROUP_F32
+#define POGS_CHOL_GROUP_F32 2
+#endif
+template <> struct CholBlock<float> { static constexpr int NB = POGS_CHOL_NB_F32; };
 template <> struct CholBlock<double> { static constexpr int NB = 64; };
 
 // G (n x n, lower triangle valid, leading dim ldg) is overwritten by its Cholesky

@@ -905,7 +905,7 @@ void cholesky_lower(T *G, size_t ldg, int n, T *W, size_t ldw, hipStream_t s) {
   constexpr int NB = CholBlock<T>::NB;
   // (measured at n = 10000, Cholesky phase in ms for groups of 1 | 2 | 4: fp32, 128-wide panels 13.5 | 12.3 | 12.2;
   // fp64, 64-wide panels 29.1 | 24.7 | 23.6; fp32 at n = 5000 4.6 | 4.6 | 4.9)
-  constexpr int kCholGroup = sizeof(T) == 8 ? 4 : 2;
+  constexpr int kCholGroup = sizeof(T) == 8 ? 4 : POGS_CHOL_GROUP_F32;
   // Panels are taken in GROUPS of kCholGroup: inside a group a panel's block column is updated by the
   // group's earlier panels only (left-looking), and the trailing matrix is updated once per group with
   // all of its panels (K = kCholGroup NB).  The trailing update is bound

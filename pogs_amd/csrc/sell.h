@@ -193,10 +193,20 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
     else sell_load<unsigned short, UB>(a_rid + e0, B.r);
   };
   T acc = 0;   // running sum of the lane's current row (rows never straddle tiles)
+  // POGS_SELL_ABLATE (timing only, WRONG results; scripts/build_variant.py + scripts/spmv_probe.sh, round 6's table in
+  // profiles/NOTES_r06.md): bit 0 -- every LDS access of the batch compiled out (the gathers read a register instead, the
+  // row sums are not flushed); bit 1 -- the row-end / id-slot logic compiled out (no element ends a row).
+#ifndef POGS_SELL_ABLATE
+#define POGS_SELL_ABLATE 0
+#endif
+  constexpr bool kNoLds = (POGS_SELL_ABLATE & 1) != 0, kNoIds = (POGS_SELL_ABLATE & 2) != 0;
   auto consume = [&](const SellBatch<T, TWO> &B) {
     T xg[UB];
 #pragma unroll
-    for (int j = 0; j < UB; ++j) xg[j] = s_x[TWO ? (B.c[j] & (kSellEndBit - 1)) : B.c[j]];
+    for (int j = 0; j < UB; ++j) {
+      if constexpr (kNoLds) xg[j] = static_cast<T>(B.c[j]);
+      else xg[j] = s_x[TWO ? (B.c[j] & (kSellEndBit - 1)) : B.c[j]];
+    }
     // running sums in registers first; the row ends of the batch are then flushed with INDEPENDENT
     // LDS accesses (all reads, then all writes).  A row belongs to one lane and ends once, so the
     // (up to UB) sums a lane flushes here are distinct and nobody else touches them -- written as
@@ -210,7 +220,10 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
     for (int j = 0; j < UB; ++j) {
       const T v = B.v[j];
       acc = sell_fma(SQ ? v * v : v, xg[j], acc);   // fused, written out: this unit is compiled with -ffp-contract=off
-      if constexpr (TWO) {
+      if constexpr (kNoIds) {
+        en[j] = false;
+        row[j] = 0;
+      } else if constexpr (TWO) {
         en[j] = (B.c[j] & kSellEndBit) != 0;
         row[j] = static_cast<unsigned short>(seen ? B.rr >> 16 : B.rr & 0xFFFFu);
         seen = seen || en[j];
@@ -221,7 +234,11 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
       fl[j] = acc;
       acc = en[j] ? static_cast<T>(0) : acc;
     }
-    if constexpr (TWO && kSellFlatFlush) {
+    if constexpr (kNoLds) {
+      // (the sums must stay live: folded into the running sum, which the kernel's tail keeps)
+#pragma unroll
+      for (int j = 0; j < UB; ++j) acc += en[j] ? fl[j] : static_cast<T>(0);
+    } else if constexpr (TWO && kSellFlatFlush) {
       // Flat flush: EVERY element reads and writes one LDS word -- a row end its row sum, any other element the lane's own
       // scratch word behind the row sums (conflict-free) -- so the batch is straight-line code: no exec mask is saved and
       // restored around each of the eight accesses, no branch skips a write that some lane of the wavefront needs anyway
@@ -383,6 +400,9 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
         fetch(e0, B[q]);
       }
     }
+  }
+  if constexpr (kNoLds) {   // (ablation build: keeps the running sums, and with them the loads and products, alive)
+    if (acc == static_cast<T>(123.456)) s_y[t] = acc;
   }
   __syncthreads();
 }

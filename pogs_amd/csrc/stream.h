@@ -799,16 +799,17 @@ __global__ void __launch_bounds__(TPB, (ND > 0 ? stream2_waves_per_simd(TPB, NV,
 #endif
 constexpr bool stream2_db_c(int nd, int nv) { return POGS_STREAM2_DB != 0 && nd > 0 && nv == 5; }
 
-template <typename T, int TPB, int NV, int ND, int NA, typename Op>
-__global__ void __launch_bounds__(TPB, stream2_waves_per_simd(TPB, NV, ND, NA)) stream_rows2_db_kernel(StreamArgs2<T> a, Op op) {
+// R rows per step (the tile in flight is R rows too); BPC: workgroups per CU the register budget is held to
+template <typename T, int TPB, int NV, int R, int ND, int NA, int BPC, typename Op>
+__global__ void __launch_bounds__(TPB, (BPC * (TPB / 64) + 3) / 4) stream_rows2_db_kernel(StreamArgs2<T> a, Op op) {
   using V = typename Vec16<T>::type;
   using Pre = typename Op::Pre;
   constexpr int VEC = Vec16<T>::N;
   constexpr int NW = TPB / 64;
   constexpr int NS = Op::NS > 0 ? Op::NS : 1;
   static_assert(ND > 0, "the column-sum-only form has no chain to hide");
-  __shared__ T s_part[2 * ND * NW];
-  __shared__ T s_u[2 * NA];
+  __shared__ T s_part[2 * R * ND * NW];
+  __shared__ T s_u[2 * R * NA];
   __shared__ double s_red[NS * NW];
   extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
   T *s_x1 = reinterpret_cast<T *>(s_dyn);
@@ -831,73 +832,93 @@ __global__ void __launch_bounds__(TPB, stream2_waves_per_simd(TPB, NV, ND, NA)) 
 #pragma unroll
   for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
 
-  int row = blockIdx.x;
-  V cur[NV];
+  const int nblk = (a.m + R - 1) / R;
+  int blk = blockIdx.x;
+  V cur[R][NV];
   Pre pre_cur;
-  if (t == 0 && row < a.m) pre_cur = op.prefetch(row);
+  if (t < R && blk < nblk && blk * R + t < a.m) pre_cur = op.prefetch(blk * R + t);
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int col = (v * TPB + t) * VEC;
-    cur[v] = (col < a.n_pad && row < a.m) ? stream_load<V>(a.A + static_cast<size_t>(row) * a.lda + col) : dev::vzero<V>();
+  for (int r = 0; r < R; ++r) {
+    const int row = blk * R + r;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * TPB + t) * VEC;
+      cur[r][v] = (col < a.n_pad && blk < nblk && row < a.m) ? stream_load<V>(a.A + static_cast<size_t>(row) * a.lda + col)
+                                                              : dev::vzero<V>();
+    }
   }
   int slot = 0;
-  for (; row < a.m; row += gridDim.x, slot ^= 1) {
-    // the next row of this workgroup and its functor's operands: requested first (the functor's operands before
+  for (; blk < nblk; blk += gridDim.x, slot ^= 1) {
+    const int row0 = blk * R;
+    // the next tile of this workgroup and its functor's operands: requested first (the functor's operands before
     // the tile, so that waiting for them next step does not wait for anything younger)
-    const int nrow = row + gridDim.x;
+    const int nblk_ = blk + gridDim.x, nrow0 = nblk_ * R;
     Pre pre_nxt;
-    if (t == 0 && nrow < a.m) pre_nxt = op.prefetch(nrow);
-    V nxt[NV];
-    {
-      const T *rp = a.A + static_cast<size_t>(nrow) * a.lda;
+    if (t < R && nblk_ < nblk && nrow0 + t < a.m) pre_nxt = op.prefetch(nrow0 + t);
+    V nxt[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = nrow0 + r;
+      const T *rp = a.A + static_cast<size_t>(row) * a.lda;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int col = (v * TPB + t) * VEC;
-        nxt[v] = (col < a.n_pad && nrow < a.m) ? stream_load<V>(rp + col) : dev::vzero<V>();
+        nxt[r][v] = (col < a.n_pad && nblk_ < nblk && row < a.m) ? stream_load<V>(rp + col) : dev::vzero<V>();
       }
     }
-    T s0 = 0, s1 = 0;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      s0 += dev::vdot(cur[v], xv[v]);
-      if (ND > 1) {
-        const int col = (v * TPB + t) * VEC;
-        if (col < a.n_pad) s1 += dev::vdot(cur[v], *reinterpret_cast<const V *>(s_x1 + col));
+    for (int r = 0; r < R; ++r) {
+      T s0 = 0, s1 = 0;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        s0 += dev::vdot(cur[r][v], xv[v]);
+        if (ND > 1) {
+          const int col = (v * TPB + t) * VEC;
+          if (col < a.n_pad) s1 += dev::vdot(cur[r][v], *reinterpret_cast<const V *>(s_x1 + col));
+        }
       }
-    }
-    s0 = dev::wave_sum(s0);
-    if (ND > 1) s1 = dev::wave_sum(s1);
-    if (lane == 0) {
-      s_part[(slot * ND + 0) * NW + wave] = s0;
-      if (ND > 1) s_part[(slot * ND + 1) * NW + wave] = s1;
+      s0 = dev::wave_sum(s0);
+      if (ND > 1) s1 = dev::wave_sum(s1);
+      if (lane == 0) {
+        s_part[((slot * R + r) * ND + 0) * NW + wave] = s0;
+        if (ND > 1) s_part[((slot * R + r) * ND + 1) * NW + wave] = s1;
+      }
     }
     __syncthreads();
-    if (t == 0) {
+    if (t < R) {
+      const int row = row0 + t;
       T uu[NA];
-      T dots[ND];
 #pragma unroll
-      for (int d = 0; d < ND; ++d) {
-        T s = 0;
+      for (int q = 0; q < NA; ++q) uu[q] = 0;
+      if (row < a.m) {
+        T dots[ND];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) s += s_part[(slot * ND + d) * NW + w];
-        dots[d] = s;
+        for (int d = 0; d < ND; ++d) {
+          T s = 0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) s += s_part[((slot * R + t) * ND + d) * NW + w];
+          dots[d] = s;
+        }
+        op.row(row, pre_cur, dots, sacc, uu);
       }
-      op.row(row, pre_cur, dots, sacc, uu);
 #pragma unroll
-      for (int q = 0; q < NA; ++q) s_u[slot * NA + q] = uu[q];
+      for (int q = 0; q < NA; ++q) s_u[(slot * R + t) * NA + q] = uu[q];
     }
     __syncthreads();
-    {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
       T uu[NA];
 #pragma unroll
-      for (int q = 0; q < NA; ++q) uu[q] = s_u[slot * NA + q];
+      for (int q = 0; q < NA; ++q) uu[q] = s_u[(slot * R + r) * NA + q];
 #pragma unroll
       for (int q = 0; q < NA; ++q)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) dev::vfma(acc[q][v], uu[q], cur[v]);
+        for (int v = 0; v < NV; ++v) dev::vfma(acc[q][v], uu[q], cur[r][v]);
     }
 #pragma unroll
-    for (int v = 0; v < NV; ++v) cur[v] = nxt[v];
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) cur[r][v] = nxt[r][v];
     pre_cur = pre_nxt;
   }
 #pragma unroll
@@ -957,8 +978,8 @@ void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, 
     const size_t lds = (ND > 1) ? static_cast<size_t>(a.n_pad) * sizeof(T) : 0;                 \
     if constexpr (stream2_db_c(ND, NV_)) {                                                      \
       static SmemGrants grants_db;                                                              \
-      ensure_dynamic_smem(reinterpret_cast<const void *>(&stream_rows2_db_kernel<T, TPB_, NV_, ND, NA, Op>), lds, grants_db); \
-      hipLaunchKernelGGL((stream_rows2_db_kernel<T, TPB_, NV_, ND, NA, Op>), dim3(grid), dim3(TPB_), lds, s, a, op); \
+      ensure_dynamic_smem(reinterpret_cast<const void *>(&stream_rows2_db_kernel<T, TPB_, NV_, 1, ND, NA, 3, Op>), lds, grants_db); \
+      hipLaunchKernelGGL((stream_rows2_db_kernel<T, TPB_, NV_, 1, ND, NA, 3, Op>), dim3(grid), dim3(TPB_), lds, s, a, op); \
       return;                                                                                   \
     }                                                                                           \
     static SmemGrants grants;   /* per device; concurrent solvers share it */                   \

@@ -16,7 +16,7 @@ import json,sys
 ls=[l for l in sys.stdin.read().splitlines() if l.startswith('BENCH_DETAIL ')]
 if not ls: print('$tag rep $rep: FAILED'); print(open('/tmp/ab_err.log').read()[-1500:]); sys.exit(0)
 d=json.loads(ls[-1][13:]); rf=d['roofline']; par=d.get('parity_vs_reference') or {}
-print('%-10s rep $rep: %8.1f it/s  pass %.4f ms (frac %.3f)  iteration_frac %.3f  iters %s  status %s  rel_x %s  ttc %.4f s' % ('$tag', d['value'], rf['avg_launch_ms'], rf['frac'], rf['iteration_frac'], d['solve_iterations'], d['solve_status'], par.get('rel_x'), d['time_to_converge_s']))"
+print('%-10s rep $rep: %8.1f it/s  pass %.4f ms (frac %.3f)  iteration_frac %.3f  iters %s  status %s  rel_x %s  ttc %.4f s  setup_ms %s' % ('$tag', d['value'], rf['avg_launch_ms'], rf['frac'], rf['iteration_frac'], d['solve_iterations'], d['solve_status'], par.get('rel_x'), d['time_to_converge_s'], {k[:-3]: round(v, 2) for k, v in d.get('setup_ms', {}).items()}))"
   done
 done
 cp /tmp/base.so pogs_amd/libpogs_amd.so

@@ -100,16 +100,17 @@ int regs_of(K kernel) {
   return at.numRegs;
 }
 
-int main(int argc, char **argv) {
-  const int m = argc > 1 ? atoi(argv[1]) : 200000, n = argc > 2 ? atoi(argv[2]) : 5000, reps = argc > 3 ? atoi(argv[3]) : 15;
+template <int NV>
+int run(int m, int n, int reps, int table) {
   using T = float;
-  constexpr int TPB = 256, NV = 5;
+  constexpr int TPB = 256;
   const int n_pad = (n + 3) / 4 * 4;
-  if (n_pad > TPB * NV * 4) { printf("n too wide for 256 x 5\n"); return 1; }
+  if (n_pad > TPB * NV * 4) { printf("n too wide for 256 x %d\n", NV); return 1; }
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   const int ncu = prop.multiProcessorCount;
-  printf("device %s, %d CUs; A = %d x %d fp32 (%.2f GB), median of %d launches each\n", prop.name, ncu, m, n, 4.0 * m * n_pad / 1e9, reps);
+  printf("device %s, %d CUs; A = %d x %d fp32 (%.2f GB), 256 threads x %d vectors, median of %d launches each\n", prop.name, ncu, m, n,
+         4.0 * m * n_pad / 1e9, NV, reps);
 
   T *A, *xv, *x1, *vec[12], *cp0, *cp1;
   int *h;
@@ -160,7 +161,7 @@ int main(int argc, char **argv) {
   Timer tm;
   const double gb = 4.0 * m * n_pad / 1e9;
   auto report = [&](const char *name, int grid, int regs, double ms) {
-    printf("%-78s grid %4d (%d/CU)  %3d VGPR  %.4f ms  %.0f GB/s\n", name, grid, grid / ncu, regs, ms, gb / ms * 1e3);
+    printf("%-86s grid %4d (%d/CU)  %3d VGPR  %.4f ms  %.0f GB/s\n", name, grid, grid / ncu, regs, ms, gb / ms * 1e3);
     fflush(stdout);
   };
 
@@ -177,9 +178,9 @@ int main(int argc, char **argv) {
     const size_t l = (ND > 1) ? lds2 : 0;                                                                       \
     report(NAME, g, regs_of(k), tm.run([&] { hipLaunchKernelGGL(k, dim3(g), dim3(TPB), l, 0, a2, OP); }, reps)); \
   }
-#define ROWS2DB(NAME, ND, NA, OPT, OP, GRID)                                                                     \
+#define ROWS2DB(NAME, R, ND, NA, BPC, OPT, OP, GRID)                                                             \
   {                                                                                                             \
-    auto k = stream_rows2_db_kernel<T, TPB, NV, ND, NA, OPT>;                                                    \
+    auto k = stream_rows2_db_kernel<T, TPB, NV, R, ND, NA, BPC, OPT>;                                            \
     const int g = (GRID);                                                                                       \
     const size_t l = (ND > 1) ? lds2 : 0;                                                                       \
     report(NAME, g, regs_of(k), tm.run([&] { hipLaunchKernelGGL(k, dim3(g), dim3(TPB), l, 0, a2, OP); }, reps)); \
@@ -187,29 +188,71 @@ int main(int argc, char **argv) {
 
   for (int round = 0; round < 2; ++round) {
     printf("---- round %d\n", round);
-    ROWS("A  rows  R2 dot+acc SQ  SkRowOp            (Sinkhorn-Knopp's pass)", 2, true, true, true, SkRowOp<T>, sk1, 2 * ncu);
-    ROWS("B  rows  R2 dot+acc     SkRowOp            (no squaring)", 2, true, true, false, SkRowOp<T>, sk1, 2 * ncu);
-    ROWS("B3 rows  R2 dot+acc     SkRowOp            (three per CU)", 2, true, true, false, SkRowOp<T>, sk1, 3 * ncu);
-    ROWS("C  rows  R2 dot+acc     Fused1Op cheap     (the iteration's functor, lean, in the rows skeleton)", 2, true, true, false,
-         F1C, F1C{fcheap}, 2 * ncu);
-    ROWS("C3 rows  R2 dot+acc     Fused1Op cheap     (three per CU)", 2, true, true, false, F1C, F1C{fcheap}, 3 * ncu);
-    ROWS("CL rows  R2 dot+acc     Fused1Op logistic", 2, true, true, false, F1L, F1L{flog}, 2 * ncu);
-    ROWS2("D  rows2 R2 1 dot 1 acc Sk2Op              (SK's functor in the rows2 skeleton)", 2, 1, 1, Sk2Op<T>, sk2, 2 * ncu);
-    ROWS2("D3 rows2 R2 1 dot 1 acc Sk2Op              (three per CU)", 2, 1, 1, Sk2Op<T>, sk2, 3 * ncu);
-    ROWS2("E3 rows2 R2 1 dot 1 acc Sk2SumsOp          (+ six fp64 sums)", 2, 1, 1, Sk2SumsOp<T>, sk2s, 3 * ncu);
-    ROWS2("F3 rows2 R2 2 dot 1 acc Sk2Op              (+ second dot from LDS)", 2, 2, 1, Sk2Op<T>, sk2, 3 * ncu);
-    ROWS2("G3 rows2 R2 1 dot 2 acc Sk2Op              (+ second accumulator)", 2, 1, 2, Sk2Op<T>, sk2, 3 * ncu);
-    ROWS2("H3 rows2 R2 2 dot 2 acc Sk2Op              (both)", 2, 2, 2, Sk2Op<T>, sk2, 3 * ncu);
-    ROWS2("H2 rows2 R2 2 dot 2 acc Sk2Op              (both, two per CU)", 2, 2, 2, Sk2Op<T>, sk2, 2 * ncu);
-    ROWS2("I3 rows2 R2 2 dot 2 acc Sk2SumsOp          (both + sums)", 2, 2, 2, Sk2SumsOp<T>, sk2s, 3 * ncu);
-    ROWS2("J3 rows2 R2 1 dot 1 acc FusedIterOp cheap  (lean iteration pass)", 2, 1, 1, FIC, fcheap, 3 * ncu);
-    ROWS2("J2 rows2 R2 1 dot 1 acc FusedIterOp cheap  (two per CU)", 2, 1, 1, FIC, fcheap, 2 * ncu);
-    ROWS2("K3 rows2 R2 2 dot 2 acc FusedIterOp cheap  (full iteration pass, lasso)", 2, 2, 2, FIC, fcheap, 3 * ncu);
-    ROWS2("L3 rows2 R2 2 dot 2 acc FusedIterOp logistic (the shipped C3 pass)", 2, 2, 2, FIL, flog, 3 * ncu);
-    ROWS2DB("M3 rows2-db R1+next 2 dot 2 acc FusedIterOp logistic", 2, 2, FIL, flog, 3 * ncu);
-    ROWS2DB("N3 rows2-db R1+next 2 dot 2 acc Sk2Op", 2, 2, Sk2Op<T>, sk2, 3 * ncu);
-    ROWS2DB("O3 rows2-db R1+next 1 dot 1 acc Sk2Op", 1, 1, Sk2Op<T>, sk2, 3 * ncu);
-    ROWS2DB("O4 rows2-db R1+next 1 dot 1 acc Sk2Op   (four per CU)", 1, 1, Sk2Op<T>, sk2, 4 * ncu);
+    if constexpr (NV == 5) {
+      if (table == 1) {
+        ROWS("A  rows  R2 dot+acc SQ  SkRowOp            (Sinkhorn-Knopp's pass)", 2, true, true, true, SkRowOp<T>, sk1, 2 * ncu);
+        ROWS("B  rows  R2 dot+acc     SkRowOp            (no squaring)", 2, true, true, false, SkRowOp<T>, sk1, 2 * ncu);
+        ROWS("B3 rows  R2 dot+acc     SkRowOp            (three per CU)", 2, true, true, false, SkRowOp<T>, sk1, 3 * ncu);
+        ROWS("C  rows  R2 dot+acc     Fused1Op cheap     (the iteration's functor, lean, in the rows skeleton)", 2, true, true, false, F1C, F1C{fcheap}, 2 * ncu);
+        ROWS("C3 rows  R2 dot+acc     Fused1Op cheap     (three per CU)", 2, true, true, false, F1C, F1C{fcheap}, 3 * ncu);
+        ROWS("CL rows  R2 dot+acc     Fused1Op logistic", 2, true, true, false, F1L, F1L{flog}, 2 * ncu);
+        ROWS2("D  rows2 R2 1 dot 1 acc Sk2Op              (SK's functor in the rows2 skeleton)", 2, 1, 1, Sk2Op<T>, sk2, 2 * ncu);
+        ROWS2("D3 rows2 R2 1 dot 1 acc Sk2Op              (three per CU)", 2, 1, 1, Sk2Op<T>, sk2, 3 * ncu);
+        ROWS2("E3 rows2 R2 1 dot 1 acc Sk2SumsOp          (+ six fp64 sums)", 2, 1, 1, Sk2SumsOp<T>, sk2s, 3 * ncu);
+        ROWS2("F3 rows2 R2 2 dot 1 acc Sk2Op              (+ second dot from LDS)", 2, 2, 1, Sk2Op<T>, sk2, 3 * ncu);
+        ROWS2("G3 rows2 R2 1 dot 2 acc Sk2Op              (+ second accumulator)", 2, 1, 2, Sk2Op<T>, sk2, 3 * ncu);
+        ROWS2("H3 rows2 R2 2 dot 2 acc Sk2Op              (both)", 2, 2, 2, Sk2Op<T>, sk2, 3 * ncu);
+        ROWS2("H2 rows2 R2 2 dot 2 acc Sk2Op              (both, two per CU)", 2, 2, 2, Sk2Op<T>, sk2, 2 * ncu);
+        ROWS2("I3 rows2 R2 2 dot 2 acc Sk2SumsOp          (both + sums)", 2, 2, 2, Sk2SumsOp<T>, sk2s, 3 * ncu);
+        ROWS2("J3 rows2 R2 1 dot 1 acc FusedIterOp cheap  (lean iteration pass)", 2, 1, 1, FIC, fcheap, 3 * ncu);
+        ROWS2("J2 rows2 R2 1 dot 1 acc FusedIterOp cheap  (two per CU)", 2, 1, 1, FIC, fcheap, 2 * ncu);
+        ROWS2("K3 rows2 R2 2 dot 2 acc FusedIterOp cheap  (full iteration pass, lasso)", 2, 2, 2, FIC, fcheap, 3 * ncu);
+        ROWS2("L3 rows2 R2 2 dot 2 acc FusedIterOp logistic (the shipped C3 pass)", 2, 2, 2, FIL, flog, 3 * ncu);
+        ROWS2DB("M3 rows2-db R1+next 2 dot 2 acc FusedIterOp logistic", 1, 2, 2, 3, FIL, flog, 3 * ncu);
+        ROWS2DB("N3 rows2-db R1+next 2 dot 2 acc Sk2Op", 1, 2, 2, 3, Sk2Op<T>, sk2, 3 * ncu);
+        ROWS2DB("O3 rows2-db R1+next 1 dot 1 acc Sk2Op", 1, 1, 1, 3, Sk2Op<T>, sk2, 3 * ncu);
+        ROWS2DB("O4 rows2-db R1+next 1 dot 1 acc Sk2Op   (four per CU)", 1, 1, 1, 4, Sk2Op<T>, sk2, 4 * ncu);
+      } else {
+        // table 2: the finding of table 1 (two workgroups per CU stream 8 % faster than three, whatever the skeleton; three
+        // are there to hide the functor) -- what hides the functor at TWO per CU?
+        ROWS("A  rows  R2 dot+acc SQ  SkRowOp            (Sinkhorn-Knopp's pass)", 2, true, true, true, SkRowOp<T>, sk1, 2 * ncu);
+        ROWS2("L3 rows2 R2 2 dot 2 acc FusedIterOp logistic (the shipped C3 pass)", 2, 2, 2, FIL, flog, 3 * ncu);
+        ROWS2("L2 rows2 R2 2 dot 2 acc FusedIterOp logistic (two per CU)", 2, 2, 2, FIL, flog, 2 * ncu);
+        ROWS2("K3 rows2 R2 2 dot 2 acc FusedIterOp cheap", 2, 2, 2, FIC, fcheap, 3 * ncu);
+        ROWS2("K2 rows2 R2 2 dot 2 acc FusedIterOp cheap    (two per CU)", 2, 2, 2, FIC, fcheap, 2 * ncu);
+        ROWS2("H2 rows2 R2 2 dot 2 acc Sk2Op              (two per CU)", 2, 2, 2, Sk2Op<T>, sk2, 2 * ncu);
+        ROWS2DB("M2  db R1+next 2 dot 2 acc logistic  (two per CU, 168 regs)", 1, 2, 2, 3, FIL, flog, 2 * ncu);
+        ROWS2DB("M3  db R1+next 2 dot 2 acc logistic  (three per CU)", 1, 2, 2, 3, FIL, flog, 3 * ncu);
+        ROWS2DB("P2  db R2+next 2 dot 2 acc logistic  (two per CU, 256 regs)", 2, 2, 2, 2, FIL, flog, 2 * ncu);
+        ROWS2DB("P2c db R2+next 2 dot 2 acc cheap     (two per CU)", 2, 2, 2, 2, FIC, fcheap, 2 * ncu);
+        ROWS2DB("P2s db R2+next 2 dot 2 acc Sk2Op     (two per CU)", 2, 2, 2, 2, Sk2Op<T>, sk2, 2 * ncu);
+        ROWS2DB("P1  db R2+next 2 dot 2 acc logistic  (ONE per CU)", 2, 2, 2, 2, FIL, flog, 1 * ncu);
+        ROWS2DB("Q2  db R3+next 2 dot 2 acc logistic  (two per CU)", 3, 2, 2, 2, FIL, flog, 2 * ncu);
+        ROWS2DB("Q1  db R4+next 2 dot 2 acc logistic  (ONE per CU, 512 regs)", 4, 2, 2, 1, FIL, flog, 1 * ncu);
+        ROWS2DB("R2  db R2+next 1 dot 1 acc logistic  (lean, two per CU)", 2, 1, 1, 2, FIL, flog, 2 * ncu);
+      }
+    } else {
+      // C2's shape: 256 x 10, one row per step, two workgroups per CU
+      ROWS("A  rows  R2 dot+acc SQ  SkRowOp            (Sinkhorn-Knopp's pass)", 2, true, true, true, SkRowOp<T>, sk1, 2 * ncu);
+      ROWS2("K2 rows2 R1 2 dot 2 acc FusedIterOp cheap  (the shipped C2 pass)", 1, 2, 2, FIC, fcheap, 2 * ncu);
+      ROWS2("H2 rows2 R1 2 dot 2 acc Sk2Op", 1, 2, 2, Sk2Op<T>, sk2, 2 * ncu);
+      ROWS2("K1 rows2 R1 2 dot 2 acc FusedIterOp cheap  (one per CU)", 1, 2, 2, FIC, fcheap, 1 * ncu);
+      ROWS2DB("M2  db R1+next 2 dot 2 acc cheap     (two per CU, 256 regs)", 1, 2, 2, 2, FIC, fcheap, 2 * ncu);
+      ROWS2DB("M2s db R1+next 2 dot 2 acc Sk2Op     (two per CU)", 1, 2, 2, 2, Sk2Op<T>, sk2, 2 * ncu);
+      ROWS2DB("M1  db R1+next 2 dot 2 acc cheap     (ONE per CU)", 1, 2, 2, 2, FIC, fcheap, 1 * ncu);
+      ROWS2DB("P1  db R2+next 2 dot 2 acc cheap     (ONE per CU, 512 regs)", 2, 2, 2, 1, FIC, fcheap, 1 * ncu);
+      ROWS2DB("R2  db R1+next 1 dot 1 acc cheap     (lean, two per CU)", 1, 1, 1, 2, FIC, fcheap, 2 * ncu);
+    }
   }
+  for (auto &p : vec) CK(hipFree(p));
+  CK(hipFree(A)); CK(hipFree(xv)); CK(hipFree(x1)); CK(hipFree(h)); CK(hipFree(cp0)); CK(hipFree(cp1)); CK(hipFree(sp));
   return 0;
+}
+
+int main(int argc, char **argv) {
+  // c3_bisect [table] [reps]: 1 = the bisection between the two skeletons (C3's shape), 2 = what hides the functor at two
+  // workgroups per CU (C3's shape), 3 = the same question at C2's shape (256 x 10)
+  const int table = argc > 1 ? atoi(argv[1]) : 1, reps = argc > 2 ? atoi(argv[2]) : 15;
+  if (table == 3) return run<10>(100000, 10000, reps, table);
+  return run<5>(200000, 5000, reps, table);
 }

@@ -222,8 +222,7 @@ def test_two_process_rehearsal_of_the_launcher_path():
     starts them (`--nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`),
     both on cuda:0 -- RCCL refuses that, so the process group is gloo and the solver handles are joined by the test
     plug-in's shared-memory communicator (POGS_AMD_BENCH_REHEARSAL=1, tests/transport/test_transport.hip).  Runs at
-    a reduced shape through: rank environment, the 128-byte id broadcast (once per handle: the timed one, five
-    create / solve / destroy cycles, the exact-setup handle), per-rank shard generation, windows agreed by broadcast,
+    a reduced shape through: rank environment, the 128-byte id broadcast, per-rank shard generation, windows agreed by broadcast,
     max-over-ranks timing, the all-gather of the shards' checksums, rank 0's unsharded parity solve and CPU leg
     while rank 1 waits in long_barrier, and the assembly of the two output lines."""
     import socket
@@ -263,7 +262,7 @@ def test_two_process_rehearsal_of_the_launcher_path():
     cb = det["cpu_baseline"]
     assert cb["kind"] == "reference" and cb["value"] > 0 and "extrapolated" in cb, cb
     assert _close(cb["value"], cb["value_on_one_shard"] / 2) and "extrapolated" in sm["cpu_baseline"]
-    # five create / solve / destroy cycles, every one a fresh id broadcast and a fresh communicator
-    assert det["handle_cycles"]["n"] == 5 and det["exact_setup"]["status"] == 0
+    # (the N = 1 extras -- handle cycles, exact setup, one-shot host call -- are not part of an N > 1 line)
+    assert det["solve_status"] == 0 and det["config"]["solve_iterations"] == sm["solve_iterations"]
     print("two-process rehearsal: %.1f s wall" % wall)
     assert wall < 240.0, wall       # (about 40 s on a warm box; the bound only catches a hang-and-timeout path)
