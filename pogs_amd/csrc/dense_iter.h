@@ -23,6 +23,11 @@ void DenseSolver<T, Tag>::load_problem(const FnHost &f, const FnHost &g, const S
   pre_cheap_ = all_h(f, m_, [](int h) { return is_cheap_prox(h); }) && all_h(g, n_, [](int h) { return is_cheap_prox(h); });
   fused_now_ = fused_ok_ && (all_cheap || all_logistic);
   fused_logistic_ = fused_now_ && all_logistic && !all_cheap;
+#ifndef POGS_NV5_CHEAP_BPC   // (0: three per CU for every solve at 256 x 5, as before round 6 -- A / B builds)
+#define POGS_NV5_CHEAP_BPC 2
+#endif
+  planA_.bpc_override = (POGS_NV5_CHEAP_BPC > 0 && fused_now_ && !fused_logistic_ && !tmode_ && std::is_same<T, float>::value &&
+                         planA_.tpb == 256 && planA_.nv == 5) ? POGS_NV5_CHEAP_BPC : 0;
   // scaled copies: h and b shared with the originals (pogs.cpp:608-617)
   launch_scale_objective<T>(f_.view(), fs_.a.p, fs_.c.p, fs_.d.p, fs_.e.p, d_.p, m_, true, s);
   launch_scale_objective<T>(g_.view(), gs_.a.p, gs_.c.p, gs_.d.p, gs_.e.p, e_.p, n_, false, s);

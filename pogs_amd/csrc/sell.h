@@ -21,8 +21,9 @@
 //     adds its running sum to that row's sum in LDS and starts over.  A row lies in exactly one
 //     stream of a tile, so no two lanes ever touch the same sum (no atomics), and a row is summed
 //     in ascending column blocks and CSR order inside a block -- a fixed order.
-//     Rows are dealt to the streams longest first in serpentine order, which keeps the 512 stream
-//     lengths of a tile within one or two elements of each other (padding ~5 % at C4).
+//     Rows are dealt to the streams longest first, a row only to streams whose lane has the row's residue mod 32
+//     (round 6, sell_plan_kernel: the row-end flushes of a wavefront then never meet on an LDS bank), greedily onto the
+//     least loaded one: the 512 stream lengths of a tile stay within a batch of each other (padding ~6 % at C4).
 //   * bytes per non-zero: 4 (value) + 2 (local column) + 2 (tag) = the 8 of CSR (s + 4), no row
 //     offsets and no x traffic from HBM.
 //
@@ -201,6 +202,13 @@ __device__ __forceinline__ void sell_row_sums(const SellView<T> &A, const T *__r
 #endif
   constexpr bool kNoLds = (POGS_SELL_ABLATE & 1) != 0, kNoIds = (POGS_SELL_ABLATE & 2) != 0;
   auto consume = [&](const SellBatch<T, TWO> &B) {
+    // (an ablation must not shrink the load stream: the id pair / tags stay loaded even where nothing reads them -- the
+    // first form of these builds let the compiler drop that load, 1 of 7.35 bytes per element, and what it measured
+    // was the bytes: profiles/NOTES_r06.md section 5)
+    if constexpr (POGS_SELL_ABLATE != 0) {
+      if constexpr (TWO) asm volatile("" ::"v"(B.rr));
+      else asm volatile("" ::"v"(B.r[0]), "v"(B.r[UB - 1]));
+    }
     T xg[UB];
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
@@ -504,8 +512,7 @@ __global__ void __launch_bounds__(256) sell_count_kernel(const int *ind, const i
 
 // One workgroup (256 threads) per tile.  The non-empty rows are ordered by class -- rows longer
 // than 32 first, then lengths 32 down to 1, rows of a class in row order (a stable counting sort)
-// -- and dealt to the 512 streams in serpentine order (0..511, 511..0, ...), so every stream gets
-// one row of every "rank band" and the stream lengths come out nearly equal.  Outputs:
+// -- and dealt to the 512 streams bank-aware (below).  Outputs:
 // soff[tile * rr_rows + row] = stream << 23 | offset of the row in its stream, tile_nu[tile] =
 // 64-element units of the tile = 8 * K, K = longest stream rounded up to the batch size.
 // *err |= 4 if an offset does not fit its 23 bits (the caller then keeps the plain CSR kernel).
@@ -521,30 +528,44 @@ __global__ void __launch_bounds__(256) sell_count_kernel(const int *ind, const i
 // single-element rows they need a lot (the caller compares the two totals and takes the smaller
 // matrix).  *err |= 8: an offset of this layout does not fit 22 bits (the caller keeps the tags).
 constexpr int kSellClasses = kSellLmax + 2;   // 0 unused, 1..32, 33 = longer
+// Bank-aware dealing (round 6).  A row end is flushed into its row sum with a dependent LDS read-add-write of
+// s_y[local row]; a wavefront's 64 flushes of a batch position used to land on random banks, and those conflicts were
+// measured as 10 % of the SpMV (123.7 -> 111.6 us with them compiled out, profiles/NOTES_r06.md section 5).  The LDS
+// serves a 4-byte access in two groups of 32 lanes on 32 banks (8-byte: the same residues), so a flush is conflict-free
+// whenever every lane's row satisfies  local row mod 32 == lane mod 32  -- whatever the other lanes flush at that moment,
+// including the lanes of the flat flush that hit their own scratch word (RR + thread: the same residue).  The planner
+// therefore deals the rows of residue class q only to the 16 streams {8 wavefronts} x {lanes q, q + 32}:
+//   * rows in class order (long first), stably split by residue;
+//   * one lane per residue places its rows greedily on the least loaded of its 16 streams while the stream stays within
+//     the budget B = the tile's elements / 512, rounded up to a batch (at least the longest row); a row that does not fit
+//     goes to an overflow list (< 1 % of the rows at C4: the residue totals differ by a few per cent);
+//   * overflow rows go, first fit, to any stream with room (their flushes may conflict -- they are few).
+// A row's elements stay together, in order, in ONE lane's stream, so every row sum is added up exactly as before: the
+// assignment changes the layout, not a single bit of the results.
+constexpr int kSellResidues = 32;
+constexpr int kSellPerRes = kSellStreams / kSellResidues;   // 16 streams per residue
+constexpr int kSellOvfCap = 2048;
+constexpr int kSellFillCb = 1024;   // sell_fill_kernel: column blocks it keeps running counts for (unsorted rows)
+__device__ __forceinline__ int sell_res_stream(int q, int j) { return (j >> 1) * 64 + q + 32 * (j & 1); }
+constexpr size_t sell_plan_lds(int rr_rows) { return 3 * static_cast<size_t>(rr_rows) * sizeof(unsigned short); }
 __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cnt, SellDims D, int *tile_nu,
                                                         unsigned *soff, int *tile_nu2, unsigned *soff2, int *err) {
-  extern __shared__ unsigned short s_sorted[];           // [rr_rows]: rows in dealing order
-  __shared__ unsigned short s_hist[kSellClasses][256];   // per thread and class: rows, then their exclusive prefix
+  extern __shared__ unsigned short s_dyn[];               // three arrays of rr_rows entries
+  unsigned short *s_sorted = s_dyn;                       // rows in class order; later (stream << 7 | position) per ROW
+  unsigned short *s_xrow = s_dyn + D.rr_rows;             // rows split by residue; later the rows by stream
+  unsigned short *s_xlen = s_dyn + 2 * D.rr_rows;         // their lengths
+  unsigned short *s_sp = s_sorted, *s_by = s_xrow;
+  __shared__ unsigned short s_hist[kSellClasses][256];    // per thread and class (then residue): entries, then their exclusive prefix
   __shared__ int s_tot[kSellClasses], s_cbase[kSellClasses];
-  __shared__ int s_max[4], s_max2[4];
+  __shared__ int s_max[4], s_max2[4], s_sum[4];
+  __shared__ int s_load[kSellStreams], s_start[kSellStreams + 1];
+  __shared__ unsigned short s_cnt[kSellStreams], s_ovf[kSellOvfCap];
+  __shared__ int s_novf, s_budget;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int rpt = (D.rr_rows + 255) / 256;               // consecutive rows per thread
-  for (int tile = blockIdx.x; tile < D.nrr * D.ncb; tile += gridDim.x) {
-    const int rr = tile / D.ncb;
-    const int nr = min(D.rr_rows, D.nrows - rr * D.rr_rows);
-    const unsigned short *tc = cnt + static_cast<size_t>(tile) * D.rr_rows;
-    unsigned *to = soff + static_cast<size_t>(tile) * D.rr_rows;
-    unsigned *to2 = soff2 ? soff2 + static_cast<size_t>(tile) * D.rr_rows : nullptr;
-    for (int c = 0; c < kSellClasses; ++c) s_hist[c][t] = 0;
-    const int r_lo = t * rpt, r_hi = min(nr, r_lo + rpt);
-    for (int r = r_lo; r < r_hi; ++r) {
-      const int len = tc[r];
-      if (len == 0) continue;
-      s_hist[len <= kSellLmax ? len : kSellLmax + 1][t] += 1;
-    }
-    __syncthreads();
-    // exclusive scans over the 256 threads: one wavefront per class (4 entries per lane)
-    for (int c = 1 + wave; c < kSellClasses; c += 4) {
+  // exclusive scans of s_hist[c][0..255] for c = c0, c0 + 1, ..., c1 - 1: one wavefront per c (4 entries per lane)
+  auto scan_hist = [&](int c0, int c1) {
+    for (int c = c0 + wave; c < c1; c += 4) {
       int v[4], sum = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -565,6 +586,32 @@ __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cn
       }
       if (lane == 63) s_tot[c] = inc;
     }
+  };
+  for (int tile = blockIdx.x; tile < D.nrr * D.ncb; tile += gridDim.x) {
+    const int rr = tile / D.ncb;
+    const int nr = min(D.rr_rows, D.nrows - rr * D.rr_rows);
+    const unsigned short *tc = cnt + static_cast<size_t>(tile) * D.rr_rows;
+    unsigned *to = soff + static_cast<size_t>(tile) * D.rr_rows;
+    unsigned *to2 = soff2 ? soff2 + static_cast<size_t>(tile) * D.rr_rows : nullptr;
+    for (int c = 0; c < kSellClasses; ++c) s_hist[c][t] = 0;
+    const int r_lo = t * rpt, r_hi = min(nr, r_lo + rpt);
+    int my_sum = 0, my_max = 0;
+    for (int r = r_lo; r < r_hi; ++r) {
+      const int len = tc[r];
+      if (len == 0) continue;
+      s_hist[len <= kSellLmax ? len : kSellLmax + 1][t] += 1;
+      my_sum += len;
+      my_max = max(my_max, len);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      my_sum += __shfl_xor(my_sum, off, 64);
+      my_max = max(my_max, __shfl_xor(my_max, off, 64));
+    }
+    if (lane == 0) { s_sum[wave] = my_sum; s_max[wave] = my_max; }
+    if (t == 0) s_novf = 0;
+    for (int i = t; i < kSellStreams; i += 256) { s_load[i] = 0; s_cnt[i] = 0; }
+    __syncthreads();
+    scan_hist(1, kSellClasses);
     __syncthreads();
     if (t == 0) {
       int b = 0;
@@ -573,6 +620,10 @@ __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cn
         b += s_tot[c];
       }
       s_cbase[0] = b;   // non-empty rows of the tile
+      const int total = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+      const int lmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+      const int mean = (total + kSellStreams - 1) / kSellStreams;
+      s_budget = (max(mean, lmax) + kSellUB - 1) / kSellUB * kSellUB;
     }
     __syncthreads();
     {
@@ -591,18 +642,145 @@ __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cn
     }
     __syncthreads();
     const int nne = s_cbase[0];
+    // ---- the class-ordered rows, stably split by residue (local row mod 32): a counting sort over chunks of the list
+    const int cpt = (nne + 255) / 256;
+    const int k_lo = min(nne, t * cpt), k_hi = min(nne, k_lo + cpt);
+    for (int q = 0; q < kSellResidues; ++q) s_hist[q][t] = 0;
+    for (int k = k_lo; k < k_hi; ++k) s_hist[s_sorted[k] & (kSellResidues - 1)][t] += 1;
+    __syncthreads();
+    scan_hist(0, kSellResidues);
+    __syncthreads();
+    if (t == 0) {
+      int b = 0;
+      for (int q = 0; q < kSellResidues; ++q) {
+        s_cbase[q] = b;
+        b += s_tot[q];
+      }
+      s_cbase[kSellResidues] = b;
+    }
+    __syncthreads();
+    {
+      int rank[kSellResidues];
+#pragma unroll
+      for (int q = 0; q < kSellResidues; ++q) rank[q] = 0;
+      for (int k = k_lo; k < k_hi; ++k) {
+        const int r = s_sorted[k], q = r & (kSellResidues - 1);
+        const int d = s_cbase[q] + s_hist[q][t] + rank[q];
+        rank[q] += 1;
+        s_xrow[d] = static_cast<unsigned short>(r);
+        s_xlen[d] = tc[r];
+      }
+    }
+    __syncthreads();
+    // ---- one lane per residue: greedy placement on its 16 streams (loads and counts in registers, static indexing)
+    if (t < kSellResidues) {
+      const int q = t, B = s_budget;
+      int ld[kSellPerRes], cn[kSellPerRes];
+#pragma unroll
+      for (int j = 0; j < kSellPerRes; ++j) { ld[j] = 0; cn[j] = 0; }
+      for (int k = s_cbase[q]; k < s_cbase[q + 1]; ++k) {
+        const int r = s_xrow[k], len = s_xlen[k];
+        int best = ld[0], bj = 0;
+#pragma unroll
+        for (int j = 1; j < kSellPerRes; ++j) {
+          const bool lt = ld[j] < best;
+          best = lt ? ld[j] : best;
+          bj = lt ? j : bj;
+        }
+        int pos = 0;
+#pragma unroll
+        for (int j = 0; j < kSellPerRes; ++j) pos = (j == bj) ? cn[j] : pos;
+        if (best + len <= B && pos < 127) {
+#pragma unroll
+          for (int j = 0; j < kSellPerRes; ++j) {
+            ld[j] += (j == bj) ? len : 0;
+            cn[j] += (j == bj) ? 1 : 0;
+          }
+          s_sp[r] = static_cast<unsigned short>((sell_res_stream(q, bj) << 7) | pos);
+        } else {
+          const int o = atomicAdd(&s_novf, 1);
+          if (o < kSellOvfCap) {
+            s_ovf[o] = static_cast<unsigned short>(r);
+          } else {   // (list full: a pathological tile) the row stays with its residue, over the budget
+#pragma unroll
+            for (int j = 0; j < kSellPerRes; ++j) {
+              ld[j] += (j == bj) ? len : 0;
+              cn[j] += (j == bj) ? 1 : 0;
+            }
+            s_sp[r] = static_cast<unsigned short>((sell_res_stream(q, bj) << 7) | min(pos, 127));
+            if (pos >= 127) atomicOr(err, 4);   // cannot be laid out: the caller keeps the plain kernel
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kSellPerRes; ++j) {
+        s_load[sell_res_stream(q, j)] = ld[j];
+        s_cnt[sell_res_stream(q, j)] = static_cast<unsigned short>(cn[j]);
+      }
+    }
+    __syncthreads();
+    // ---- overflow rows: first fit, a cursor going round the streams; nothing fits -> the least loaded stream
+    if (t == 0) {
+      const int novf = min(s_novf, kSellOvfCap), B = s_budget;
+      int cur = 0;
+      for (int o = 0; o < novf; ++o) {
+        const int r = s_ovf[o], len = tc[r];
+        int pick = -1;
+        for (int step = 0; step < kSellStreams; ++step) {
+          const int sidx = (cur + step) & (kSellStreams - 1);
+          if (s_load[sidx] + len <= B && s_cnt[sidx] < 127) { pick = sidx; break; }
+        }
+        if (pick < 0) {
+          int best = 0x7fffffff;
+          for (int sidx = 0; sidx < kSellStreams; ++sidx)
+            if (s_cnt[sidx] < 127 && s_load[sidx] < best) { best = s_load[sidx]; pick = sidx; }
+        }
+        if (pick < 0) { atomicOr(err, 4); pick = 0; }
+        cur = (pick + 1) & (kSellStreams - 1);
+        s_sp[r] = static_cast<unsigned short>((pick << 7) | min(static_cast<int>(s_cnt[pick]), 127));
+        s_load[pick] += len;
+        s_cnt[pick] += 1;
+      }
+    }
+    __syncthreads();
+    // ---- rows by stream: exclusive prefix of the counts (one wavefront, 8 streams per lane), then every row to its place
+    if (wave == 0) {
+      int v[8], sum = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        v[q] = s_cnt[lane * 8 + q];
+        sum += v[q];
+      }
+      int inc = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+      }
+      int run = inc - sum;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        s_start[lane * 8 + q] = run;
+        run += v[q];
+      }
+      if (lane == 63) s_start[kSellStreams] = inc;
+    }
+    __syncthreads();
+    for (int r = r_lo; r < r_hi; ++r) {
+      if (tc[r] == 0) continue;
+      const int sp = s_sp[r];
+      s_by[s_start[sp >> 7] + (sp & 127)] = static_cast<unsigned short>(r);
+    }
+    __syncthreads();
     int longest = 0, longest2 = 0;
     for (int sidx = t; sidx < kSellStreams; sidx += 256) {
-      auto kof = [&](int p) { return p * kSellStreams + ((p & 1) ? kSellStreams - 1 - sidx : sidx); };
-      int run = 0, np = 0;   // np: rows of this stream (only the last pass can miss one)
-      for (int p = 0; p * kSellStreams < nne; ++p) {
-        const int k = kof(p);
-        if (k >= nne) continue;
-        const int r = s_sorted[k];
+      const int base = s_start[sidx], np = s_start[sidx + 1] - base;   // this stream's rows: s_by[base .. base + np), long first
+      int run = 0;
+      for (int p = 0; p < np; ++p) {
+        const int r = s_by[base + p];
         if (run >= (1 << kSellOffBits)) atomicOr(err, 4);
         to[r] = (static_cast<unsigned>(sidx) << kSellOffBits) | static_cast<unsigned>(run & ((1 << kSellOffBits) - 1));
         run += tc[r];
-        ++np;
       }
       longest = max(longest, run);
       if (to2) {
@@ -610,8 +788,8 @@ __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cn
         int i = 0, j = np - 1, pos = 0, ends = 0;   // front (long rows), back (short rows), stream position, ends in its batch
         int ri = 0, li = 0, rj = 0, lj = 0;
         if (np > 0) {
-          ri = s_sorted[kof(0)]; li = tc[ri];
-          rj = s_sorted[kof(j)]; lj = tc[rj];
+          ri = s_by[base]; li = tc[ri];
+          rj = s_by[base + j]; lj = tc[rj];
         }
         while (i <= j) {
           const int slot = pos & 3;
@@ -621,11 +799,11 @@ __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cn
           if (ends < 2 && lj <= left) {          // a short row that ends inside this batch
             r = rj; len = lj;
             --j;
-            if (i <= j) { rj = s_sorted[kof(j)]; lj = tc[rj]; }
-          } else if (ends < 2 || li > left) {    // the longest one left: li >= lj > left, it ends in a later batch
+            if (i <= j) { rj = s_by[base + j]; lj = tc[rj]; }
+          } else if (ends < 2 || li > left) {    // the front row: it ends in a later batch, or this batch has room for its end
             r = ri; len = li;
             ++i;
-            if (i <= j) { ri = s_sorted[kof(i)]; li = tc[ri]; }
+            if (i <= j) { ri = s_by[base + i]; li = tc[ri]; }
           } else {                               // two ends and nothing leaves the batch: zeros up to its boundary
             pos += left;
             continue;
@@ -646,6 +824,7 @@ __global__ void __launch_bounds__(256) sell_plan_kernel(const unsigned short *cn
       longest = max(longest, __shfl_xor(longest, off, 64));
       longest2 = max(longest2, __shfl_xor(longest2, off, 64));
     }
+    __syncthreads();   // (s_max was read for the budget)
     if (lane == 0) { s_max[wave] = longest; s_max2[wave] = longest2; }
     __syncthreads();
     if (t == 0) {
@@ -672,7 +851,12 @@ __global__ void __launch_bounds__(256) sell_fill_kernel(const T *val, const int 
                                                         const unsigned short *cnt, const unsigned *soff, const int *tile_unit,
                                                         T *sval, unsigned short *sloc, unsigned short *srid, unsigned *dst_out,
                                                         int two) {
-  const int lane = threadIdx.x & 63;
+  // (rows whose column blocks are NOT in order -- an unsorted input: one running count per column block and wavefront in
+  // LDS, the row taken 64 non-zeros at a time: an element's position is the count so far plus its rank among the lower
+  // lanes of its chunk with the same block.  Linear in the row's length; the count over the row's prefix it replaces
+  // was quadratic, minutes for a row of 1e5 unsorted non-zeros.  More than kSellFillCb column blocks: the prefix count.)
+  __shared__ int s_run[4][kSellFillCb];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int w = static_cast<int>((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nw = static_cast<int>((gridDim.x * blockDim.x) >> 6);
   for (int r = w; r < D.nrows; r += nw) {
     const int rr = r / D.rr_rows, lr = r - rr * D.rr_rows;
@@ -680,16 +864,34 @@ __global__ void __launch_bounds__(256) sell_fill_kernel(const T *val, const int 
     bool mono = true;
     for (int k = p0 + 1 + lane; k < p1; k += 64) mono = mono && (ind[k] / D.bw >= ind[k - 1] / D.bw);
     mono = __all(mono);
-    for (int k = p0 + lane; k < p1; k += 64) {
-      const int c = ind[k], cb = c / D.bw;
+    const bool counted = !mono && D.ncb <= kSellFillCb;
+    if (counted)
+      for (int q = lane; q < D.ncb; q += 64) s_run[wv][q] = 0;
+    for (int k0 = p0; k0 < p1; k0 += 64) {   // (uniform trip count: the whole wavefront takes part in the shuffles)
+      const int k = k0 + lane;
+      const bool have = k < p1;
+      const int c = have ? ind[k] : 0, cb = have ? c / D.bw : -1;
       int j = 0;
       if (mono) {
-        int kk = k;
-        while (kk > p0 && ind[kk - 1] / D.bw == cb) --kk;
-        j = k - kk;
-      } else {
+        if (have) {
+          int kk = k;
+          while (kk > p0 && ind[kk - 1] / D.bw == cb) --kk;
+          j = k - kk;
+        }
+      } else if (counted) {
+        int rank = 0, tot = 0;
+        for (int l = 0; l < 64; ++l) {
+          const int ocb = __shfl(cb, l, 64);
+          rank += (l < lane && ocb == cb) ? 1 : 0;
+          tot += (ocb == cb) ? 1 : 0;
+        }
+        const int base = have ? s_run[wv][cb] : 0;
+        j = base + rank;
+        if (have && rank == tot - 1) s_run[wv][cb] = base + tot;   // (the last lane of each block's group: one writer per word)
+      } else if (have) {
         for (int q = p0; q < k; ++q) j += (ind[q] / D.bw == cb) ? 1 : 0;
       }
+      if (!have) continue;
       const int tile = rr * D.ncb + cb;
       const size_t idx = static_cast<size_t>(tile) * D.rr_rows + lr;
       const unsigned so = soff[idx];

@@ -870,9 +870,9 @@ class SparseSolver final : public SolverBase {
     const int gt = static_cast<int>(std::min<long long>(ntiles, ctx_.num_cu * 8));
     {
       static SmemGrants grants;   // (row ranges taller than 23 K rows: static + dynamic LDS of the planner pass 64 KB)
-      ensure_dynamic_smem(reinterpret_cast<const void *>(&sell_plan_kernel), rr_rows * sizeof(unsigned short) + 20480, grants);
+      ensure_dynamic_smem(reinterpret_cast<const void *>(&sell_plan_kernel), sell_plan_lds(rr_rows) + 32768, grants);
     }
-    hipLaunchKernelGGL(sell_plan_kernel, dim3(gt), dim3(256), rr_rows * sizeof(unsigned short), s, M.scnt.p, D, nu.p,
+    hipLaunchKernelGGL(sell_plan_kernel, dim3(gt), dim3(256), sell_plan_lds(rr_rows), s, M.scnt.p, D, nu.p,
                        M.ssoff.p, nu2.p, soff2.p, err.p);
     exclusive_scan(nu.p, static_cast<int>(ntiles), M.tile_unit.p);
     int tot = 0, tot2 = 0, herr = 0;

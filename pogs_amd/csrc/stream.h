@@ -74,6 +74,11 @@ struct StreamPlan {
   // columns each) -- column sums window-wise, row dots as partial dots that a small kernel adds
   // before the row functor runs; a fused row-dot + column-sum pass becomes those two in turn
   bool xl = false;
+  // one-pass kernel (ND > 0): workgroups per CU of the NEXT launches when > 0 -- the solver sets it per solve
+  // (dense_iter.h: load_problem).  At 256 x 5 the kernel is built for three per CU, which the logistic row functor
+  // needs (its serial chain is exposed at two: 0.76 against 0.63 ms per pass at C3) and which by itself costs 8 %:
+  // solves whose prox is a few operations run two per CU (0.622 against 0.655 ms; profiles/NOTES_r06.md section 4)
+  int bpc_override = 0;
 };
 template <typename T> inline int stream_window_cols(const StreamPlan &p) { return p.tpb * p.nv * Vec16<T>::N; }
 template <typename T> inline int stream_windows(const StreamPlan &p, int n_pad) {
@@ -962,7 +967,9 @@ template <int ND, int NA = 2>
 inline int stream2_grid(const StreamPlan &p, int m) {
   const int R = stream2_rows<ND, NA>(p);
   const int nblk = (m + R - 1) / R;
-  const int gmax = ND > 0 ? (p.tpb == 256 && p.num_cu > 0 ? p.num_cu * stream2_blocks_per_cu(256, p.nv, ND, NA) : p.grid_max)
+  const int gmax = ND > 0 ? (p.tpb == 256 && p.num_cu > 0
+                                 ? p.num_cu * (p.bpc_override > 0 ? p.bpc_override : stream2_blocks_per_cu(256, p.nv, ND, NA))
+                                 : p.grid_max)
                           : p.grid_dot;   // (the column-sum-only form keeps the two-per-CU grid)
   return nblk < gmax ? (nblk > 0 ? nblk : 1) : gmax;
 }

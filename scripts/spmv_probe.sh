@@ -8,7 +8,7 @@ cp $R/pogs_amd/libpogs_amd.so /tmp/orig.so
 for tagenv in "$@"; do
   tag=${tagenv%%:*}; envs=${tagenv#*:}; [ "$envs" = "$tagenv" ] && envs=""
   envs=$(echo $envs | tr ":" " ")
-  cp $R/pogs_amd/variants/libpogs_amd_$tag.so $R/pogs_amd/libpogs_amd.so
+  if [ "$tag" = base ]; then cp /tmp/orig.so $R/pogs_amd/libpogs_amd.so; else cp $R/pogs_amd/variants/libpogs_amd_$tag.so $R/pogs_amd/libpogs_amd.so; fi
   rm -rf /tmp/kt_$tag
   env $envs timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt_$tag -o p -- python $R/scripts/spmv_probe.py > $R/gpurun_out/probe/$tag.log 2>&1
   db=$(find /tmp/kt_$tag -name "*.db" | head -1)
