@@ -786,165 +786,6 @@ __global__ void __launch_bounds__(TPB, (ND > 0 ? stream2_waves_per_simd(TPB, NV,
   }
 }
 
-// ---------------------------------------------------------------------------
-// stream_rows2_db_kernel: the one-pass iteration kernel with ONE row per step and the NEXT row in flight.
-// At 256 x 5 (rows of <= 1280 vectors: C3) stream_rows2_kernel takes two rows per step and holds them through
-// dot -> barrier -> row functor (one lane per row) -> barrier -> column sums before it asks for the next two:
-// every workgroup's loads stop for the length of that chain, and at this row length nothing else on the CU
-// covers it (the pass ran at 0.77 of the data-sheet peak where Sinkhorn-Knopp's pass over the same matrix,
-// the same skeleton with a three-instruction functor, reaches 0.86).  Here the register tile is the same size
-// -- two rows -- but they are consecutive STEPS: row k + 1 (and its functor operands) is requested before row
-// k is reduced, so the chain of row k runs under the load of row k + 1.  Same arithmetic per row, same
-// round-robin dealing of rows to workgroups (row = blockIdx.x + k gridDim.x): the column partials of a workgroup
-// add the same rows in the same order as a two-row step's did only when the grid is the same, so results are
-// compared through the usual tolerances, not bit for bit (the second stage's partial count changes with R).
-// ---------------------------------------------------------------------------
-#ifndef POGS_STREAM2_DB   // 1: use it where stream2_db_c says (experiment switch until measured)
-#define POGS_STREAM2_DB 0
-#endif
-constexpr bool stream2_db_c(int nd, int nv) { return POGS_STREAM2_DB != 0 && nd > 0 && nv == 5; }
-
-// R rows per step (the tile in flight is R rows too); BPC: workgroups per CU the register budget is held to
-template <typename T, int TPB, int NV, int R, int ND, int NA, int BPC, typename Op>
-__global__ void __launch_bounds__(TPB, (BPC * (TPB / 64) + 3) / 4) stream_rows2_db_kernel(StreamArgs2<T> a, Op op) {
-  using V = typename Vec16<T>::type;
-  using Pre = typename Op::Pre;
-  constexpr int VEC = Vec16<T>::N;
-  constexpr int NW = TPB / 64;
-  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
-  static_assert(ND > 0, "the column-sum-only form has no chain to hide");
-  __shared__ T s_part[2 * R * ND * NW];
-  __shared__ T s_u[2 * R * NA];
-  __shared__ double s_red[NS * NW];
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-  T *s_x1 = reinterpret_cast<T *>(s_dyn);
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-
-  V xv[NV];
-  V acc[NA][NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int col = (v * TPB + t) * VEC;
-    xv[v] = (col < a.n_pad) ? *reinterpret_cast<const V *>(a.xin0 + col) : dev::vzero<V>();
-    if (ND > 1 && col < a.n_pad) *reinterpret_cast<V *>(s_x1 + col) = *reinterpret_cast<const V *>(a.xin1 + col);
-  }
-  if (ND > 1) __syncthreads();
-#pragma unroll
-  for (int q = 0; q < NA; ++q)
-#pragma unroll
-    for (int v = 0; v < NV; ++v) acc[q][v] = dev::vzero<V>();
-  double sacc[NS];
-#pragma unroll
-  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
-
-  const int nblk = (a.m + R - 1) / R;
-  int blk = blockIdx.x;
-  V cur[R][NV];
-  Pre pre_cur;
-  if (t < R && blk < nblk && blk * R + t < a.m) pre_cur = op.prefetch(blk * R + t);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int row = blk * R + r;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int col = (v * TPB + t) * VEC;
-      cur[r][v] = (col < a.n_pad && blk < nblk && row < a.m) ? stream_load<V>(a.A + static_cast<size_t>(row) * a.lda + col)
-                                                              : dev::vzero<V>();
-    }
-  }
-  int slot = 0;
-  for (; blk < nblk; blk += gridDim.x, slot ^= 1) {
-    const int row0 = blk * R;
-    // the next tile of this workgroup and its functor's operands: requested first (the functor's operands before
-    // the tile, so that waiting for them next step does not wait for anything younger)
-    const int nblk_ = blk + gridDim.x, nrow0 = nblk_ * R;
-    Pre pre_nxt;
-    if (t < R && nblk_ < nblk && nrow0 + t < a.m) pre_nxt = op.prefetch(nrow0 + t);
-    V nxt[R][NV];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int row = nrow0 + r;
-      const T *rp = a.A + static_cast<size_t>(row) * a.lda;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int col = (v * TPB + t) * VEC;
-        nxt[r][v] = (col < a.n_pad && nblk_ < nblk && row < a.m) ? stream_load<V>(rp + col) : dev::vzero<V>();
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      T s0 = 0, s1 = 0;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        s0 += dev::vdot(cur[r][v], xv[v]);
-        if (ND > 1) {
-          const int col = (v * TPB + t) * VEC;
-          if (col < a.n_pad) s1 += dev::vdot(cur[r][v], *reinterpret_cast<const V *>(s_x1 + col));
-        }
-      }
-      s0 = dev::wave_sum(s0);
-      if (ND > 1) s1 = dev::wave_sum(s1);
-      if (lane == 0) {
-        s_part[((slot * R + r) * ND + 0) * NW + wave] = s0;
-        if (ND > 1) s_part[((slot * R + r) * ND + 1) * NW + wave] = s1;
-      }
-    }
-    __syncthreads();
-    if (t < R) {
-      const int row = row0 + t;
-      T uu[NA];
-#pragma unroll
-      for (int q = 0; q < NA; ++q) uu[q] = 0;
-      if (row < a.m) {
-        T dots[ND];
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-          T s = 0;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) s += s_part[((slot * R + t) * ND + d) * NW + w];
-          dots[d] = s;
-        }
-        op.row(row, pre_cur, dots, sacc, uu);
-      }
-#pragma unroll
-      for (int q = 0; q < NA; ++q) s_u[(slot * R + t) * NA + q] = uu[q];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      T uu[NA];
-#pragma unroll
-      for (int q = 0; q < NA; ++q) uu[q] = s_u[(slot * R + r) * NA + q];
-#pragma unroll
-      for (int q = 0; q < NA; ++q)
-#pragma unroll
-        for (int v = 0; v < NV; ++v) dev::vfma(acc[q][v], uu[q], cur[r][v]);
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int v = 0; v < NV; ++v) cur[r][v] = nxt[r][v];
-    pre_cur = pre_nxt;
-  }
-#pragma unroll
-  for (int q = 0; q < NA; ++q) {
-    T *out = (q == 0 ? a.col_partials0 : a.col_partials1) + static_cast<size_t>(blockIdx.x) * a.n_pad;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int col = (v * TPB + t) * VEC;
-      if (col < a.n_pad) *reinterpret_cast<V *>(out + col) = acc[q][v];
-    }
-  }
-  if (Op::NS > 0) {
-    __syncthreads();
-    dev::block_sum<NS, TPB>(sacc, s_red);
-    if (t == 0) {
-#pragma unroll
-      for (int k = 0; k < NS; ++k) a.scalar_partials[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
-    }
-  }
-}
-
 // Whether the two-dot / two-accumulator kernel fits the register file for this plan
 // (row tile 4*R*NV + 2 x vectors 8*NV + 2 accumulators 8*NV VGPRs, R = 1).
 inline bool stream2_supported(const StreamPlan &p) {
@@ -958,7 +799,7 @@ inline bool stream2_supported(const StreamPlan &p) {
 // (one dot product and one accumulator -- the pass without the exact residuals -- leave room for a
 // second row at 8 .. 10 vectors per thread: 4*NV*(R + 1 + 1) + ~70)
 constexpr int stream2_rows_c(int nd, int nv, int na = 2) {
-  return stream2_db_c(nd, nv) ? 1 : nd > 0 ? ((nd == 1 && na == 1 && nv > 8) ? 2 : (nv <= 2 ? 8 : nv <= 4 ? 4 : nv == 5 ? 2 : nv <= 6 ? 3 : nv <= 8 ? 2 : 1))
+  return nd > 0 ? ((nd == 1 && na == 1 && nv > 8) ? 2 : (nv <= 2 ? 8 : nv <= 4 ? 4 : nv == 5 ? 2 : nv <= 6 ? 3 : nv <= 8 ? 2 : 1))
                 : (nv <= 4 ? 8 : nv <= 8 ? 4 : 2);
 }
 template <int ND, int NA = 2>
@@ -983,12 +824,6 @@ void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, 
   if (p.tpb == TPB_ && p.nv == NV_) {                                                           \
     constexpr int R_ = stream2_rows_c(ND, NV_, NA);                                             \
     const size_t lds = (ND > 1) ? static_cast<size_t>(a.n_pad) * sizeof(T) : 0;                 \
-    if constexpr (stream2_db_c(ND, NV_)) {                                                      \
-      static SmemGrants grants_db;                                                              \
-      ensure_dynamic_smem(reinterpret_cast<const void *>(&stream_rows2_db_kernel<T, TPB_, NV_, 1, ND, NA, 3, Op>), lds, grants_db); \
-      hipLaunchKernelGGL((stream_rows2_db_kernel<T, TPB_, NV_, 1, ND, NA, 3, Op>), dim3(grid), dim3(TPB_), lds, s, a, op); \
-      return;                                                                                   \
-    }                                                                                           \
     static SmemGrants grants;   /* per device; concurrent solvers share it */                   \
     ensure_dynamic_smem(reinterpret_cast<const void *>(&stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>), lds, grants); \
     hipLaunchKernelGGL((stream_rows2_kernel<T, TPB_, NV_, R_, ND, NA, Op>), dim3(grid),         \

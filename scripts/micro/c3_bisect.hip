@@ -2,7 +2,7 @@
 // vectors): Sinkhorn-Knopp's pass (stream_rows_kernel, 0.58 ms) and the one-pass iteration kernel
 // (stream_rows2_kernel, 0.63-0.65 ms).  Timing only: the kernels are the library's own templates (csrc/stream.h,
 // csrc/ops.h), instantiated here with functors that morph one into the other one element at a time.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I pogs_amd/csrc scripts/micro/c3_bisect.hip -o scripts/micro/bin/c3_bisect
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I pogs_amd/csrc -I scripts/micro scripts/micro/c3_bisect.hip -o scripts/micro/bin/c3_bisect
 //   scripts/micro/bin/c3_bisect [m n reps]
 #include <hip/hip_runtime.h>
 
@@ -14,6 +14,7 @@
 
 #include "ops.h"
 #include "stream.h"
+#include "stream_experiments.h"   // the prefetching and the functor-wavefront forms: measured, not shipped
 
 using namespace pogs_amd;
 
@@ -186,10 +187,36 @@ int run(int m, int n, int reps, int table) {
     report(NAME, g, regs_of(k), tm.run([&] { hipLaunchKernelGGL(k, dim3(g), dim3(TPB), l, 0, a2, OP); }, reps)); \
   }
 
+#define ROWS2FW(NAME, R, ND, NA, BPC, OPT, OP, GRID)                                                            \
+  {                                                                                                             \
+    auto k = stream_rows2_fw_kernel<T, TPB, NV, R, ND, NA, BPC, OPT>;                                            \
+    const int g = (GRID);                                                                                       \
+    const size_t l = stream2_fw_lds<T>(n_pad, TPB, NV, R, ND);                                                  \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(l))); \
+    int occ_ = 0;                                                                                               \
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_, k, TPB + kFwThreads, l));                            \
+    printf("   (runtime's occupancy for the next line: %d workgroups per CU, %zu B of dynamic LDS)\n", occ_, l);  \
+    report(NAME, g, regs_of(k), tm.run([&] { hipLaunchKernelGGL(k, dim3(g), dim3(TPB + kFwThreads), l, 0, a2, OP); }, reps)); \
+  }
+
   for (int round = 0; round < 2; ++round) {
     printf("---- round %d\n", round);
     if constexpr (NV == 5) {
-      if (table == 1) {
+      if (table == 4) {
+        // table 4: the functor on a wavefront of its own, the column sums one step late (stream_rows2_fw_kernel)
+        ROWS("A  rows  R2 dot+acc SQ  SkRowOp            (Sinkhorn-Knopp's pass)", 2, true, true, true, SkRowOp<T>, sk1, 2 * ncu);
+        ROWS2("H2 rows2 R2 2 dot 2 acc Sk2Op              (two per CU)", 2, 2, 2, Sk2Op<T>, sk2, 2 * ncu);
+        ROWS2("L3 rows2 R2 2 dot 2 acc FusedIterOp logistic (the shipped C3 pass)", 2, 2, 2, FIL, flog, 3 * ncu);
+        ROWS2("K2 rows2 R2 2 dot 2 acc FusedIterOp cheap    (two per CU: shipped for lasso-type since round 6)", 2, 2, 2, FIC, fcheap, 2 * ncu);
+        ROWS2FW("W2  fw R2 2 dot 2 acc logistic  (two per CU)", 2, 2, 2, 2, FIL, flog, 2 * ncu);
+        ROWS2FW("W2c fw R2 2 dot 2 acc cheap     (two per CU)", 2, 2, 2, 2, FIC, fcheap, 2 * ncu);
+        ROWS2FW("W2s fw R2 2 dot 2 acc Sk2Op     (two per CU)", 2, 2, 2, 2, Sk2Op<T>, sk2, 2 * ncu);
+        ROWS2FW("X2  fw R1 2 dot 2 acc logistic  (two per CU)", 1, 2, 2, 2, FIL, flog, 2 * ncu);
+        ROWS2FW("X3  fw R1 2 dot 2 acc logistic  (three per CU)", 1, 2, 2, 3, FIL, flog, 3 * ncu);
+        ROWS2FW("X4  fw R1 2 dot 2 acc logistic  (four per CU)", 1, 2, 2, 4, FIL, flog, 4 * ncu);
+        ROWS2FW("Y2  fw R3 2 dot 2 acc logistic  (two per CU)", 3, 2, 2, 2, FIL, flog, 2 * ncu);
+        ROWS2FW("W2l fw R2 1 dot 1 acc logistic  (lean, two per CU)", 2, 1, 1, 2, FIL, flog, 2 * ncu);
+      } else if (table == 1) {
         ROWS("A  rows  R2 dot+acc SQ  SkRowOp            (Sinkhorn-Knopp's pass)", 2, true, true, true, SkRowOp<T>, sk1, 2 * ncu);
         ROWS("B  rows  R2 dot+acc     SkRowOp            (no squaring)", 2, true, true, false, SkRowOp<T>, sk1, 2 * ncu);
         ROWS("B3 rows  R2 dot+acc     SkRowOp            (three per CU)", 2, true, true, false, SkRowOp<T>, sk1, 3 * ncu);
@@ -251,7 +278,7 @@ int run(int m, int n, int reps, int table) {
 
 int main(int argc, char **argv) {
   // c3_bisect [table] [reps]: 1 = the bisection between the two skeletons (C3's shape), 2 = what hides the functor at two
-  // workgroups per CU (C3's shape), 3 = the same question at C2's shape (256 x 10)
+  // workgroups per CU (C3's shape), 3 = the same question at C2's shape (256 x 10), 4 = the functor wavefront (C3's shape)
   const int table = argc > 1 ? atoi(argv[1]) : 1, reps = argc > 2 ? atoi(argv[2]) : 15;
   if (table == 3) return run<10>(100000, 10000, reps, table);
   return run<5>(200000, 5000, reps, table);
