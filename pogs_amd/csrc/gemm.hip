@@ -295,53 +295,53 @@ __global__ void __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2))) ge
   gemm_body<T, A_KMAJ, B_KMAJ, LOWER, false>(g);
 }
 
-// The 16 steps j = 16 JB .. 16 JB + 15 of potrf_inv_kernel.  JB is a template parameter so
+// The TS steps j = TS JB .. TS JB + TS - 1 of potrf_inv_kernel.  JB is a template parameter so
 // that which register groups take part is known at compile time (rows a >= JB; L columns
 // b >= JB; X columns b <= JB) and the register arrays are only indexed statically.
-template <typename T, int NB, int JB>
-__device__ __forceinline__ void potrf_steps(T (&Lr)[NB / 16][NB / 16], T (&Xr)[NB / 16][NB / 16], T (&colj)[2][NB],
+template <typename T, int NB, int TS, int JB>
+__device__ __forceinline__ void potrf_steps(T (&Lr)[NB / TS][NB / TS], T (&Xr)[NB / TS][NB / TS], T (&colj)[2][NB],
                                             T (&rowj)[2][NB], int nb, int tx, int ty) {
-  constexpr int NBK = NB / 16;
-  for (int jl = 0; jl < 16; ++jl) {
-    const int j = 16 * JB + jl, par = jl & 1;
+  constexpr int NBK = NB / TS;
+  for (int jl = 0; jl < TS; ++jl) {
+    const int j = TS * JB + jl, par = jl & 1;
     if (j >= nb) break;
     if (tx == jl) {
 #pragma unroll
-      for (int a = JB; a < NBK; ++a) colj[par][ty + 16 * a] = Lr[a][JB];
+      for (int a = JB; a < NBK; ++a) colj[par][ty + TS * a] = Lr[a][JB];
     }
     if (ty == jl) {
 #pragma unroll
-      for (int b = 0; b <= JB; ++b) rowj[par][tx + 16 * b] = Xr[JB][b];
+      for (int b = 0; b <= JB; ++b) rowj[par][tx + TS * b] = Xr[JB][b];
     }
     __syncthreads();
     // unconditional LDS reads (a read under a lane condition becomes a branch with its own wait)
     T lij[NBK], fl[NBK], fx[NBK];
     const T djj = colj[par][j];
 #pragma unroll
-    for (int a = JB; a < NBK; ++a) lij[a] = colj[par][ty + 16 * a];
+    for (int a = JB; a < NBK; ++a) lij[a] = colj[par][ty + TS * a];
 #pragma unroll
-    for (int b = JB; b < NBK; ++b) fl[b] = colj[par][tx + 16 * b];
+    for (int b = JB; b < NBK; ++b) fl[b] = colj[par][tx + TS * b];
 #pragma unroll
-    for (int b = 0; b <= JB; ++b) fx[b] = rowj[par][tx + 16 * b];
+    for (int b = 0; b <= JB; ++b) fx[b] = rowj[par][tx + TS * b];
     const T ljj = sqrt(djj);
     const T inv = static_cast<T>(1) / ljj;
 #pragma unroll
-    for (int a = JB; a < NBK; ++a) lij[a] = (ty + 16 * a > j) ? lij[a] * inv : static_cast<T>(0);
+    for (int a = JB; a < NBK; ++a) lij[a] = (ty + TS * a > j) ? lij[a] * inv : static_cast<T>(0);
 #pragma unroll
-    for (int b = JB; b < NBK; ++b) fl[b] = (tx + 16 * b > j) ? fl[b] * inv : static_cast<T>(0);
+    for (int b = JB; b < NBK; ++b) fl[b] = (tx + TS * b > j) ? fl[b] * inv : static_cast<T>(0);
 #pragma unroll
-    for (int b = 0; b <= JB; ++b) fx[b] = (tx + 16 * b <= j) ? fx[b] * inv : static_cast<T>(0);
+    for (int b = 0; b <= JB; ++b) fx[b] = (tx + TS * b <= j) ? fx[b] * inv : static_cast<T>(0);
     // the owners finish column j of L and row j of X
     if (tx == jl) {
 #pragma unroll
       for (int a = JB; a < NBK; ++a) {
-        const int i = ty + 16 * a;
+        const int i = ty + TS * a;
         Lr[a][JB] = (i == j) ? ljj : ((i > j) ? lij[a] : Lr[a][JB]);
       }
     }
     if (ty == jl) {
 #pragma unroll
-      for (int b = 0; b <= JB; ++b) Xr[JB][b] = (tx + 16 * b <= j) ? fx[b] : Xr[JB][b];
+      for (int b = 0; b <= JB; ++b) Xr[JB][b] = (tx + TS * b <= j) ? fx[b] : Xr[JB][b];
     }
 #pragma unroll
     for (int a = JB; a < NBK; ++a) {
@@ -351,45 +351,52 @@ __device__ __forceinline__ void potrf_steps(T (&Lr)[NB / 16][NB / 16], T (&Xr)[N
       for (int b = 0; b <= JB; ++b) Xr[a][b] -= lij[a] * fx[b];
     }
   }
-  if constexpr (JB + 1 < NBK) potrf_steps<T, NB, JB + 1>(Lr, Xr, colj, rowj, nb, tx, ty);
+  if constexpr (JB + 1 < NBK) potrf_steps<T, NB, TS, JB + 1>(Lr, Xr, colj, rowj, nb, tx, ty);
 }
 
 // Cholesky of one NB x NB diagonal block together with the inverse of its factor, one
-// workgroup, right-looking, the whole block in registers: thread (ty, tx) of a 16 x 16 layout
-// owns the elements (ty + 16 a, tx + 16 b) of L and of X = L^-1.  Step j: the owners publish
+// workgroup, right-looking, the whole block in registers: thread (ty, tx) of a TS x TS layout
+// owns the elements (ty + TS a, tx + TS b) of L and of X = L^-1.  Step j: the owners publish
 // column j of L and row j of X (unscaled) through LDS, one barrier, then every thread applies
 //   L[i][c] -= L[i][j] L[c][j]  (j < c, j < i)      X[i][c] -= L[i][j] X[j][c]  (c <= j < i)
-// to its own registers; 16-row / 16-column groups that lie entirely outside the active region
+// to its own registers; TS-row / TS-column groups that lie entirely outside the active region
 // are skipped with uniform branches.  (A version that kept the block in LDS spent 340 us per
 // 128-block on address arithmetic and LDS round trips; the Cholesky was 75 % potrf time.)
-template <typename T, int NB>
-__global__ void __launch_bounds__(256) potrf_inv_kernel(T *G, size_t ldg, int nb, T *Winv, size_t ldw) {
-  constexpr int NBK = NB / 16;
+// TS = 16 (shipped): 256 threads with (NB / 16)^2 elements of each matrix; TS = 32: 1024 threads (16 wavefronts, four per
+// SIMD) with a quarter of the per-step arithmetic each -- same bits, measured slower (kPotrfTS below).
+template <typename T, int NB, int TS>
+__global__ void __launch_bounds__(TS * TS) potrf_inv_kernel(T *G, size_t ldg, int nb, T *Winv, size_t ldw) {
+  constexpr int NBK = NB / TS;
+  static_assert(NB % TS == 0 && (TS == 16 || TS == 32), "thread layout");
   __shared__ T colj[2][NB], rowj[2][NB];
   const int t = threadIdx.x;
-  const int tx = t & 15, ty = t >> 4;
+  const int tx = t % TS, ty = t / TS;
   T Lr[NBK][NBK], Xr[NBK][NBK];
 #pragma unroll
   for (int a = 0; a < NBK; ++a)
 #pragma unroll
     for (int b = 0; b < NBK; ++b) {
-      const int i = ty + 16 * a, c = tx + 16 * b;
+      const int i = ty + TS * a, c = tx + TS * b;
       const T unit = (i == c) ? static_cast<T>(1) : static_cast<T>(0);
       Lr[a][b] = (i < nb && c <= i) ? G[static_cast<size_t>(i) * ldg + c] : unit;
       Xr[a][b] = unit;
     }
-  potrf_steps<T, NB, 0>(Lr, Xr, colj, rowj, nb, tx, ty);
+  potrf_steps<T, NB, TS, 0>(Lr, Xr, colj, rowj, nb, tx, ty);
 #pragma unroll
   for (int a = 0; a < NBK; ++a)
 #pragma unroll
     for (int b = 0; b < NBK; ++b) {
-      const int i = ty + 16 * a, c = tx + 16 * b;
+      const int i = ty + TS * a, c = tx + TS * b;
       if (i < nb && c <= i) {
         G[static_cast<size_t>(i) * ldg + c] = Lr[a][b];
         Winv[static_cast<size_t>(i) * ldw + c] = Xr[a][b];
       }
     }
 }
+#ifndef POGS_POTRF_TS   // (A / B builds; 32 = 1024 threads was measured in round 6 and is slower: the 16-wavefront barrier of
+#define POGS_POTRF_TS 16   //  every step costs more than the quarter of the arithmetic saves -- Cholesky 12.28 -> 13.4 ms at C2)
+#endif
+constexpr int kPotrfTS = POGS_POTRF_TS;
 
 template <typename T>
 __global__ void __launch_bounds__(256) transpose_kernel(const T *in, size_t ld_in, int rows, int cols, T *out,
@@ -915,7 +922,7 @@ void cholesky_lower(T *G, size_t ldg, int n, T *W, size_t ldw, hipStream_t s) {
   auto factor_panel = [&](int o, int nb) {   // diagonal block + the panel below it; returns the rows below
     T *Gd = G + static_cast<size_t>(o) * ldg + o;
     T *Wd = W + static_cast<size_t>(o) * ldw + o;
-    hipLaunchKernelGGL((potrf_inv_kernel<T, NB>), dim3(1), dim3(256), 0, s, Gd, ldg, nb, Wd, ldw);
+    hipLaunchKernelGGL((potrf_inv_kernel<T, NB, kPotrfTS>), dim3(1), dim3(kPotrfTS * kPotrfTS), 0, s, Gd, ldg, nb, Wd, ldw);
     const int rem = n - o - nb;
     if (rem > 0) {
       T *L21 = G + static_cast<size_t>(o + nb) * ldg + o;
