@@ -24,13 +24,13 @@ t0 = time.time()
 s = pogs_amd.Solver(A.data_ptr(), dtype=np.float32, shape=(m, n), device_ptr=True, profile=True)
 t1 = time.time()
 f, gg = G.lasso_functions(b, 0.1, n)
-r = s.solve(f, gg, verbose=2)
+r = s.solve(f, gg, verbose=int(os.environ.get("QC_VERBOSE", "0")))
 t2 = time.time()
 st = s.stats()
 print(json.dumps({"create_s": t1 - t0, "solve_s": t2 - t1, "status": r["status"], "iters": r["iterations"],
                   "optval": r["optval"], **st}, indent=1))
 it = st["iterations"]
-print("it/s", it / st["t_loop_s"], "ms/iter", 1e3 * st["t_loop_s"] / it, "spec hits/misses", st.get("spec_hits"), st.get("spec_misses"))
+print("fronts_ahead", st.get("fronts_ahead"), "noops", st.get("fronts_ahead_noops")); print("it/s", it / st["t_loop_s"], "ms/iter", 1e3 * st["t_loop_s"] / it, "spec hits/misses", st.get("spec_hits"), st.get("spec_misses"))
 if st["stream_launches"]:
     avg = st["stream_ms"] / st["stream_launches"]
     print("stream kernel avg ms", avg, "GB/s", st["stream_bytes"] / st["stream_launches"] / (avg * 1e-3) / 1e9)
