@@ -202,7 +202,11 @@ int run(int m, int n, int reps, int table) {
   for (int round = 0; round < 2; ++round) {
     printf("---- round %d\n", round);
     if constexpr (NV == 5) {
-      if (table == 4) {
+      if (table == 5) {
+        // table 5: the same kernel at two and at three workgroups per CU, for a counter run (rocprofv3 --pmc ...)
+        ROWS("B  rows  R2 dot+acc     SkRowOp            (two per CU)", 2, true, true, false, SkRowOp<T>, sk1, 2 * ncu);
+        ROWS("B3 rows  R2 dot+acc     SkRowOp            (three per CU)", 2, true, true, false, SkRowOp<T>, sk1, 3 * ncu);
+      } else if (table == 4) {
         // table 4: the functor on a wavefront of its own, the column sums one step late (stream_rows2_fw_kernel)
         ROWS("A  rows  R2 dot+acc SQ  SkRowOp            (Sinkhorn-Knopp's pass)", 2, true, true, true, SkRowOp<T>, sk1, 2 * ncu);
         ROWS2("H2 rows2 R2 2 dot 2 acc Sk2Op              (two per CU)", 2, 2, 2, Sk2Op<T>, sk2, 2 * ncu);
