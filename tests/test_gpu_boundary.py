@@ -2,6 +2,9 @@
 the non-convex-coefficient warning and clamp, the verbose summary, error returns instead of
 faults, and the device a handle lives on."""
 import ctypes
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -10,6 +13,7 @@ import oracle_binding as ob
 from helpers import relerr, soa
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 def _pogs():
@@ -358,3 +362,28 @@ def test_broadcast_coefficients_give_the_array_paths_bits(kind):
         g4.c
         r3, r4 = s.solve(f, g3), s.solve(f, g4)
         assert r3["status"] == r4["status"] and np.array_equal(r3["x"], r4["x"])
+
+
+def test_a_test_transport_id_is_refused_without_the_plug_in():
+    """The in-process / shared-memory communicators are NOT in libpogs_amd.so (round 6): a unique id that starts with
+    `POGS` is served by the shared object POGS_AMD_TRANSPORT_PLUGIN names and refused -- with a message that says so --
+    when the variable is not set.  (A fresh process: the plug-in table is loaded once per process.)"""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+os.environ.pop("POGS_AMD_TRANSPORT_PLUGIN", None)
+import numpy as np
+import pogs_amd
+A = np.random.default_rng(0).standard_normal((64, 8)).astype(np.float32)
+uid = b"POGSLOCAL:refused".ljust(128, b"\0")
+try:
+    pogs_amd.Solver(A, dtype=np.float32, dist=(0, 1, 64, uid))
+    print("CREATED")
+except Exception as e:
+    print("REFUSED", str(e))
+""" % ROOT
+    env = dict(os.environ)
+    env.pop("POGS_AMD_TRANSPORT_PLUGIN", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    out = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:]
+    assert out.startswith("REFUSED") and "POGS_AMD_TRANSPORT_PLUGIN" in out, (out, r.stderr[-800:])
