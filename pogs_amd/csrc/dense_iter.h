@@ -28,6 +28,8 @@ void DenseSolver<T, Tag>::load_problem(const FnHost &f, const FnHost &g, const S
 #endif
   planA_.bpc_override = (POGS_NV5_CHEAP_BPC > 0 && fused_now_ && !fused_logistic_ && !tmode_ && std::is_same<T, float>::value &&
                          planA_.tpb == 256 && planA_.nv == 5) ? POGS_NV5_CHEAP_BPC : 0;
+  planA_.pf = POGS_NV5_PREFETCH != 0 && fused_logistic_ && !tmode_ && std::is_same<T, float>::value && planA_.tpb == 256 &&
+              planA_.nv == 5;
   // scaled copies: h and b shared with the originals (pogs.cpp:608-617)
   launch_scale_objective<T>(f_.view(), fs_.a.p, fs_.c.p, fs_.d.p, fs_.e.p, d_.p, m_, true, s);
   launch_scale_objective<T>(g_.view(), gs_.a.p, gs_.c.p, gs_.d.p, gs_.e.p, e_.p, n_, false, s);

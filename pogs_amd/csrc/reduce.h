@@ -44,6 +44,21 @@ __device__ __forceinline__ float wave_sum(float v) {   // (fp32 sums stay on the
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// (the fp32 tree in the vector ALU, bit for bit wave_sum(float)'s: for the one kernel whose step time is a chain of
+//  LDS round trips -- stream_rows2_pf_kernel, stream.h)
+__device__ __forceinline__ float wave_sum_valu(float v) {
+  auto bits = [](float f) { return __builtin_bit_cast(unsigned, f); };
+  auto flt = [](unsigned u) { return __builtin_bit_cast(float, u); };
+  WavePair32 p = swap_u32<32>(bits(v));
+  v = flt(p.a) + flt(p.b);
+  p = swap_u32<16>(bits(v));
+  v = flt(p.a) + flt(p.b);
+  v += flt(dpp_u32<0x128>(bits(v)));
+  v += flt(dpp_u32<0x124>(bits(v)));
+  v += flt(dpp_u32<0x4E>(bits(v)));
+  v += flt(dpp_u32<0xB1>(bits(v)));
+  return v;
+}
 __device__ __forceinline__ double wave_sum(double v) {
   auto halves = [](double d, unsigned &lo, unsigned &hi) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, d);
@@ -68,6 +83,7 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 // (the same tree through the LDS crossbar: what the two above are tested against, tests/test_gpu_kernels)
+__device__ __forceinline__ double wave_sum_valu(double v) { return wave_sum(v); }
 template <typename T>
 __device__ __forceinline__ T wave_sum_shfl(T v) {
 #pragma unroll

@@ -79,6 +79,7 @@ struct StreamPlan {
   // needs (its serial chain is exposed at two: 0.76 against 0.63 ms per pass at C3) and which by itself costs 8 %:
   // solves whose prox is a few operations run two per CU (0.622 against 0.655 ms; profiles/NOTES_r06.md section 4)
   int bpc_override = 0;
+  bool pf = false;   // 256 x 5, fp32, slow row functor: stream_rows2_pf_kernel (set per solve, dense_iter.h)
 };
 template <typename T> inline int stream_window_cols(const StreamPlan &p) { return p.tpb * p.nv * Vec16<T>::N; }
 template <typename T> inline int stream_windows(const StreamPlan &p, int n_pad) {
@@ -786,6 +787,161 @@ __global__ void __launch_bounds__(TPB, (ND > 0 ? stream2_waves_per_simd(TPB, NV,
   }
 }
 
+// ---------------------------------------------------------------------------
+// stream_rows2_pf_kernel: the one-pass iteration kernel (two dots, two accumulators) with the NEXT tile in flight,
+// for a SLOW row functor at 256 x 5 (the logistic prox: C3).
+// What round 6's phase timing found (scripts/micro/c3_bisect.hip tables 6-8, profiles/NOTES_r06.md section 12): a
+// step of stream_rows2_kernel at this shape is  wait for the tile 27 % | dots 33 % | functor 37 % (1.5 us, one
+// lane per row) | column sums < 1 %,  and "dots" is not arithmetic: it is the ten dependent 16-byte LDS reads of
+// the second dot vector and four six-level ds_bpermute wavefront sums.  Two workgroups per CU stream 8 % faster
+// than three, but then nothing covers the functor.  This form:
+//   * both dot vectors in registers and the wavefront sums in the vector ALU (wave_sum_valu: same tree, same bits):
+//     the dots become ~0.4 us of arithmetic;
+//   * the tile of step k + 1 (and its functor's operands) is requested before step k is reduced: 228 VGPRs, two
+//     workgroups per CU, and the functor of step k runs under the load of step k + 1;
+//   * every tile load UNCONDITIONAL (row and column clamped into the matrix; the dot vectors are zero in the lanes
+//     past n_pad, the functor gives u = 0 to rows past m, and the partials of those lanes are never stored).  A
+//     guarded load is a branch, and behind a branch the compiler cannot count the loads younger than the tile it is
+//     about to use: it emits s_waitcnt vmcnt(0) -- waits for the NEXT tile too -- and the prefetch is gone.  (That is
+//     what the round-3 and round-6 prefetching forms measured as "no gain" had done.)
+// Measured (same boxes, shipped three-per-CU form -> this): 0.639 -> 0.617, 0.652 -> 0.627 ms over C3's matrix.
+// Same arithmetic per row as stream_rows2_kernel; the grid differs (two per CU), so the column partials add the
+// rows in another grouping: compared through the usual tolerances, not bit for bit.
+// ---------------------------------------------------------------------------
+#ifndef POGS_NV5_PREFETCH   // (0: the three-per-CU form for the logistic solves too, as before -- A / B builds)
+#define POGS_NV5_PREFETCH 1
+#endif
+template <typename T, int TPB, int NV, int R, typename Op>
+__global__ void __launch_bounds__(TPB, (2 * (TPB / 64) + 3) / 4) stream_rows2_pf_kernel(StreamArgs2<T> a, Op op) {
+  using V = typename Vec16<T>::type;
+  using Pre = typename Op::Pre;
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int NW = TPB / 64;
+  constexpr int NS = Op::NS > 0 ? Op::NS : 1;
+  constexpr int ND = 2, NA = 2;
+  __shared__ T s_part[2 * R * ND * NW];
+  __shared__ T s_u[2 * R * NA];
+  __shared__ double s_red[NS * NW];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+  V xv[NV], x1v[NV];
+  V acc[NA][NV];
+  int colc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int col = (v * TPB + t) * VEC;
+    const bool in = col < a.n_pad;
+    colc[v] = in ? col : a.n_pad - VEC;
+    xv[v] = in ? *reinterpret_cast<const V *>(a.xin0 + col) : dev::vzero<V>();
+    x1v[v] = in ? *reinterpret_cast<const V *>(a.xin1 + col) : dev::vzero<V>();
+  }
+#pragma unroll
+  for (int q = 0; q < NA; ++q)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[q][v] = dev::vzero<V>();
+  double sacc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sacc[k] = 0.0;
+
+  const int nblk = (a.m + R - 1) / R;
+  int blk = blockIdx.x;
+  V cur[R][NV];
+  Pre pre_cur;
+  if (t < R && blk < nblk && blk * R + t < a.m) pre_cur = op.prefetch(blk * R + t);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int row = blk * R + r;
+    const T *rp = a.A + static_cast<size_t>(row < a.m ? row : a.m - 1) * a.lda;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) cur[r][v] = stream_load<V>(rp + colc[v]);
+  }
+  int slot = 0;
+  for (; blk < nblk; blk += gridDim.x, slot ^= 1) {
+    const int row0 = blk * R;
+    // the next tile of this workgroup: its functor's operands first (waiting for them next step then waits for
+    // nothing younger), then the rows
+    const int nblk_ = blk + gridDim.x, nrow0 = nblk_ * R;
+    Pre pre_nxt;
+    if (t < R && nblk_ < nblk && nrow0 + t < a.m) pre_nxt = op.prefetch(nrow0 + t);
+    V nxt[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = nrow0 + r;
+      const T *rp = a.A + static_cast<size_t>(row < a.m ? row : a.m - 1) * a.lda;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) nxt[r][v] = stream_load<V>(rp + colc[v]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      T s0 = 0, s1 = 0;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        s0 += dev::vdot(cur[r][v], xv[v]);
+        s1 += dev::vdot(cur[r][v], x1v[v]);
+      }
+      s0 = dev::wave_sum_valu(s0);
+      s1 = dev::wave_sum_valu(s1);
+      if (lane == 0) {
+        s_part[((slot * R + r) * ND + 0) * NW + wave] = s0;
+        s_part[((slot * R + r) * ND + 1) * NW + wave] = s1;
+      }
+    }
+    __syncthreads();
+    if (t < R) {
+      const int row = row0 + t;
+      T uu[NA];
+#pragma unroll
+      for (int q = 0; q < NA; ++q) uu[q] = 0;
+      if (row < a.m) {
+        T dots[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+          T s = 0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) s += s_part[((slot * R + t) * ND + d) * NW + w];
+          dots[d] = s;
+        }
+        op.row(row, pre_cur, dots, sacc, uu);
+      }
+#pragma unroll
+      for (int q = 0; q < NA; ++q) s_u[(slot * R + t) * NA + q] = uu[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      T uu[NA];
+#pragma unroll
+      for (int q = 0; q < NA; ++q) uu[q] = s_u[(slot * R + r) * NA + q];
+#pragma unroll
+      for (int q = 0; q < NA; ++q)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dev::vfma(acc[q][v], uu[q], cur[r][v]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) cur[r][v] = nxt[r][v];
+    pre_cur = pre_nxt;
+  }
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    T *out = (q == 0 ? a.col_partials0 : a.col_partials1) + static_cast<size_t>(blockIdx.x) * a.n_pad;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * TPB + t) * VEC;
+      if (col < a.n_pad) *reinterpret_cast<V *>(out + col) = acc[q][v];
+    }
+  }
+  if (Op::NS > 0) {
+    __syncthreads();
+    dev::block_sum<NS, TPB>(sacc, s_red);
+    if (t == 0) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) a.scalar_partials[static_cast<size_t>(blockIdx.x) * NS + k] = sacc[k];
+    }
+  }
+}
+
 // Whether the two-dot / two-accumulator kernel fits the register file for this plan
 // (row tile 4*R*NV + 2 x vectors 8*NV + 2 accumulators 8*NV VGPRs, R = 1).
 inline bool stream2_supported(const StreamPlan &p) {
@@ -809,7 +965,9 @@ inline int stream2_grid(const StreamPlan &p, int m) {
   const int R = stream2_rows<ND, NA>(p);
   const int nblk = (m + R - 1) / R;
   const int gmax = ND > 0 ? (p.tpb == 256 && p.num_cu > 0
-                                 ? p.num_cu * (p.bpc_override > 0 ? p.bpc_override : stream2_blocks_per_cu(256, p.nv, ND, NA))
+                                 ? p.num_cu * ((p.pf && ND == 2 && NA == 2) ? 2
+                                               : p.bpc_override > 0         ? p.bpc_override
+                                                                            : stream2_blocks_per_cu(256, p.nv, ND, NA))
                                  : p.grid_max)
                           : p.grid_dot;   // (the column-sum-only form keeps the two-per-CU grid)
   return nblk < gmax ? (nblk > 0 ? nblk : 1) : gmax;
@@ -819,6 +977,12 @@ template <typename T, int ND, int NA, typename Tag = AllPlans, typename Op>
 void launch_stream2(const StreamPlan &p, const StreamArgs2<T> &a, const Op &op, hipStream_t s) {
   POGS_CHECK(stream2_supported(p), "plan not supported by the two-accumulator kernel");
   const int grid = stream2_grid<ND, NA>(p, a.m);
+  if constexpr (ND == 2 && NA == 2 && std::is_same<T, float>::value && Tag::has(256, 5)) {
+    if (p.pf && p.tpb == 256 && p.nv == 5) {   // (the slow-functor form: next tile in flight, two workgroups per CU)
+      hipLaunchKernelGGL((stream_rows2_pf_kernel<T, 256, 5, stream2_rows_c(2, 5, 2), Op>), dim3(grid), dim3(256), 0, s, a, op);
+      return;
+    }
+  }
 #define POGS_STREAM2_CASE(TPB_, NV_)                                                            \
   if constexpr (Tag::has(TPB_, NV_) && TPB_ != 1024)                                            \
   if (p.tpb == TPB_ && p.nv == NV_) {                                                           \

@@ -386,6 +386,31 @@ def test_logistic_fp32_4000x200():
     _check_solution(A, f, g, got, want, np.float32, tight=False)
 
 
+@pytest.mark.parametrize("m,n", [(6001, 4099), (5403, 5117)])
+def test_the_256x5_streaming_shape_logistic_and_lasso(m, n):
+    """Rows of 1025 .. 1280 float4 vectors run on 256 threads x 5 vectors, two rows per step.  In fp32 a logistic
+    solve takes stream_rows2_pf_kernel there (next tile in flight, every tile load unconditional with the row and
+    the column clamped: stream.h) and a lasso the plain kernel at two workgroups per CU: odd row counts (the last
+    step holds one row and a clamped one) and row lengths that are not a multiple of four (n_pad = n + 1 resp. + 3)
+    nor of the 1280 slots (idle lanes, clamped columns) -- against the oracle."""
+    pogs = _pogs()
+    from pogs_amd import synth
+
+    A, y, _ = synth.dense_logistic(m, n, seed=m % 97, dtype=np.float32, logit_std=2.0)
+    lam = 0.05 * float(np.max(np.abs(A.T @ y)))   # a tenth of the lambda that zeroes the solution
+    got = pogs.solve_logistic(A, y, lam, dtype=np.float32)
+    f, g = pogs.graph.logistic_functions(y, lam, n)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float32)
+    _check_solution(A, f, g, got, want, np.float32, tight=False)
+    # (noise and lambda large enough that the dual, y - b, is not a small difference of two large vectors)
+    A, b, _ = synth.dense_lasso(m, n, seed=n % 89, dtype=np.float32, noise=3.0)
+    lam = 0.05 * float(np.max(np.abs(A.T @ b)))
+    got = pogs.solve_lasso(A, b, lam, dtype=np.float32)
+    f, g = pogs.graph.lasso_functions(b, lam, n)
+    want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float32)
+    _check_solution(A, f, g, got, want, np.float32, tight=False)
+
+
 def test_tight_tolerance_converges_to_same_point():
     """abs_tol = rel_tol = 1e-6: both engines land on the same optimum (<= 1e-5)."""
     pogs = _pogs()
