@@ -891,8 +891,10 @@ def run_config(env, name, with_cpu):
                         "(BASELINE.json configs[%d])" % (m, n, nnz, cfg["lambd"], cfg["cfg_index"]))
             projector = "CGLS (LDS-gather SpMV, device-resident CG loop)"
         else:
-            kernel = "stream_rows2_kernel<FusedIterOp> (the one pass over A per iteration)"
-            kernel_key = "stream_rows2_kernel<%s" % ("double" if cfg["dtype"] == "f64" else "float")
+            # (fp32 logistic solves on rows of 1025 .. 1280 float4 vectors run the prefetching form, stream.h)
+            pf = cfg["kind"] != "dense_lasso" and cfg["dtype"] != "f64" and 1024 < (n + 3) // 4 <= 1280 and m > n
+            kernel = "%s<FusedIterOp> (the one pass over A per iteration)" % ("stream_rows2_pf_kernel" if pf else "stream_rows2_kernel")
+            kernel_key = "stream_rows2_"   # both forms (a solve launches one of them; its element type is the config's)
             one_pass = esize * (m * n + 0.5 * n * n)  # A once + the lower triangle of W = L^-1
             two_pass = esize * (2.0 * m * n + n * n)  # the reference algorithm
             iteration = {"bytes_model": "one-pass engine: A once + the lower triangle of W per iteration",
