@@ -314,6 +314,15 @@ int run(int m, int n, int reps, int table) {
         timed("L2 logistic prox, two per CU", stream_rows2_timed_kernel<T, TPB, NV, 2, 2, 2, FIL>, flog, 2 * ncu, lds2);
         timed("L3 logistic prox, three per CU (shipped shape)", stream_rows2_timed_kernel<T, TPB, NV, 2, 2, 2, FIL>, flog, 3 * ncu, lds2);
         CK(hipFree(stamps));
+      } else if (table == 9) {
+        // table 9: the plain skeleton and the prefetching one with the same (Sinkhorn-Knopp) functor at two workgroups per CU,
+        // for a counter run (scripts/pmc_wg_per_cu.sh 9): why is the prefetching skeleton's floor 7 % higher?
+        ROWS2("H2 rows2 Sk2Op    (two per CU)", 2, 2, 2, Sk2Op<T>, sk2, 2 * ncu);
+        {
+          auto k = stream_rows2_db_kernel<T, TPB, NV, 2, 2, 2, 2, Sk2Op<T>, true, true>;
+          report("D2 db R2+next, x1 in regs, ALU sums, Sk2Op, 2/CU", 2 * ncu, regs_of(k),
+                 tm.run([&] { hipLaunchKernelGGL(k, dim3(2 * ncu), dim3(TPB), lds2, 0, a2, sk2); }, reps));
+        }
       } else if (table == 5) {
         // table 5: the same kernel at two and at three workgroups per CU, for a counter run (rocprofv3 --pmc ...)
         ROWS("B  rows  R2 dot+acc     SkRowOp            (two per CU)", 2, true, true, false, SkRowOp<T>, sk1, 2 * ncu);
