@@ -278,6 +278,17 @@ int run(int m, int n, int reps, int table) {
         //  compute() + commit() the logistic form measured 0.629 against 0.623 and the cheap one 0.640 against 0.648:
         //  nothing, the split was not kept in ops.h; the Sinkhorn-Knopp functor below carries it for the record.)
         DBD("E2 db R2+next, late stores,            Sk2Op,    2/CU", 2, 2, Sk2Op<T>, sk2, 2 * ncu);
+#define DBL(NAME, LATE_, OPT, OP)                                                                                 \
+  {                                                                                                             \
+    auto k = stream_rows2_db_kernel<T, TPB, NV, 2, 2, 2, 2, OPT, true, true, false, LATE_>;                      \
+    report(NAME, 2 * ncu, regs_of(k), tm.run([&] { hipLaunchKernelGGL(k, dim3(2 * ncu), dim3(TPB), lds2, 0, a2, OP); }, reps)); \
+  }
+        DBL("G2 db R2+next requested after the dots, logistic, 2/CU", 1, FIL, flog);
+        DBL("G2 db R2+next requested after the dots, cheap,    2/CU", 1, FIC, fcheap);
+        DBL("G2 db R2+next requested after the dots, Sk2Op,    2/CU", 1, Sk2Op<T>, sk2);
+        DBL("g2 db R2+next one row early, one after the dots, logistic, 2/CU", 2, FIL, flog);
+        DBL("g2 db R2+next one row early, one after the dots, cheap,    2/CU", 2, FIC, fcheap);
+        DBL("g2 db R2+next one row early, one after the dots, Sk2Op,    2/CU", 2, Sk2Op<T>, sk2);
         DBF("D2 db R3+next, x1 in regs, ALU sums, logistic, 2/CU", 3, 2, FIL, flog, 2 * ncu);
         DBF("D2 db R3+next, x1 in regs, ALU sums, cheap,    2/CU", 3, 2, FIC, fcheap, 2 * ncu);
         DBF("D2 db R2+next, x1 in regs, ALU sums, Sk2Op,    2/CU", 2, 2, Sk2Op<T>, sk2, 2 * ncu);

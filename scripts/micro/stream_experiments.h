@@ -40,7 +40,7 @@ __device__ __forceinline__ double wave_sum_alu(double v) { return wave_sum(v); }
 // R rows per step (the tile in flight is R rows too); BPC: workgroups per CU the register budget is held to
 template <typename Op, bool DEFER> struct DeferPost { struct type {}; };
 template <typename Op> struct DeferPost<Op, true> { using type = typename Op::Post; };
-template <typename T, int TPB, int NV, int R, int ND, int NA, int BPC, typename Op, bool X1REG = false, bool ALUSUM = false, bool DEFER = false>
+template <typename T, int TPB, int NV, int R, int ND, int NA, int BPC, typename Op, bool X1REG = false, bool ALUSUM = false, bool DEFER = false, int LATE = 0>
 __global__ void __launch_bounds__(TPB, (BPC * (TPB / 64) + 3) / 4) stream_rows2_db_kernel(StreamArgs2<T> a, Op op) {
   using V = typename Vec16<T>::type;
   using Pre = typename Op::Pre;
@@ -111,13 +111,20 @@ __global__ void __launch_bounds__(TPB, (BPC * (TPB / 64) + 3) / 4) stream_rows2_
     Pre pre_nxt;
     if (t < R && nblk_ < nblk && nrow0 + t < a.m) pre_nxt = op.prefetch(nrow0 + t);
     V nxt[R][NV];
+    // LATE = 0: the whole next tile requested here; 1: after the dots' barrier (in flight under the functor and the column
+    // sums only); 2: its first row here, the others after the barrier
+    auto issue_next = [&](int r0, int r1) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int row = nrow0 + r;
-      const T *rp = a.A + static_cast<size_t>(row < a.m ? row : a.m - 1) * a.lda;
+      for (int r = 0; r < R; ++r) {
+        if (r < r0 || r >= r1) continue;
+        const int row = nrow0 + r;
+        const T *rp = a.A + static_cast<size_t>(row < a.m ? row : a.m - 1) * a.lda;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) nxt[r][v] = stream_load<V>(rp + colc[v]);
-    }
+        for (int v = 0; v < NV; ++v) nxt[r][v] = stream_load<V>(rp + colc[v]);
+      }
+    };
+    if constexpr (LATE == 0) issue_next(0, R);
+    if constexpr (LATE == 2) issue_next(0, 1);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       T s0 = 0, s1 = 0;
@@ -141,6 +148,8 @@ __global__ void __launch_bounds__(TPB, (BPC * (TPB / 64) + 3) / 4) stream_rows2_
       }
     }
     __syncthreads();
+    if constexpr (LATE == 1) issue_next(0, R);
+    if constexpr (LATE == 2) issue_next(1, R);
     if (t < R) {
       const int row = row0 + t;
       T uu[NA];
