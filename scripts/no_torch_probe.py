@@ -1,6 +1,6 @@
-"""Development aid (round 6): does the package work in a process that never imports torch (system HIP runtime)?"""
+"""Development aid: does the package work in a process that never imports torch (system HIP runtime)?"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 t0 = time.time()
 import numpy as np
 import pogs_amd as pogs
