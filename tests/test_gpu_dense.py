@@ -402,6 +402,8 @@ def test_the_256x5_streaming_shape_logistic_and_lasso(m, n):
     f, g = pogs.graph.logistic_functions(y, lam, n)
     want = ob.oracle_solve(A, soa(f), soa(g), dtype=np.float32)
     _check_solution(A, f, g, got, want, np.float32, tight=False)
+    if n != 4099:
+        return   # (the lasso half once: the plain kernel at this shape is also in test_every_streaming_shape_and_type_once)
     # (noise and lambda large enough that the dual, y - b, is not a small difference of two large vectors)
     A, b, _ = synth.dense_lasso(m, n, seed=n % 89, dtype=np.float32, noise=3.0)
     lam = 0.05 * float(np.max(np.abs(A.T @ b)))
