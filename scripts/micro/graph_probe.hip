@@ -92,6 +92,24 @@ int main(int argc, char **argv) {
     for (int k = 0; k < 5; ++k) CK(hipGraphExecKernelNodeSetParams(ge, nodes[k], &np[k]));
     CK(hipGraphLaunch(ge, s));
   });
+  // (d) the look-ahead shape: the three short launches of the NEXT iteration are already in the queue when the host polls; after the
+  //     poll it enqueues only the long one and the publish (and then the front after next) -- the upper bound of what speculating on
+  //     the decision could give
+  for (int k = 0; k < 3; ++k) hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, s, ticks(k), static_cast<int *>(nullptr));
+  run("(d) the three short launches enqueued before the poll", [&](unsigned long long q) {
+    hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, s, ticks(3), static_cast<int *>(nullptr));
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, s, ticks(4), word_dev, q);
+    for (int k = 0; k < 3; ++k) hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, s, ticks(k), static_cast<int *>(nullptr));
+  });
+  CK(hipStreamSynchronize(s));
+  // (e) as (d), but only the FIRST short launch ahead
+  hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, s, ticks(0), static_cast<int *>(nullptr));
+  run("(e) only the first short launch enqueued before the poll", [&](unsigned long long q) {
+    for (int k = 1; k < 4; ++k) hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, s, ticks(k), static_cast<int *>(nullptr));
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, s, ticks(4), word_dev, q);
+    hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, s, ticks(0), static_cast<int *>(nullptr));
+  });
+  CK(hipStreamSynchronize(s));
   run("(a) five launches, again", [&](unsigned long long q) {
     for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(spin_kernel, dim3(256), dim3(256), 0, s, ticks(k), static_cast<int *>(nullptr));
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, s, ticks(4), word_dev, q);
